@@ -1,0 +1,516 @@
+// blend.hip -- multi-band / feather / plain blender, replaces the reference's
+// cv::detail::Blender calls: image_stitching/image_stitching.cpp:1175-1192 (createDefault,
+// setNumBands / setSharpness, prepare), :1218 (feed), :1225 (blend).
+//
+// HBM layout: the panorama accumulators are one 16SC3 Laplacian image and one f32 weight image per
+// pyramid level, tight rows (level widths are multiples of 2 by construction).  A feed never
+// materialises OpenCV's reflect-padded copy of the frame: level 0 of the frame pyramid is a *view*
+// (index maps) of the warped image; only levels >= 1 of the Gaussian pyramids exist in scratch.
+// The Laplacian (pyrUp + saturating subtract), the weight multiply and the accumulate are one
+// kernel per level, and pixels whose weight is exactly 0 are skipped: `dst += (short)(lap * 0)`,
+// `wsum += 0` are no-ops, so the result is bit-identical while the read-modify-write traffic of the
+// panorama drops to the footprint of the frame's non-zero weights.
+#include "common.h"
+#include "dev_math.h"
+#include <algorithm>
+#include <cmath>
+
+#define MIS_MAX_BANDS 16
+
+struct MisBlender {
+    MisContext* ctx = nullptr;
+    int type = MIS_BLEND_MULTI_BAND, actual_bands = 5, num_bands = 0;
+    float sharpness = 0.02f;
+    MisRect roi{0, 0, 0, 0};  // dst_roi_ (padded for multi-band)
+    int fw = 0, fh = 0;       // dst_roi_final_ size
+    int lw[MIS_MAX_BANDS + 1], lh[MIS_MAX_BANDS + 1];
+    int16_t* lap[MIS_MAX_BANDS + 1];
+    float* wgt[MIS_MAX_BANDS + 1];
+    uint8_t* dst_mask = nullptr;  // plain blender
+    void* pano_mem = nullptr;
+    bool prepared = false;
+    // grow-only scratch of one feed: Gaussian pyramids of the frame (levels 1..nb) and of its weights
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+constexpr float WEIGHT_EPS = 1e-5f;
+
+__device__ __forceinline__ int16_t sat_s16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+// Level-0 view of one frame inside its padded tile: copyMakeBorder(BORDER_REFLECT) of the image,
+// copyMakeBorder(BORDER_CONSTANT 0) of mask/255.
+struct FrameView {
+    const int16_t* img;   // 16SC3
+    size_t istride;       // in int16 elements
+    const uint8_t* mask;
+    size_t mstride;
+    int w, h;             // image size
+    int left, top;        // margins of the padded tile
+    int tw, th;           // padded tile size
+};
+
+__device__ __forceinline__ void view_px(const FrameView& v, int tx, int ty, int* c) {
+    const int16_t* p = v.img + (size_t)mis_reflect(ty - v.top, v.h) * v.istride + 3 * (size_t)mis_reflect(tx - v.left, v.w);
+    c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
+}
+__device__ __forceinline__ float view_w(const FrameView& v, int tx, int ty) {
+    int x = tx - v.left, y = ty - v.top;
+    if ((unsigned)x >= (unsigned)v.w || (unsigned)y >= (unsigned)v.h) return 0.f;
+    return (float)v.mask[(size_t)y * v.mstride + x] * (float)(1. / 255.);
+}
+
+// ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101, s16: (v + 128) >> 8 ----
+// one thread per destination pixel (3 channels)
+template <bool FROM_VIEW>
+__global__ __launch_bounds__(256) void pyr_down_s16x3_kernel(FrameView v, const int16_t* src, int sw, int sh, int16_t* dst, int dw, int dh) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int acc[3] = {0, 0, 0};
+    const int kw[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        int sy = mis_reflect101(2 * y - 2 + j, sh);
+        int row[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            int sx = mis_reflect101(2 * x - 2 + i, sw);
+            int c[3];
+            if (FROM_VIEW) view_px(v, sx, sy, c);
+            else { const int16_t* p = src + ((size_t)sy * sw + sx) * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
+            row[0] += kw[i] * c[0]; row[1] += kw[i] * c[1]; row[2] += kw[i] * c[2];
+        }
+        acc[0] += kw[j] * row[0]; acc[1] += kw[j] * row[1]; acc[2] += kw[j] * row[2];
+    }
+    int16_t* d = dst + ((size_t)y * dw + x) * 3;
+    d[0] = (int16_t)((acc[0] + 128) >> 8); d[1] = (int16_t)((acc[1] + 128) >> 8); d[2] = (int16_t)((acc[2] + 128) >> 8);
+}
+
+// ---- pyrDown f32: row = s[2x]*6 + (s[2x-1]+s[2x+1])*4 + s[2x-2] + s[2x+2]; same vertically; * 1/256 ----
+template <bool FROM_VIEW>
+__global__ __launch_bounds__(256) void pyr_down_f32_kernel(FrameView v, const float* src, int sw, int sh, float* dst, int dw, int dh) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int xi[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) xi[i] = mis_reflect101(2 * x - 2 + i, sw);
+    float hr[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        int sy = mis_reflect101(2 * y - 2 + j, sh);
+        float s[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) s[i] = FROM_VIEW ? view_w(v, xi[i], sy) : src[(size_t)sy * sw + xi[i]];
+        hr[j] = ((s[2] * 6.f + (s[1] + s[3]) * 4.f) + s[0]) + s[4];
+    }
+    float r = ((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4];
+    dst[(size_t)y * dw + x] = r * (1.f / 256.f);
+}
+
+// pyrUp of a coarse 16SC3 level evaluated at one fine pixel (fine = 2 x coarse exactly):
+// even: r[x-1] + 6 r[x] + r[x+1], odd: 4 (r[x] + r[x+1]); left/top neighbour of sample 0 is sample 1,
+// right/bottom neighbour of the last sample is the last sample; (v + 32) >> 6.
+__device__ __forceinline__ void pyr_up_at(const int16_t* c, int cw, int ch, int fx, int fy, int* out) {
+    int X = fx >> 1, Y = fy >> 1;
+    int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
+    int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
+    const int16_t* r0 = c + (size_t)ym * cw * 3;
+    const int16_t* r1 = c + (size_t)Y * cw * 3;
+    const int16_t* r2 = c + (size_t)yp * cw * 3;
+    const bool ox = fx & 1, oy = fy & 1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int h0, h1, h2;
+        if (!ox) {
+            h0 = r0[3 * xm + k] + r0[3 * X + k] * 6 + r0[3 * xp + k];
+            h1 = r1[3 * xm + k] + r1[3 * X + k] * 6 + r1[3 * xp + k];
+            h2 = r2[3 * xm + k] + r2[3 * X + k] * 6 + r2[3 * xp + k];
+        } else {
+            h0 = (r0[3 * X + k] + r0[3 * xp + k]) * 4;
+            h1 = (r1[3 * X + k] + r1[3 * xp + k]) * 4;
+            h2 = (r2[3 * X + k] + r2[3 * xp + k]) * 4;
+        }
+        int v = oy ? (h1 + h2) * 4 : (h0 + h1 * 6 + h2);
+        out[k] = (int16_t)((v + 32) >> 6);
+    }
+}
+
+// ---- one pyramid level of a feed: Laplacian = G_i - pyrUp(G_{i+1}) (saturating), then
+// dst += (short)(lap * w), wsum += w over the tile rectangle of the panorama level ----
+template <bool FROM_VIEW, bool LAST>
+__global__ __launch_bounds__(256) void laplace_accumulate_kernel(FrameView v, const int16_t* g, const float* wl, int tw, int th,
+                                                                 const int16_t* coarse, int cw, int ch, int16_t* dlap, float* dwgt,
+                                                                 int pw, int x_tl, int y_tl) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= tw || y >= th) return;
+    float w = FROM_VIEW ? view_w(v, x, y) : wl[(size_t)y * tw + x];
+    if (w == 0.f) return;  // exact no-op contribution
+    int c[3];
+    if (FROM_VIEW) view_px(v, x, y, c);
+    else { const int16_t* p = g + ((size_t)y * tw + x) * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
+    if (!LAST) {
+        int up[3];
+        pyr_up_at(coarse, cw, ch, x, y, up);
+        c[0] = sat_s16(c[0] - up[0]); c[1] = sat_s16(c[1] - up[1]); c[2] = sat_s16(c[2] - up[2]);
+    }
+    size_t o = (size_t)(y_tl + y) * pw + (x_tl + x);
+    int16_t* d = dlap + o * 3;
+    d[0] = (int16_t)(d[0] + (int16_t)((float)c[0] * w));
+    d[1] = (int16_t)(d[1] + (int16_t)((float)c[1] * w));
+    d[2] = (int16_t)(d[2] + (int16_t)((float)c[2] * w));
+    dwgt[o] += w;
+}
+
+// ---- blend(): normalise by the weight sum, collapse the pyramid, emit the final image + mask ----
+__global__ __launch_bounds__(256) void normalize_kernel(int16_t* lap, const float* wgt, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float w = wgt[i] + WEIGHT_EPS;
+    int16_t* d = lap + i * 3;
+    d[0] = (int16_t)((float)d[0] / w); d[1] = (int16_t)((float)d[1] / w); d[2] = (int16_t)((float)d[2] / w);
+}
+
+// fine level (un-normalised) <- sat(pyrUp(coarse, already final) + normalise(fine))
+__global__ __launch_bounds__(256) void collapse_kernel(int16_t* fine, const float* fwgt, int fw, int fh, const int16_t* coarse, int cw, int ch) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= fw || y >= fh) return;
+    size_t o = (size_t)y * fw + x;
+    float w = fwgt[o] + WEIGHT_EPS;
+    int16_t* d = fine + o * 3;
+    int up[3];
+    pyr_up_at(coarse, cw, ch, x, y, up);
+    d[0] = sat_s16(up[0] + (int)(int16_t)((float)d[0] / w));
+    d[1] = sat_s16(up[1] + (int)(int16_t)((float)d[1] / w));
+    d[2] = sat_s16(up[2] + (int)(int16_t)((float)d[2] / w));
+}
+
+// crop to the un-padded roi, dst_mask = wsum0 > eps (or the or-ed mask), zero outside the mask
+__global__ __launch_bounds__(256) void finalize_kernel(const int16_t* lap0, const float* w0, const uint8_t* pmask, int pw, int fw, int fh,
+                                                       int16_t* dst, size_t dstride, uint8_t* dmask, size_t mstride) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= fw || y >= fh) return;
+    size_t o = (size_t)y * pw + x;
+    unsigned m = pmask ? pmask[o] : (w0[o] > WEIGHT_EPS ? 255u : 0u);
+    const int16_t* s = lap0 + o * 3;
+    int16_t* d = (int16_t*)((uint8_t*)dst + (size_t)y * dstride) + 3 * (size_t)x;
+    d[0] = m ? s[0] : (int16_t)0; d[1] = m ? s[1] : (int16_t)0; d[2] = m ? s[2] : (int16_t)0;
+    dmask[(size_t)y * mstride + x] = (uint8_t)m;
+}
+
+// ---- plain Blender::feed ----
+__global__ __launch_bounds__(256) void feed_plain_kernel(const int16_t* img, size_t istride, const uint8_t* mask, size_t mstride, int w, int h,
+                                                         int16_t* dst, uint8_t* dmask, int pw, int dx, int dy) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    unsigned m = mask[(size_t)y * mstride + x];
+    size_t o = (size_t)(dy + y) * pw + dx + x;
+    if (m) {
+        const int16_t* s = img + (size_t)y * istride + 3 * (size_t)x;
+        dst[o * 3] = s[0]; dst[o * 3 + 1] = s[1]; dst[o * 3 + 2] = s[2];
+    }
+    dmask[o] |= (uint8_t)m;
+}
+
+// ---- FeatherBlender: L1 distance transform (exact city-block distance to the nearest zero pixel,
+// clamped at 8192) as two separable min-plus sweeps; rows then columns, one thread per line ----
+__global__ void dist_rows_kernel(const uint8_t* mask, size_t mstride, int w, int h, int* d) {
+    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h) return;
+    const int INF = 8192;
+    int run = INF;
+    int* r = d + (size_t)y * w;
+    for (int x = 0; x < w; x++) { run = mask[(size_t)y * mstride + x] ? min(run + 1, INF) : 0; r[x] = run; }
+    run = INF;
+    for (int x = w - 1; x >= 0; x--) { run = mask[(size_t)y * mstride + x] ? min(run + 1, INF) : 0; r[x] = min(r[x], run); }
+}
+__global__ void dist_cols_weight_kernel(int* d, int w, int h, float sharpness, float* wm) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const int INF = 8192;
+    int run = INF;
+    for (int y = 0; y < h; y++) { int v = d[(size_t)y * w + x]; run = min(run + 1, v); d[(size_t)y * w + x] = run; }
+    run = INF;
+    for (int y = h - 1; y >= 0; y--) {
+        int v = d[(size_t)y * w + x];
+        run = min(run + 1, v);
+        int t = min(run, INF);
+        float wv = (float)t * sharpness;  // createWeightMap: multiply, then THRESH_TRUNC at 1
+        wm[(size_t)y * w + x] = wv > 1.f ? 1.f : wv;
+    }
+}
+__global__ __launch_bounds__(256) void feed_feather_kernel(const int16_t* img, size_t istride, const float* wm, int w, int h, int16_t* dst,
+                                                           float* dwgt, int pw, int dx, int dy) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    float wv = wm[(size_t)y * w + x];
+    size_t o = (size_t)(dy + y) * pw + dx + x;
+    const int16_t* s = img + (size_t)y * istride + 3 * (size_t)x;
+    int16_t* d = dst + o * 3;
+    d[0] = (int16_t)(d[0] + (int16_t)((float)s[0] * wv));
+    d[1] = (int16_t)(d[1] + (int16_t)((float)s[1] * wv));
+    d[2] = (int16_t)(d[2] + (int16_t)((float)s[2] * wv));
+    dwgt[o] += wv;
+}
+
+inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+
+int release(MisBlender* b) {
+    MisContext* ctx = b->ctx;
+    if (b->pano_mem) {
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(b->pano_mem));
+        b->pano_mem = nullptr;
+    }
+    b->prepared = false;
+    return MIS_OK;
+}
+
+int ensure_scratch(MisBlender* b, size_t bytes) {
+    MisContext* ctx = b->ctx;
+    if (bytes <= b->scratch_bytes) return MIS_OK;
+    if (b->scratch) {
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(b->scratch));
+        b->scratch = nullptr; b->scratch_bytes = 0;
+    }
+    MIS_HIP(ctx, hipMalloc(&b->scratch, bytes));
+    b->scratch_bytes = bytes;
+    return MIS_OK;
+}
+
+int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
+    MisContext* ctx = b->ctx;
+    const int nb = b->num_bands, q = 1 << nb, gap = 3 * q;
+    const MisRect& R = b->roi;
+    int brx_roi = R.x + R.width, bry_roi = R.y + R.height;
+    int tnx = std::max(R.x, tl.x - gap), tny = std::max(R.y, tl.y - gap);
+    int bnx = std::min(brx_roi, tl.x + w + gap), bny = std::min(bry_roi, tl.y + h + gap);
+    tnx = R.x + (((tnx - R.x) >> nb) << nb);
+    tny = R.y + (((tny - R.y) >> nb) << nb);
+    int width = bnx - tnx, height = bny - tny;
+    width += (q - width % q) % q;
+    height += (q - height % q) % q;
+    bnx = tnx + width; bny = tny + height;
+    int dy = std::max(bny - bry_roi, 0), dx = std::max(bnx - brx_roi, 0);
+    tnx -= dx; bnx -= dx; tny -= dy; bny -= dy;
+    FrameView v;
+    v.img = (const int16_t*)dimg.data; v.istride = dimg.stride / 2;
+    v.mask = (const uint8_t*)dmask.data; v.mstride = dmask.stride;
+    v.w = w; v.h = h; v.left = tl.x - tnx; v.top = tl.y - tny; v.tw = width; v.th = height;
+    int bottom = bny - tl.y - h, right = bnx - tl.x - w;
+    MIS_CHECK(ctx, v.left >= 0 && v.top >= 0 && bottom >= 0 && right >= 0, MIS_E_INVALID, "frame does not fit the prepared panorama roi");
+
+    // scratch: Gaussian levels 1..nb of the frame (16SC3) and of the weights (f32)
+    int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1];
+    size_t goff[MIS_MAX_BANDS + 1], woff[MIS_MAX_BANDS + 1], total = 0;
+    tw[0] = width; th[0] = height;
+    for (int i = 1; i <= nb; i++) {
+        tw[i] = (tw[i - 1] + 1) / 2; th[i] = (th[i - 1] + 1) / 2;
+        goff[i] = total; total += mis_align_up((size_t)tw[i] * th[i] * 6, 256);
+        woff[i] = total; total += mis_align_up((size_t)tw[i] * th[i] * 4, 256);
+    }
+    int rc = ensure_scratch(b, total ? total : 256);
+    if (rc != MIS_OK) return rc;
+    auto G = [&](int i) { return (int16_t*)((uint8_t*)b->scratch + goff[i]); };
+    auto W = [&](int i) { return (float*)((uint8_t*)b->scratch + woff[i]); };
+    dim3 blk(256);
+    for (int i = 0; i < nb; i++) {
+        dim3 g = grid2d(tw[i + 1], th[i + 1]);
+        if (i == 0) {
+            hipLaunchKernelGGL((pyr_down_s16x3_kernel<true>), g, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], G(1), tw[1], th[1]);
+            hipLaunchKernelGGL((pyr_down_f32_kernel<true>), g, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], W(1), tw[1], th[1]);
+        } else {
+            hipLaunchKernelGGL((pyr_down_s16x3_kernel<false>), g, blk, 0, ctx->stream, v, G(i), tw[i], th[i], G(i + 1), tw[i + 1], th[i + 1]);
+            hipLaunchKernelGGL((pyr_down_f32_kernel<false>), g, blk, 0, ctx->stream, v, W(i), tw[i], th[i], W(i + 1), tw[i + 1], th[i + 1]);
+        }
+    }
+    int y_tl = tny - R.y, x_tl = tnx - R.x, y_br = bny - R.y, x_br = bnx - R.x;
+    for (int i = 0; i <= nb; i++) {
+        int rw = x_br - x_tl, rh = y_br - y_tl;  // equals tw[i] x th[i] (tile corners are multiples of 2^nb)
+        dim3 g = grid2d(rw, rh);
+        const int16_t* coarse = i < nb ? G(i + 1) : nullptr;
+        int cw = i < nb ? tw[i + 1] : 0, ch = i < nb ? th[i + 1] : 0;
+        if (i == 0 && nb > 0)
+            hipLaunchKernelGGL((laplace_accumulate_kernel<true, false>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, coarse, cw, ch,
+                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
+        else if (i == 0)
+            hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, coarse, cw, ch,
+                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
+        else if (i < nb)
+            hipLaunchKernelGGL((laplace_accumulate_kernel<false, false>), g, blk, 0, ctx->stream, v, G(i), W(i), rw, rh, coarse, cw, ch,
+                               b->lap[i], b->wgt[i], b->lw[i], x_tl, y_tl);
+        else
+            hipLaunchKernelGGL((laplace_accumulate_kernel<false, true>), g, blk, 0, ctx->stream, v, G(i), W(i), rw, rh, coarse, cw, ch,
+                               b->lap[i], b->wgt[i], b->lw[i], x_tl, y_tl);
+        x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+int feed_feather(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
+    MisContext* ctx = b->ctx;
+    size_t n = (size_t)w * h;
+    int rc = ensure_scratch(b, mis_align_up(n * 4, 256) * 2);
+    if (rc != MIS_OK) return rc;
+    int* d = (int*)b->scratch;
+    float* wm = (float*)((uint8_t*)b->scratch + mis_align_up(n * 4, 256));
+    hipLaunchKernelGGL(dist_rows_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)dmask.data, dmask.stride, w, h, d);
+    hipLaunchKernelGGL(dist_cols_weight_kernel, dim3((w + 63) / 64), dim3(64), 0, ctx->stream, d, w, h, b->sharpness, wm);
+    hipLaunchKernelGGL(feed_feather_kernel, grid2d(w, h), dim3(256), 0, ctx->stream, (const int16_t*)dimg.data, dimg.stride / 2, wm, w, h,
+                       b->lap[0], b->wgt[0], b->lw[0], tl.x - b->roi.x, tl.y - b->roi.y);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+}  // namespace
+
+extern "C" int mis_blend_config(int blend_type, float blend_strength, int pano_w, int pano_h, int* type_out, int* num_bands, float* sharpness) {
+    if (!type_out || !num_bands || !sharpness) return MIS_E_INVALID;
+    // image_stitching.cpp:1176-1190
+    float blend_width = sqrtf((float)(pano_w * pano_h)) * blend_strength / 100.f;
+    *num_bands = 0; *sharpness = 0.f; *type_out = blend_type;
+    if (blend_width < 1.f) *type_out = MIS_BLEND_NO;
+    else if (blend_type == MIS_BLEND_MULTI_BAND) *num_bands = (int)(ceil(log((double)blend_width) / log(2.)) - 1.);
+    else if (blend_type == MIS_BLEND_FEATHER) *sharpness = 1.f / blend_width;
+    return MIS_OK;
+}
+
+extern "C" int mis_result_roi(const MisPoint* c, const MisSize* s, int n, MisRect* roi) {
+    if (!c || !s || !roi || n < 1) return MIS_E_INVALID;
+    int tlx = INT32_MAX, tly = INT32_MAX, brx = INT32_MIN, bry = INT32_MIN;
+    for (int i = 0; i < n; i++) {
+        tlx = std::min(tlx, c[i].x); tly = std::min(tly, c[i].y);
+        brx = std::max(brx, c[i].x + s[i].width); bry = std::max(bry, c[i].y + s[i].height);
+    }
+    roi->x = tlx; roi->y = tly; roi->width = brx - tlx; roi->height = bry - tly;
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_create(MisContext* ctx, int type, int num_bands, float sharpness, MisBlender** out) {
+    if (!ctx || !out) return MIS_E_INVALID;
+    MIS_CHECK(ctx, type == MIS_BLEND_NO || type == MIS_BLEND_FEATHER || type == MIS_BLEND_MULTI_BAND, MIS_E_INVALID, "unknown blender type %d", type);
+    MisBlender* b = new MisBlender();
+    b->ctx = ctx; b->type = type; b->actual_bands = num_bands; b->sharpness = sharpness;
+    for (int i = 0; i <= MIS_MAX_BANDS; i++) { b->lap[i] = nullptr; b->wgt[i] = nullptr; }
+    *out = b;
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_destroy(MisBlender* b) {
+    if (!b) return MIS_OK;
+    hipSetDevice(b->ctx->device);
+    release(b);
+    if (b->scratch) { hipStreamSynchronize(b->ctx->stream); hipFree(b->scratch); }
+    delete b;
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_num_bands(const MisBlender* b) { return b ? b->num_bands : MIS_E_INVALID; }
+
+extern "C" int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const MisSize* sizes, int n) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, corners && sizes && n >= 1, MIS_E_INVALID, "prepare needs at least one corner/size");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = release(b);
+    if (rc != MIS_OK) return rc;
+    mis_result_roi(corners, sizes, n, &b->roi);
+    MIS_CHECK(ctx, b->roi.width > 0 && b->roi.height > 0, MIS_E_INVALID, "empty panorama roi");
+    b->fw = b->roi.width; b->fh = b->roi.height;
+    b->num_bands = 0;
+    if (b->type == MIS_BLEND_MULTI_BAND) {
+        // MultiBandBlender::prepare: crop unnecessary bands, pad to a multiple of 2^bands
+        double max_len = (double)std::max(b->roi.width, b->roi.height);
+        b->num_bands = std::min(b->actual_bands, (int)ceil(log(max_len) / log(2.0)));
+        MIS_CHECK(ctx, b->num_bands >= 0 && b->num_bands <= MIS_MAX_BANDS, MIS_E_INVALID, "number of bands %d out of range", b->num_bands);
+        int q = 1 << b->num_bands;
+        b->roi.width += (q - b->roi.width % q) % q;
+        b->roi.height += (q - b->roi.height % q) % q;
+    }
+    b->lw[0] = b->roi.width; b->lh[0] = b->roi.height;
+    for (int i = 1; i <= b->num_bands; i++) { b->lw[i] = (b->lw[i - 1] + 1) / 2; b->lh[i] = (b->lh[i - 1] + 1) / 2; }
+    size_t total = 0, loff[MIS_MAX_BANDS + 1], woff[MIS_MAX_BANDS + 1], moff = 0;
+    for (int i = 0; i <= b->num_bands; i++) {
+        size_t px = (size_t)b->lw[i] * b->lh[i];
+        loff[i] = total; total += mis_align_up(px * 6, 256);
+        woff[i] = total; total += mis_align_up(px * 4, 256);
+    }
+    if (b->type == MIS_BLEND_NO) { moff = total; total += mis_align_up((size_t)b->lw[0] * b->lh[0], 256); }
+    MIS_HIP(ctx, hipMalloc(&b->pano_mem, total));
+    MIS_HIP(ctx, hipMemsetAsync(b->pano_mem, 0, total, ctx->stream));
+    for (int i = 0; i <= b->num_bands; i++) {
+        b->lap[i] = (int16_t*)((uint8_t*)b->pano_mem + loff[i]);
+        b->wgt[i] = (float*)((uint8_t*)b->pano_mem + woff[i]);
+    }
+    b->dst_mask = b->type == MIS_BLEND_NO ? (uint8_t*)b->pano_mem + moff : nullptr;
+    b->prepared = true;
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisImage* mask, MisPoint tl) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "feed before prepare");
+    MIS_CHECK(ctx, img && mask && img->dtype == MIS_S16 && img->channels == 3 && mask->dtype == MIS_U8 && mask->channels == 1,
+              MIS_E_INVALID, "feed needs a 16SC3 image and an 8U mask");
+    MIS_CHECK(ctx, img->width == mask->width && img->height == mask->height, MIS_E_INVALID, "image / mask size mismatch");
+    MIS_CHECK(ctx, tl.x >= b->roi.x && tl.y >= b->roi.y && tl.x + img->width <= b->roi.x + b->fw && tl.y + img->height <= b->roi.y + b->fh,
+              MIS_E_INVALID, "frame at (%d,%d) %dx%d lies outside the prepared roi", tl.x, tl.y, img->width, img->height);
+    MIS_CHECK(ctx, img->stride % 2 == 0, MIS_E_INVALID, "16SC3 stride must be even");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    DevImage di, dm;
+    int rc;
+    if ((rc = mis_dev_image_in(ctx, img, &di)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_in(ctx, mask, &dm)) != MIS_OK) return rc;
+    const int w = img->width, h = img->height;
+    if (b->type == MIS_BLEND_MULTI_BAND) rc = feed_multiband(b, di, dm, w, h, tl);
+    else if (b->type == MIS_BLEND_FEATHER) rc = feed_feather(b, di, dm, w, h, tl);
+    else {
+        hipLaunchKernelGGL(feed_plain_kernel, grid2d(w, h), dim3(256), 0, ctx->stream, (const int16_t*)di.data, di.stride / 2,
+                           (const uint8_t*)dm.data, dm.stride, w, h, b->lap[0], b->dst_mask, b->lw[0], tl.x - b->roi.x, tl.y - b->roi.y);
+        rc = hipGetLastError() == hipSuccess ? MIS_OK : mis_set_error(ctx, MIS_E_HIP, "feed_plain launch failed");
+    }
+    int r1 = mis_dev_image_release(ctx, &di), r2 = mis_dev_image_release(ctx, &dm);
+    return rc != MIS_OK ? rc : (r1 != MIS_OK ? r1 : r2);
+}
+
+extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "blend before prepare");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    DevImage dd, dm;
+    int rc;
+    if ((rc = mis_dev_image_out(ctx, dst, b->fw, b->fh, 3, MIS_S16, &dd)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_out(ctx, dmask, b->fw, b->fh, 1, MIS_U8, &dm)) != MIS_OK) return rc;
+    MIS_CHECK(ctx, dd.stride % 2 == 0, MIS_E_INVALID, "16SC3 stride must be even");
+    const int nb = b->num_bands;
+    if (b->type != MIS_BLEND_NO) {
+        // coarsest level (or the single level of the feather blender): plain normalise;
+        // every finer level: normalise fused with the collapse step
+        size_t n = (size_t)b->lw[nb] * b->lh[nb];
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b->lap[nb], b->wgt[nb], n);
+        for (int i = nb; i > 0; i--)
+            hipLaunchKernelGGL(collapse_kernel, grid2d(b->lw[i - 1], b->lh[i - 1]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1],
+                               b->lw[i - 1], b->lh[i - 1], b->lap[i], b->lw[i], b->lh[i]);
+    }
+    hipLaunchKernelGGL(finalize_kernel, grid2d(b->fw, b->fh), dim3(256), 0, ctx->stream, b->lap[0], b->wgt[0], b->dst_mask, b->lw[0], b->fw,
+                       b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride);
+    MIS_HIP(ctx, hipGetLastError());
+    if ((rc = mis_dev_image_commit(ctx, dst, &dd)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_commit(ctx, dmask, &dm)) != MIS_OK) return rc;
+    b->prepared = false;  // the accumulators are consumed (the reference releases them in blend())
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_level_info(const MisBlender* b, int level, int* width, int* height, void** lap_dev, void** weight_dev) {
+    if (!b || level < 0 || level > b->num_bands) return MIS_E_INVALID;
+    if (width) *width = b->lw[level];
+    if (height) *height = b->lh[level];
+    if (lap_dev) *lap_dev = b->lap[level];
+    if (weight_dev) *weight_dev = b->wgt[level];
+    return MIS_OK;
+}

@@ -1,0 +1,49 @@
+// common.h -- internal declarations shared by the libmistitch.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/mistitch.h"
+
+struct MisContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // grow-only scratch for host<->device staging
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+int mis_set_error(MisContext* ctx, int code, const char* fmt, ...);
+
+#define MIS_HIP(ctx, call)                                                                             \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return mis_set_error((ctx), MIS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define MIS_CHECK(ctx, cond, code, ...)                              \
+    do {                                                             \
+        if (!(cond)) return mis_set_error((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+static inline size_t mis_dtype_size(int dtype) { return dtype == MIS_U8 ? 1 : (dtype == MIS_S16 ? 2 : 4); }
+static inline size_t mis_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Device view of an image: either the caller's device pointer or a staged copy of a host buffer.
+struct DevImage {
+    void* data = nullptr;
+    size_t stride = 0;
+    bool owned = false;
+};
+int mis_dev_image_in(MisContext* ctx, const MisImage* img, DevImage* out);   // read access
+int mis_dev_image_release(MisContext* ctx, DevImage* d);
+// Prepare an output image (allocate when data == NULL) and, for host outputs, a device twin.
+int mis_dev_image_out(MisContext* ctx, MisImage* img, int width, int height, int channels, int dtype, DevImage* out);
+int mis_dev_image_commit(MisContext* ctx, const MisImage* img, DevImage* d);  // copy back for host outputs, release

@@ -1,0 +1,121 @@
+// context.hip -- MisContext: device + stream + error text, image staging helpers.
+#include "common.h"
+#include <stdarg.h>
+
+int mis_set_error(MisContext* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" const char* mis_version(void) { return "mistitch 0.1 (gfx950)"; }
+
+extern "C" int mis_context_create(int device, void* stream, MisContext** out) {
+    if (!out) return MIS_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MIS_E_HIP;  // no CPU fallback
+    if (device < 0 || device >= count) return MIS_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
+    MisContext* ctx = new MisContext();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MIS_E_HIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return MIS_OK;
+}
+
+extern "C" int mis_context_destroy(MisContext* ctx) {
+    if (!ctx) return MIS_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MIS_OK;
+}
+
+extern "C" int mis_context_synchronize(MisContext* ctx) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
+}
+
+extern "C" const char* mis_last_error(const MisContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mis_image_free(MisContext* ctx, MisImage* img) {
+    if (!ctx || !img) return MIS_E_INVALID;
+    if (img->data && img->mem == MIS_MEM_DEVICE) {
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(img->data));
+    }
+    img->data = nullptr;
+    return MIS_OK;
+}
+
+int mis_dev_image_in(MisContext* ctx, const MisImage* img, DevImage* out) {
+    MIS_CHECK(ctx, img && img->data && img->width > 0 && img->height > 0, MIS_E_INVALID, "null or empty input image");
+    size_t row = (size_t)img->width * img->channels * mis_dtype_size(img->dtype);
+    MIS_CHECK(ctx, img->stride >= row, MIS_E_INVALID, "stride %zu smaller than a row (%zu)", img->stride, row);
+    if (img->mem == MIS_MEM_DEVICE) {
+        out->data = img->data; out->stride = img->stride; out->owned = false;
+        return MIS_OK;
+    }
+    size_t pitch = mis_align_up(row, 256);
+    MIS_HIP(ctx, hipMalloc(&out->data, pitch * img->height));
+    out->stride = pitch; out->owned = true;
+    MIS_HIP(ctx, hipMemcpy2DAsync(out->data, pitch, img->data, img->stride, row, img->height, hipMemcpyHostToDevice, ctx->stream));
+    return MIS_OK;
+}
+
+int mis_dev_image_release(MisContext* ctx, DevImage* d) {
+    if (d->owned && d->data) {
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(d->data));
+    }
+    d->data = nullptr; d->owned = false;
+    return MIS_OK;
+}
+
+int mis_dev_image_out(MisContext* ctx, MisImage* img, int width, int height, int channels, int dtype, DevImage* out) {
+    MIS_CHECK(ctx, img, MIS_E_INVALID, "null output image");
+    size_t row = (size_t)width * channels * mis_dtype_size(dtype);
+    if (!img->data) {
+        size_t pitch = mis_align_up(row, 256);
+        void* p = nullptr;
+        MIS_HIP(ctx, hipMalloc(&p, pitch * (size_t)height));
+        img->data = p; img->width = width; img->height = height; img->channels = channels;
+        img->stride = pitch; img->dtype = dtype; img->mem = MIS_MEM_DEVICE;
+    }
+    MIS_CHECK(ctx, img->width == width && img->height == height && img->channels == channels && img->dtype == dtype,
+              MIS_E_INVALID, "output image is %dx%dx%d dtype %d, expected %dx%dx%d dtype %d", img->width, img->height,
+              img->channels, img->dtype, width, height, channels, dtype);
+    MIS_CHECK(ctx, img->stride >= row, MIS_E_INVALID, "output stride too small");
+    if (img->mem == MIS_MEM_DEVICE) {
+        out->data = img->data; out->stride = img->stride; out->owned = false;
+        return MIS_OK;
+    }
+    size_t pitch = mis_align_up(row, 256);
+    MIS_HIP(ctx, hipMalloc(&out->data, pitch * (size_t)height));
+    out->stride = pitch; out->owned = true;
+    return MIS_OK;
+}
+
+int mis_dev_image_commit(MisContext* ctx, const MisImage* img, DevImage* d) {
+    if (d->owned && d->data) {
+        size_t row = (size_t)img->width * img->channels * mis_dtype_size(img->dtype);
+        MIS_HIP(ctx, hipMemcpy2DAsync(img->data, img->stride, d->data, d->stride, row, img->height, hipMemcpyDeviceToHost, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(d->data));
+    }
+    d->data = nullptr; d->owned = false;
+    return MIS_OK;
+}

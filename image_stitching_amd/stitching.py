@@ -1,0 +1,568 @@
+"""Host-side mirror of the reference's stitching interface over the libmistitch C ABI.
+
+Names and argument meaning follow the cv::detail objects that image_stitching.cpp's main() drives
+(file:line cited per class).  Images are torch CUDA tensors (zero-copy device pointers) or numpy
+arrays (host buffers staged by the library).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _capi as capi
+
+try:  # torch is plumbing: device memory + streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class MisError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libmistitch error %d: %s" % (code, text))
+        self.code = code
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4")])
+DMATCH_DTYPE = np.dtype([("query_idx", "i4"), ("train_idx", "i4"), ("img_idx", "i4"), ("distance", "f4")])
+
+_TORCH_DT = {}
+if torch is not None:
+    _TORCH_DT = {torch.uint8: capi.U8, torch.int16: capi.S16, torch.float32: capi.F32}
+_NP_DT = {np.dtype(np.uint8): capi.U8, np.dtype(np.int16): capi.S16, np.dtype(np.float32): capi.F32}
+
+
+def _mat9(m):
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(9))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def as_image(a):
+    """torch CUDA tensor / numpy array (H,W) or (H,W,C) -> MisImage describing it in place."""
+    img = capi.MisImage()
+    if torch is not None and isinstance(a, torch.Tensor):
+        if a.dim() == 2:
+            h, w = a.shape
+            c = 1
+            assert a.stride(1) == 1, "rows must be dense"
+        else:
+            h, w, c = a.shape
+            assert a.stride(2) == 1 and a.stride(1) == c, "pixels must be dense within a row"
+        img.data = a.data_ptr()
+        img.stride = a.stride(0) * a.element_size()
+        img.dtype = _TORCH_DT[a.dtype]
+        img.mem = capi.MEM_DEVICE if a.is_cuda else capi.MEM_HOST
+    else:
+        a = np.asarray(a)
+        if a.ndim == 2:
+            h, w = a.shape
+            c = 1
+            assert a.strides[1] == a.itemsize
+        else:
+            h, w, c = a.shape
+            assert a.strides[2] == a.itemsize and a.strides[1] == c * a.itemsize
+        img.data = a.ctypes.data
+        img.stride = a.strides[0]
+        img.dtype = _NP_DT[a.dtype]
+        img.mem = capi.MEM_HOST
+    img.width, img.height, img.channels = w, h, c
+    return img
+
+
+def _empty_image(ctx, h, w, c, tdtype):
+    """Device image with 256-byte aligned row pitch, returned as a (possibly strided) tensor view."""
+    es = torch.empty((), dtype=tdtype).element_size()
+    row = w * c * es
+    pitch = (row + 255) // 256 * 256
+    buf = torch.empty((h, pitch // es), dtype=tdtype, device=ctx.device)
+    v = buf[:, : w * c]
+    return v.view(h, w, c) if c > 1 else v
+
+
+class Context:
+    """One HIP device + one stream (include/mistitch.h: MisContext)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = capi.load()
+        if torch is None:
+            raise ImportError("torch is required for device memory management")
+        self.device = torch.device("cuda", device)
+        if stream is None:
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream().cuda_stream
+        self.stream = stream
+        h = C.c_void_p()
+        rc = self.lib.mis_context_create(device, C.c_void_p(stream), C.byref(h))
+        if rc != capi.MIS_OK:
+            raise MisError(rc, "mis_context_create failed (no HIP device? there is no CPU fallback)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != capi.MIS_OK:
+            raise MisError(rc, self.lib.mis_last_error(self.h).decode())
+
+    def synchronize(self):
+        self.check(self.lib.mis_context_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mis_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# warp: cv::detail::SphericalWarper (image_stitching.cpp:973, :985, :988, :1117, :1138, :1154, :1159)
+def warp_roi(scale, src_size, K, R):
+    """RotationWarper::warpRoi(src_size, K, R) -> (x, y, width, height)."""
+    lib = capi.load()
+    _, kp = _mat9(K)
+    _, rp = _mat9(R)
+    r = capi.MisRect()
+    rc = lib.mis_warp_roi(float(scale), int(src_size[0]), int(src_size[1]), kp, rp, C.byref(r))
+    if rc != capi.MIS_OK:
+        raise MisError(rc, "mis_warp_roi: invalid arguments")
+    return r.x, r.y, r.width, r.height
+
+
+class SphericalWarper:
+    """warper_creator->create(scale) (image_stitching.cpp:973, :1117)."""
+
+    def __init__(self, ctx, scale):
+        self.ctx, self.scale = ctx, float(scale)
+
+    def warpRoi(self, src_size, K, R):
+        return warp_roi(self.scale, src_size, K, R)
+
+    def warp(self, src, K, R, interp=capi.INTER_LINEAR, border=capi.BORDER_REFLECT):
+        """Point warp(src, K, R, interp, border, dst) -> (tl, dst)."""
+        simg = as_image(src)
+        x, y, w, h = warp_roi(self.scale, (simg.width, simg.height), K, R)
+        dst = _empty_image(self.ctx, h, w, simg.channels, torch.uint8)
+        dimg = as_image(dst)
+        ka, kp = _mat9(K)
+        ra, rp = _mat9(R)
+        tl = capi.MisPoint()
+        self.ctx.check(self.ctx.lib.mis_warp_spherical(self.ctx.h, C.byref(simg), self.scale, kp, rp, interp, border,
+                                                       C.byref(dimg), C.byref(tl)))
+        return (tl.x, tl.y), dst
+
+    def warp_fused(self, src_bgr, K, R, roi=None):
+        """Compose-scale step of main(): warp(img, LINEAR, REFLECT) + warp(mask, NEAREST, CONSTANT) +
+        convertTo(CV_16S) (image_stitching.cpp:1154-1164) -> (tl, img_warped_s, mask_warped)."""
+        simg = as_image(src_bgr)
+        x, y, w, h = roi if roi is not None else warp_roi(self.scale, (simg.width, simg.height), K, R)
+        dst = _empty_image(self.ctx, h, w, 3, torch.int16)
+        msk = _empty_image(self.ctx, h, w, 1, torch.uint8)
+        dimg, mimg = as_image(dst), as_image(msk)
+        ka, kp = _mat9(K)
+        ra, rp = _mat9(R)
+        tl = capi.MisPoint()
+        self.ctx.check(self.ctx.lib.mis_warp_spherical_fused(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(dimg),
+                                                             C.byref(mimg), C.byref(tl)))
+        return (tl.x, tl.y), dst, msk
+
+
+# ------------------------------------------------------------------------------------------------
+# blend: cv::detail::Blender / MultiBandBlender / FeatherBlender (image_stitching.cpp:1173-1225)
+def result_roi(corners, sizes):
+    lib = capi.load()
+    n = len(corners)
+    cs = (capi.MisPoint * n)(*[capi.MisPoint(int(c[0]), int(c[1])) for c in corners])
+    ss = (capi.MisSize * n)(*[capi.MisSize(int(s[0]), int(s[1])) for s in sizes])
+    r = capi.MisRect()
+    rc = lib.mis_result_roi(cs, ss, n, C.byref(r))
+    if rc != capi.MIS_OK:
+        raise MisError(rc, "mis_result_roi: invalid arguments")
+    return r.x, r.y, r.width, r.height
+
+
+def blend_config(blend_type, blend_strength, pano_size):
+    """image_stitching.cpp:1176-1190 -> (type, num_bands, sharpness)."""
+    lib = capi.load()
+    t, nb, sh = C.c_int(), C.c_int(), C.c_float()
+    lib.mis_blend_config(int(blend_type), float(blend_strength), int(pano_size[0]), int(pano_size[1]), C.byref(t),
+                         C.byref(nb), C.byref(sh))
+    return t.value, nb.value, sh.value
+
+
+class Blender:
+    """Blender::createDefault(type) (image_stitching.cpp:1175)."""
+
+    def __init__(self, ctx, btype=capi.BLEND_NO, num_bands=5, sharpness=0.02):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mis_blender_create(ctx.h, btype, num_bands, sharpness, C.byref(h)))
+        self.h = h
+        self.type = btype
+        self._size = None
+
+    @staticmethod
+    def createDefault(ctx, btype):
+        return {capi.BLEND_NO: Blender, capi.BLEND_FEATHER: FeatherBlender, capi.BLEND_MULTI_BAND: MultiBandBlender}[btype](ctx)
+
+    def prepare(self, corners, sizes):
+        n = len(corners)
+        cs = (capi.MisPoint * n)(*[capi.MisPoint(int(c[0]), int(c[1])) for c in corners])
+        ss = (capi.MisSize * n)(*[capi.MisSize(int(s[0]), int(s[1])) for s in sizes])
+        self.ctx.check(self.ctx.lib.mis_blender_prepare(self.h, cs, ss, n))
+        x, y, w, h = result_roi(corners, sizes)
+        self._size = (w, h)
+
+    def feed(self, img, mask, tl):
+        i, m = as_image(img), as_image(mask)
+        self.ctx.check(self.ctx.lib.mis_blender_feed(self.h, C.byref(i), C.byref(m), capi.MisPoint(int(tl[0]), int(tl[1]))))
+
+    def blend(self):
+        w, h = self._size
+        dst = _empty_image(self.ctx, h, w, 3, torch.int16)
+        msk = _empty_image(self.ctx, h, w, 1, torch.uint8)
+        d, m = as_image(dst), as_image(msk)
+        self.ctx.check(self.ctx.lib.mis_blender_blend(self.h, C.byref(d), C.byref(m)))
+        return dst, msk
+
+    def level(self, i):
+        """Accumulated pyramid level (host copies) before blend() -- parity tests only."""
+        w, h, lp, wp = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+        self.ctx.check(self.ctx.lib.mis_blender_level_info(self.h, i, C.byref(w), C.byref(h), C.byref(lp), C.byref(wp)))
+        self.ctx.synchronize()
+        n = w.value * h.value
+        lap = np.empty((h.value, w.value, 3), np.int16)
+        wgt = np.empty((h.value, w.value), np.float32)
+        # raw device pointers -> host through torch's runtime binding
+        _memcpy_dtoh(lap, lp.value, n * 6)
+        _memcpy_dtoh(wgt, wp.value, n * 4)
+        return lap, wgt
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mis_blender_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiBandBlender(Blender):
+    """MultiBandBlender + setNumBands (image_stitching.cpp:1180-1184)."""
+
+    def __init__(self, ctx, num_bands=5):
+        super().__init__(ctx, capi.BLEND_MULTI_BAND, num_bands, 0.0)
+
+    def numBands(self):
+        return self.ctx.lib.mis_blender_num_bands(self.h)
+
+
+class FeatherBlender(Blender):
+    """FeatherBlender + setSharpness (image_stitching.cpp:1186-1190)."""
+
+    def __init__(self, ctx, sharpness=0.02):
+        super().__init__(ctx, capi.BLEND_FEATHER, 0, sharpness)
+
+
+_hip = None
+
+
+def _memcpy_dtoh(dst_np, dev_ptr, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = _hip.hipMemcpy(dst_np.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), nbytes, 2)
+    if rc:
+        raise RuntimeError("hipMemcpy D2H failed: %d" % rc)
+
+
+# ------------------------------------------------------------------------------------------------
+# features: ORB::create + computeImageFeatures (image_stitching.cpp:545, :613)
+class ImageFeatures:
+    """cv::detail::ImageFeatures: device-resident keypoints + descriptors."""
+
+    def __init__(self, ctx, raw):
+        self.ctx, self.raw = ctx, raw
+
+    @property
+    def img_idx(self):
+        return self.raw.img_idx
+
+    @img_idx.setter
+    def img_idx(self, v):
+        self.raw.img_idx = int(v)
+
+    @property
+    def img_size(self):
+        return self.raw.img_w, self.raw.img_h
+
+    def __len__(self):
+        return self.raw.n
+
+    def download(self):
+        """-> (keypoints structured array, descriptors (n, cols))"""
+        n = self.raw.n
+        kps = np.zeros(n, KP_DTYPE)
+        dt = np.uint8 if self.raw.desc_dtype == capi.U8 else np.float32
+        desc = np.zeros((n, self.raw.desc_cols), dt)
+        if n:
+            self.ctx.check(self.ctx.lib.mis_features_download(self.ctx.h, C.byref(self.raw), kps.ctypes.data_as(C.c_void_p),
+                                                              desc.ctypes.data_as(C.c_void_p)))
+        return kps, desc
+
+    @staticmethod
+    def upload(ctx, img_size, kps, desc, img_idx=0):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc)
+        raw = capi.MisFeatures()
+        ctx.check(ctx.lib.mis_features_upload(ctx.h, int(img_size[0]), int(img_size[1]), len(kps),
+                                              kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), desc.shape[1],
+                                              _NP_DT[desc.dtype], C.byref(raw)))
+        raw.img_idx = img_idx
+        return ImageFeatures(ctx, raw)
+
+    def close(self):
+        if self.raw is not None and self.ctx.h:
+            self.ctx.lib.mis_features_free(self.ctx.h, C.byref(self.raw))
+        self.raw = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def orb_params(**kw):
+    p = capi.MisOrbParams()
+    capi.load().mis_orb_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class OrbFeatureFinder:
+    """ORB::create(4000, 1.2, 8, 1, 0, 2, HARRIS_SCORE, 40, 20) (image_stitching.cpp:545)."""
+
+    def __init__(self, ctx, max_size, params=None):
+        self.ctx = ctx
+        self.params = params or orb_params()
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mis_orb_create(ctx.h, C.byref(self.params), int(max_size[0]), int(max_size[1]), C.byref(h)))
+        self.h = h
+
+    def detect(self, img):
+        raw = capi.MisFeatures()
+        i = as_image(img)
+        self.ctx.check(self.ctx.lib.mis_orb_detect(self.h, C.byref(i), C.byref(raw)))
+        return ImageFeatures(self.ctx, raw)
+
+    def detect_batch(self, imgs):
+        n = len(imgs)
+        arr = (capi.MisImage * n)(*[as_image(i) for i in imgs])
+        raws = (capi.MisFeatures * n)()
+        self.ctx.check(self.ctx.lib.mis_orb_detect_batch(self.h, arr, n, raws))
+        out = []
+        for k in range(n):
+            r = capi.MisFeatures()
+            C.memmove(C.byref(r), C.byref(raws[k]), C.sizeof(capi.MisFeatures))
+            r.img_idx = k
+            out.append(ImageFeatures(self.ctx, r))
+        return out
+
+    def debug_level(self, level, which):
+        w, h = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.mis_orb_debug_level(self.h, level, which, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.ctx.check(self.ctx.lib.mis_orb_debug_level(self.h, level, which, out.ctypes.data_as(C.c_void_p), C.byref(w), C.byref(h)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mis_orb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def computeImageFeatures(finder, img, img_idx=0):
+    """cv::detail::computeImageFeatures(finder, img, features) + features.img_idx = i (:613-614)."""
+    f = finder.detect(img)
+    f.img_idx = img_idx
+    return f
+
+
+# ------------------------------------------------------------------------------------------------
+# matching: BestOf2NearestMatcher (image_stitching.cpp:647, :653), myLeaveBiggestComponent (:215-278)
+@dataclass
+class MatchesInfo:
+    src_img_idx: int = -1
+    dst_img_idx: int = -1
+    matches: np.ndarray = field(default_factory=lambda: np.zeros(0, DMATCH_DTYPE))
+    inliers_mask: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))
+    num_inliers: int = 0
+    H: np.ndarray = None
+    confidence: float = 0.0
+
+
+def _unpack_mi(mi):
+    n = mi.n_matches
+    out = MatchesInfo(mi.src_img_idx, mi.dst_img_idx)
+    if n and mi.matches:
+        out.matches = np.frombuffer((C.c_char * (n * 16)).from_address(C.addressof(mi.matches.contents)), DMATCH_DTYPE).copy()
+    if n and mi.inliers_mask:
+        out.inliers_mask = np.frombuffer((C.c_char * n).from_address(C.addressof(mi.inliers_mask.contents)), np.uint8).copy()
+    out.num_inliers = mi.num_inliers
+    out.H = np.array(list(mi.H), np.float64).reshape(3, 3) if mi.has_H else None
+    out.confidence = mi.confidence
+    return out
+
+
+def match_params(**kw):
+    p = capi.MisMatchParams()
+    capi.load().mis_match_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class BestOf2NearestMatcher:
+    """makePtr<BestOf2NearestMatcher>(try_cuda, match_conf) (image_stitching.cpp:647)."""
+
+    def __init__(self, ctx, match_conf=0.32, num_matches_thresh1=6, num_matches_thresh2=6):
+        self.ctx = ctx
+        self.params = match_params(match_conf=match_conf, num_matches_thresh1=num_matches_thresh1,
+                                   num_matches_thresh2=num_matches_thresh2)
+
+    def __call__(self, features, rank=0, world_size=1):
+        """(*matcher)(features, pairwise_matches) -> list of n*n MatchesInfo (row-major)."""
+        n = len(features)
+        arr = (capi.MisFeatures * n)()
+        for k, f in enumerate(features):
+            C.memmove(C.byref(arr[k]), C.byref(f.raw), C.sizeof(capi.MisFeatures))
+        mis = (capi.MisMatchesInfo * (n * n))()
+        if world_size == 1:
+            rc = self.ctx.lib.mis_match_all_pairs(self.ctx.h, arr, n, C.byref(self.params), mis)
+        else:
+            rc = self.ctx.lib.mis_match_pairs_sharded(self.ctx.h, arr, n, C.byref(self.params), rank, world_size, mis)
+        self.ctx.check(rc)
+        out = [_unpack_mi(mis[i]) for i in range(n * n)]
+        self.ctx.lib.mis_matches_free(mis, n * n)
+        return out
+
+    def collectGarbage(self):
+        pass
+
+
+def leaveBiggestComponent(pairwise_matches, n, conf_threshold):
+    """myLeaveBiggestComponent (image_stitching.cpp:215-278) on the matcher output -> kept indices."""
+    lib = capi.load()
+    mis = (capi.MisMatchesInfo * (n * n))()
+    for i, m in enumerate(pairwise_matches):
+        mis[i].confidence = m.confidence
+    idx = np.zeros(n, np.int32)
+    k = C.c_int()
+    rc = lib.mis_leave_biggest_component(mis, n, float(conf_threshold), idx.ctypes.data_as(C.c_void_p), C.byref(k))
+    if rc != capi.MIS_OK:
+        raise MisError(rc, "mis_leave_biggest_component")
+    return idx[: k.value].copy()
+
+
+def find_homography(ctx, src, dst, thresh=3.0, max_iters=2000, confidence=0.995):
+    """cv::findHomography(src, dst, mask, RANSAC) on the GPU -> (ok, H, mask)."""
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.ascontiguousarray(dst, np.float32)
+    n = src.shape[0]
+    H = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ok = C.c_int()
+    ctx.check(ctx.lib.mis_find_homography(ctx.h, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), n, thresh,
+                                          max_iters, confidence, H.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p),
+                                          C.byref(ok)))
+    return bool(ok.value), H.reshape(3, 3), mask[:n]
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class StitchConfig:
+    """The reference's globals-as-config (image_stitching.cpp:49-85), same defaults; compose_megapix
+    <= 0 keeps frames at full resolution through warp + blend (the throughput configuration)."""
+    work_megapix: float = -1
+    seam_megapix: float = 0.1
+    compose_megapix: float = 0.4
+    conf_thresh: float = 0.95
+    features_type: str = "orb"
+    match_conf: float = 0.32
+    warp_type: str = "spherical"
+    blend_type: int = capi.BLEND_MULTI_BAND
+    blend_strength: float = 5.0
+
+
+class Stitcher:
+    """The hot-path sequence of main() (image_stitching.cpp:567-1228) for frames already in HBM:
+    features -> pairwise matches (+RANSAC) -> [cameras supplied by the caller] -> compose-scale
+    warp -> blend.  Bundle adjustment, exposure compensation and seam finding are outside the
+    hot path and are not run."""
+
+    def __init__(self, ctx, frame_size, config=None):
+        self.ctx = ctx
+        self.cfg = config or StitchConfig()
+        self.frame_size = frame_size
+        self.finder = OrbFeatureFinder(ctx, frame_size)
+        self.matcher = BestOf2NearestMatcher(ctx, self.cfg.match_conf)
+
+    def features(self, frames):
+        return self.finder.detect_batch(frames)
+
+    def match(self, feats, rank=0, world_size=1):
+        return self.matcher(feats, rank, world_size)
+
+    @staticmethod
+    def warped_image_scale(cameras):
+        """median focal (image_stitching.cpp:884-895)"""
+        focals = sorted(float(c["K"][1][1]) for c in cameras)
+        n = len(focals)
+        if n % 2 == 1:
+            return float(np.float32(focals[n // 2]))
+        return float(np.float32(focals[n // 2 - 1] + focals[n // 2]) * np.float32(0.5))
+
+    def compose(self, frames, cameras, indices=None, blender=None):
+        """Compositing loop (image_stitching.cpp:1086-1225) with compose_scale = 1."""
+        indices = range(len(frames)) if indices is None else indices
+        scale = self.warped_image_scale(cameras)
+        warper = SphericalWarper(self.ctx, scale)
+        w, h = self.frame_size
+        rois = [warper.warpRoi((w, h), cameras[i]["K"], cameras[i]["R"]) for i in indices]
+        corners = [(r[0], r[1]) for r in rois]
+        sizes = [(r[2], r[3]) for r in rois]
+        if blender is None:
+            x, y, pw, ph = result_roi(corners, sizes)
+            btype, bands, sharp = blend_config(self.cfg.blend_type, self.cfg.blend_strength, (pw, ph))
+            if btype == capi.BLEND_MULTI_BAND:
+                blender = MultiBandBlender(self.ctx, bands)
+            elif btype == capi.BLEND_FEATHER:
+                blender = FeatherBlender(self.ctx, sharp)
+            else:
+                blender = Blender(self.ctx)
+        blender.prepare(corners, sizes)
+        for k, i in enumerate(indices):
+            tl, img_s, mask = warper.warp_fused(frames[i], cameras[i]["K"], cameras[i]["R"], rois[k])
+            blender.feed(img_s, mask, tl)
+        return blender.blend()
+
+    def stitch(self, frames, cameras):
+        feats = self.features(frames)
+        pm = self.match(feats)
+        idx = leaveBiggestComponent(pm, len(frames), self.cfg.conf_thresh)
+        result, mask = self.compose(frames, cameras, list(idx))
+        return result, mask, feats, pm, idx

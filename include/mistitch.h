@@ -1,0 +1,188 @@
+/*
+ * mistitch.h -- C ABI of libmistitch.so: the MI355X-native (gfx950 / HIP) stitching hot path.
+ *
+ * The reference (a1q123456/image_stitching) has no FFI of its own: image_stitching.h is an empty
+ * stub (image_stitching/image_stitching.h:1-8) and the hot path is the set of cv::detail calls
+ * main() makes.  Every entry point below replaces one of those call sites (cited per function);
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++ / torch types.
+ *  - every function returns int: MIS_OK (0) or a negative MIS_E_* code; mis_last_error() gives text.
+ *    Nothing throws across the ABI (the reference's OpenCV calls throw cv::Exception instead).
+ *  - one MisContext = one HIP device + one stream; calls on a context are serialised by the caller.
+ *  - image buffers are described by MisImage; `mem` says whether `data` is a host or a device
+ *    pointer.  Device pointers are used in place (zero copy); host pointers are staged through HBM.
+ *  - outputs whose `data` is NULL on entry are allocated by the library (in HBM) and released with
+ *    mis_image_free(); otherwise they must have exactly the required size.
+ *  - there is NO CPU fallback: without a HIP device mis_context_create() fails.
+ */
+#ifndef MISTITCH_H
+#define MISTITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIS_OK 0
+#define MIS_E_INVALID (-1)     /* bad argument */
+#define MIS_E_HIP (-2)         /* HIP runtime error */
+#define MIS_E_NOMEM (-3)
+#define MIS_E_OVERFLOW (-4)    /* an internal candidate buffer was too small for the input */
+#define MIS_E_STATE (-5)       /* call order violated (e.g. feed before prepare) */
+#define MIS_E_UNSUPPORTED (-6)
+
+enum { MIS_MEM_HOST = 0, MIS_MEM_DEVICE = 1 };
+enum { MIS_U8 = 0, MIS_S16 = 1, MIS_F32 = 2 };
+enum { MIS_INTER_NEAREST = 0, MIS_INTER_LINEAR = 1 };          /* cv::INTER_NEAREST / INTER_LINEAR */
+enum { MIS_BORDER_CONSTANT = 0, MIS_BORDER_REFLECT = 2 };       /* cv::BORDER_CONSTANT / BORDER_REFLECT */
+enum { MIS_BLEND_NO = 0, MIS_BLEND_FEATHER = 1, MIS_BLEND_MULTI_BAND = 2 }; /* cv::detail::Blender::NO/FEATHER/MULTI_BAND */
+
+typedef struct MisContext MisContext;
+typedef struct MisOrb MisOrb;
+typedef struct MisBlender MisBlender;
+
+typedef struct { int x, y; } MisPoint;
+typedef struct { int width, height; } MisSize;
+typedef struct { int x, y, width, height; } MisRect;
+
+typedef struct {
+    void* data;
+    int width, height, channels;
+    size_t stride; /* bytes between rows */
+    int dtype;     /* MIS_U8 / MIS_S16 / MIS_F32 */
+    int mem;       /* MIS_MEM_HOST / MIS_MEM_DEVICE */
+} MisImage;
+
+/* ---------------------------------------------------------------- context ------------------- */
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a stream
+ * owned by the context. */
+int mis_context_create(int device, void* stream, MisContext** out);
+int mis_context_destroy(MisContext* ctx);
+int mis_context_synchronize(MisContext* ctx);
+const char* mis_last_error(const MisContext* ctx);
+const char* mis_version(void);
+int mis_image_free(MisContext* ctx, MisImage* img);
+
+/* ---------------------------------------------------------------- features ------------------ */
+/* cv::KeyPoint as ImageFeatures::keypoints carries it (class_id is never read by the reference). */
+typedef struct {
+    float x, y, size, angle, response;
+    int octave;
+} MisKeyPoint;
+
+/* ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType,
+ * patchSize, fastThreshold) -- replaces image_stitching/image_stitching.cpp:545.  Supported:
+ * first_level 0, wta_k 2, score_type 0 (HARRIS_SCORE), patch_size <= 40, nlevels <= 16. */
+typedef struct {
+    int nfeatures;
+    float scale_factor;
+    int nlevels, edge_threshold, first_level, wta_k, score_type, patch_size, fast_threshold;
+} MisOrbParams;
+
+/* cv::detail::ImageFeatures (image_stitching.cpp:537): keypoints + descriptors stay in HBM. */
+typedef struct {
+    int img_idx;
+    int img_w, img_h;
+    int n;                    /* number of keypoints */
+    MisKeyPoint* keypoints;   /* device, n entries */
+    void* descriptors;        /* device, n x desc_cols of desc_dtype (ORB: 32 x u8) */
+    int desc_cols, desc_dtype;
+    void* owner_;             /* internal */
+} MisFeatures;
+
+void mis_orb_default_params(MisOrbParams* p); /* the reference's values (image_stitching.cpp:545) */
+int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_width, int max_height, MisOrb** out);
+int mis_orb_destroy(MisOrb* orb);
+/* computeImageFeatures(finder, img, features[i]) -- replaces image_stitching.cpp:613.
+ * `bgr` is 8UC3 interleaved BGR.  Keypoints are ordered by level, then response (descending), y, x. */
+int mis_orb_detect(MisOrb* orb, const MisImage* bgr, MisFeatures* out);
+/* same, for a batch of frames of one size with a single host synchronisation at the end */
+int mis_orb_detect_batch(MisOrb* orb, const MisImage* bgr, int n_images, MisFeatures* out);
+int mis_features_download(MisContext* ctx, const MisFeatures* f, MisKeyPoint* kps_host, void* desc_host);
+/* wrap caller-provided (host) keypoints/descriptors as device-resident features */
+int mis_features_upload(MisContext* ctx, int img_w, int img_h, int n, const MisKeyPoint* kps_host,
+                        const void* desc_host, int desc_cols, int desc_dtype, MisFeatures* out);
+int mis_features_free(MisContext* ctx, MisFeatures* f);
+/* stage intermediates of the last mis_orb_detect (host copies, for parity tests):
+ * which = 0 gray level (tight w*h), 1 NMS-surviving FAST score map, 2 blurred bordered level */
+int mis_orb_debug_level(MisOrb* orb, int level, int which, uint8_t* host_out, int* width, int* height);
+
+/* ---------------------------------------------------------------- matching ------------------ */
+/* BestOf2NearestMatcher(try_cuda, match_conf, num_matches_thresh1 = 6, num_matches_thresh2 = 6)
+ * -- replaces image_stitching.cpp:647; findHomography defaults (RANSAC, 3.0, 2000, 0.995). */
+typedef struct {
+    float match_conf;
+    int num_matches_thresh1, num_matches_thresh2;
+    double ransac_thresh;
+    int max_iters;
+    double confidence;
+} MisMatchParams;
+
+typedef struct { int query_idx, train_idx, img_idx; float distance; } MisDMatch; /* cv::DMatch */
+
+/* cv::detail::MatchesInfo (image_stitching.cpp:642); arrays are host memory owned by the library */
+typedef struct {
+    int src_img_idx, dst_img_idx;
+    int n_matches;
+    MisDMatch* matches;
+    uint8_t* inliers_mask; /* n_matches entries, NULL when RANSAC did not run */
+    int num_inliers;
+    int has_H;
+    double H[9];
+    double confidence;
+} MisMatchesInfo;
+
+void mis_match_default_params(MisMatchParams* p);
+/* (*matcher)(features, pairwise_matches) -- replaces image_stitching.cpp:653.  `out` is an n*n
+ * row-major array (diagonal entries stay default-initialised, (j,i) mirrors (i,j) with H^-1). */
+int mis_match_all_pairs(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchParams* p, MisMatchesInfo* out);
+/* sharded form: only the pairs with (pair_index % world_size) == rank are matched (others left default) */
+int mis_match_pairs_sharded(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchParams* p, int rank,
+                            int world_size, MisMatchesInfo* out);
+int mis_matches_free(MisMatchesInfo* m, int count);
+/* exact 2-NN (distance, trainIdx) for one direction; results in host memory (stage test hook) */
+int mis_knn2(MisContext* ctx, const MisFeatures* query, const MisFeatures* train, int* idx2_host, float* dist2_host);
+/* cv::findHomography(src, dst, mask, RANSAC, thresh, max_iters, confidence) on host point lists */
+int mis_find_homography(MisContext* ctx, const float* src_xy, const float* dst_xy, int n, double thresh, int max_iters,
+                        double confidence, double H[9], uint8_t* mask, int* ok);
+/* myLeaveBiggestComponent -- replaces image_stitching.cpp:215-278 (host logic on the matcher output) */
+int mis_leave_biggest_component(const MisMatchesInfo* pairwise, int n, float conf_threshold, int* indices, int* n_indices);
+
+/* ---------------------------------------------------------------- warp ---------------------- */
+/* warper->warpRoi(sz, K, R) -- replaces image_stitching.cpp:1138 (K, R: 3x3 f32 row-major) */
+int mis_warp_roi(float scale, int src_width, int src_height, const float K[9], const float R[9], MisRect* roi);
+/* warper->warp(src, K, R, interp, border, dst) -- replaces image_stitching.cpp:985, :988, :1154, :1159.
+ * u8 source with 1 or 3 channels; (INTER_LINEAR, BORDER_REFLECT) or (INTER_NEAREST, BORDER_CONSTANT). */
+int mis_warp_spherical(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9], int interp,
+                       int border, MisImage* dst, MisPoint* tl);
+/* fused compose-scale warp: image (LINEAR, REFLECT) converted to 16SC3 plus the validity mask
+ * (NEAREST, CONSTANT of an all-255 mask) in one pass -- replaces :1154 + :1157-1159 + :1164. */
+int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
+                             MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl);
+
+/* ---------------------------------------------------------------- blend --------------------- */
+/* reference-side blender sizing, image_stitching.cpp:1176-1190: returns the blend type to use in
+ * *type_out and fills num_bands (MULTI_BAND) or sharpness (FEATHER) */
+int mis_blend_config(int blend_type, float blend_strength, int pano_width, int pano_height, int* type_out, int* num_bands,
+                     float* sharpness);
+int mis_result_roi(const MisPoint* corners, const MisSize* sizes, int n, MisRect* roi); /* cv::detail::resultRoi */
+/* Blender::createDefault(type) + setNumBands / setSharpness -- replaces :1175, :1183, :1189 */
+int mis_blender_create(MisContext* ctx, int type, int num_bands, float sharpness, MisBlender** out);
+int mis_blender_destroy(MisBlender* b);
+int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const MisSize* sizes, int n); /* :1192 */
+int mis_blender_num_bands(const MisBlender* b);
+/* blender->feed(img_warped_s [16SC3], mask_warped [8U], corners[i]) -- replaces :1218 */
+int mis_blender_feed(MisBlender* b, const MisImage* img_s16x3, const MisImage* mask_u8, MisPoint tl);
+/* blender->blend(result, result_mask) -- replaces :1225 */
+int mis_blender_blend(MisBlender* b, MisImage* dst_s16x3, MisImage* dst_mask);
+/* accumulated pyramid level before blend() (host copies, parity tests / multi-GPU reduction hooks) */
+int mis_blender_level_info(const MisBlender* b, int level, int* width, int* height, void** lap_dev, void** weight_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
