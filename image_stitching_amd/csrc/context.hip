@@ -23,12 +23,9 @@ extern "C" int mis_context_create(int device, void* stream, MisContext** out) {
     if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
     MisContext* ctx = new MisContext();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MIS_E_HIP; }
-        ctx->own_stream = true;
-    }
+    // NULL is the device's default (null) stream -- the same stream torch uses unless told otherwise,
+    // so library kernels stay ordered with the caller's copies and allocator reuse.
+    ctx->stream = (hipStream_t)stream;
     *out = ctx;
     return MIS_OK;
 }

@@ -241,9 +241,9 @@ class Blender:
         return lap, wgt
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self.ctx.h:   # a destroyed context already released the device
             self.ctx.lib.mis_blender_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -384,9 +384,9 @@ class OrbFeatureFinder:
         return out
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self.ctx.h:
             self.ctx.lib.mis_orb_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -58,8 +58,8 @@ typedef struct {
 } MisImage;
 
 /* ---------------------------------------------------------------- context ------------------- */
-/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a stream
- * owned by the context. */
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL is the device's
+ * default (null) stream.  All work of the context is enqueued on that stream. */
 int mis_context_create(int device, void* stream, MisContext** out);
 int mis_context_destroy(MisContext* ctx);
 int mis_context_synchronize(MisContext* ctx);
