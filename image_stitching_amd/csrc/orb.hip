@@ -1,0 +1,734 @@
+// orb.hip -- ORB detect + describe, replaces the reference's
+// ORB::create(4000, 1.2, 8, 1, 0, 2, HARRIS_SCORE, 40, 20) (image_stitching/image_stitching.cpp:545)
+// and computeImageFeatures(finder, img, features[i]) (:613).
+//
+// Everything stays in HBM between stages and every level of the pyramid is processed by the same
+// launch (grid.z = level), so a frame costs a fixed, small number of launches:
+//   gray -> [resize l = 1..n-1] -> reflect101 borders -> FAST score -> NMS + histogram ->
+//   score cut (retainBest 2N) -> compaction -> Harris -> Harris cut (retainBest N) + canonical
+//   ranking -> keypoint assembly + intensity-centroid angle -> Gaussian blur -> rBRIEF.
+// retainBest() keeps every element >= the N-th best value; as a *set* that is order independent, so
+// the cuts are found with histograms / radix selection and the canonical keypoint order
+// (level, response desc, y, x) is produced by counting ranks -- no sort, no host round trip.
+#include "common.h"
+#include "dev_math.h"
+#include <algorithm>
+#include <cmath>
+
+#define ORB_MAX_LEVELS 16
+#define ORB_BORDER 32
+
+namespace {
+
+struct LevelDesc {
+    int w, h;          // level size
+    int pp;            // pitch of the padded buffers (bytes)
+    int sp;            // pitch of the score / nms maps
+    size_t pad_off;    // offset of the padded gray level inside `pad` / `blur`
+    size_t map_off;    // offset of the level inside `score` / `nms`
+    float scale;       // 1.2^l
+    int nfeat;         // N_l
+    int n2;            // retainBest #1 size (2 N_l with the Harris score)
+    int cap1, cand_off;  // candidate capacity / offset
+    int cap2, fin_off;   // final capacity / offset (per level segment before concatenation)
+    int tab_off;       // offset of the resize coefficient tables (x then y) of this level
+};
+
+struct Levels {
+    int n;
+    int fast_t, patch, half_patch, edge;
+    LevelDesc d[ORB_MAX_LEVELS];
+};
+
+struct Work {  // device pointers of one MisOrb workspace
+    uint8_t *pad, *blur, *score, *nms;
+    int* hist;      // nlevels x 256
+    int* thr;       // nlevels: FAST score cut
+    int* cnt1;      // nlevels: candidates written by the compaction
+    int* cnt2;      // nlevels: final keypoints per level
+    int* flags;     // [0] overflow flag
+    uint32_t* cand_xy;  // x | y << 16
+    float* cand_resp;   // FAST score, then Harris response
+    uint32_t* fin_xy;
+    float* fin_resp;
+    int* tab;       // resize tables: per level [xofs(w) xm1(w) yofs(h) ym1(h)]
+    int* umax;      // half_patch + 2
+    int8_t* pattern;  // 512 x 2
+};
+
+// ---------------------------------------------------------------- K1 gray --------------------
+// cvtColor BGR2GRAY, Q14: (B*1868 + G*9617 + R*4899 + 8192) >> 14, written into the padded level 0
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* dst, int pp) {
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
+    dst[(size_t)(y + ORB_BORDER) * pp + ORB_BORDER + x] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+}
+
+// ---------------------------------------------------------------- K2 pyramid -----------------
+// resize INTER_LINEAR_EXACT u8 (8.8 coefficients from host tables, single final rounding)
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* src, int sw, int sh, int spp, uint8_t* dst, int dw, int dh, int dpp,
+                                                     const int* tab) {
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const int *xo = tab, *xm = tab + dw, *yo = tab + 2 * dw, *ym = tab + 2 * dw + dh;
+    int x0 = xo[x], x1 = x0 + 1 < sw ? x0 + 1 : x0, mx1 = xm[x], mx0 = 256 - mx1;
+    int y0 = yo[y], y1 = y0 + 1 < sh ? y0 + 1 : y0, my1 = ym[y], my0 = 256 - my1;
+    const uint8_t* r0 = src + (size_t)(y0 + ORB_BORDER) * spp + ORB_BORDER;
+    const uint8_t* r1 = src + (size_t)(y1 + ORB_BORDER) * spp + ORB_BORDER;
+    unsigned h0 = (unsigned)r0[x0] * mx0 + (unsigned)r0[x1] * mx1;
+    unsigned h1 = (unsigned)r1[x0] * mx0 + (unsigned)r1[x1] * mx1;
+    dst[(size_t)(y + ORB_BORDER) * dpp + ORB_BORDER + x] = (uint8_t)((h0 * my0 + h1 * my1 + (1u << 15)) >> 16);
+}
+
+// copyMakeBorder(BORDER_REFLECT_101) of every level, one launch (grid.z = level)
+__global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad) {
+    const LevelDesc& d = L.d[blockIdx.z];
+    int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
+    if (px >= pw || py >= ph) return;
+    int x = px - ORB_BORDER, y = py - ORB_BORDER;
+    if ((unsigned)x < (unsigned)d.w && (unsigned)y < (unsigned)d.h) return;
+    uint8_t* p = pad + d.pad_off;
+    p[(size_t)py * d.pp + px] = p[(size_t)(mis_reflect101(y, d.h) + ORB_BORDER) * d.pp + mis_reflect101(x, d.w) + ORB_BORDER];
+}
+
+// ---------------------------------------------------------------- K3 FAST-9/16 ---------------
+// score = largest threshold for which the pixel is still a corner = max(best dark arc, best bright
+// arc) - 1 (cornerScore<16>), 0 when it is not a corner at `t`.
+__device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) {
+    const int v = p[0];
+    // a 9-arc contains one pixel of every opposite pair: reject when both ends of a pair are similar
+    int a = v - p[3 * pp], b = v - p[-3 * pp];
+    if (abs(a) <= t && abs(b) <= t) return 0;
+    int c = v - p[3], e = v - p[-3];
+    if (abs(c) <= t && abs(e) <= t) return 0;
+    int d[16];
+    d[0] = a; d[8] = b; d[4] = c; d[12] = e;
+    d[1] = v - p[3 * pp + 1]; d[2] = v - p[2 * pp + 2]; d[3] = v - p[pp + 3];
+    d[5] = v - p[-pp + 3]; d[6] = v - p[-2 * pp + 2]; d[7] = v - p[-3 * pp + 1];
+    d[9] = v - p[-3 * pp - 1]; d[10] = v - p[-2 * pp - 2]; d[11] = v - p[-pp - 3];
+    d[13] = v - p[pp - 3]; d[14] = v - p[2 * pp - 2]; d[15] = v - p[3 * pp - 1];
+    int A = -512, Bm = 512;  // A = max over arcs of min(d), Bm = min over arcs of max(d)
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        int mn = d[s], mx = d[s];
+#pragma unroll
+        for (int k = 1; k < 9; k++) {
+            int q = d[(s + k) & 15];
+            mn = min(mn, q); mx = max(mx, q);
+        }
+        A = max(A, mn); Bm = min(Bm, mx);
+    }
+    int best = max(A, -Bm);
+    return best > t ? best - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(Levels L, const uint8_t* pad, uint8_t* score) {
+    const LevelDesc& d = L.d[blockIdx.z];
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= d.w || y >= d.h) return;
+    int s = 0;
+    if (x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3)
+        s = fast_score_px(pad + d.pad_off + (size_t)(y + ORB_BORDER) * d.pp + x + ORB_BORDER, d.pp, L.fast_t);
+    score[d.map_off + (size_t)y * d.sp + x] = (uint8_t)s;
+}
+
+// 3x3 strict non-max suppression + per-level histogram of the surviving scores
+__global__ __launch_bounds__(256) void nms_hist_kernel(Levels L, const uint8_t* score, uint8_t* nms, int* hist) {
+    __shared__ int lh[256];
+    const LevelDesc& d = L.d[blockIdx.z];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < d.w && y < d.h) {
+        const uint8_t* s = score + d.map_off + (size_t)y * d.sp + x;
+        int v = s[0], keep = 0;
+        if (v && x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3) {
+            const int sp = d.sp;
+            keep = v > s[-1] && v > s[1] && v > s[-sp - 1] && v > s[-sp] && v > s[-sp + 1] && v > s[sp - 1] && v > s[sp] && v > s[sp + 1];
+            // KeyPointsFilter::runByImageBorder(edgeThreshold)
+            keep = keep && x >= L.edge && x < d.w - L.edge && y >= L.edge && y < d.h - L.edge;
+        }
+        nms[d.map_off + (size_t)y * d.sp + x] = (uint8_t)(keep ? v : 0);
+        if (keep) atomicAdd(&lh[v], 1);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[blockIdx.z * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// retainBest(2 N_l) on the integer FAST score: cut = the n2-th best score (1 = keep everything)
+__global__ void fast_cut_kernel(Levels L, const int* hist, int* thr, int* flags) {
+    int l = threadIdx.x;
+    if (l >= L.n) return;
+    const int* h = hist + l * 256;
+    int total = 0;
+    for (int v = 1; v < 256; v++) total += h[v];
+    int n2 = L.d[l].n2, t = 1;
+    if (n2 == 0) t = 256;  // keep nothing
+    else if (total > n2) {
+        int acc = 0;
+        for (int v = 255; v >= 1; v--) { acc += h[v]; if (acc >= n2) { t = v; break; } }
+    }
+    int kept = 0;
+    for (int v = t < 256 ? t : 256; v < 256; v++) kept += h[v];
+    if (kept > L.d[l].cap1) atomicOr(&flags[0], 1);
+    thr[l] = t;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(Levels L, const uint8_t* nms, const int* thr, int* cnt1, uint32_t* cand_xy, float* cand_resp) {
+    const LevelDesc& d = L.d[blockIdx.z];
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= d.w || y >= d.h) return;
+    int v = nms[d.map_off + (size_t)y * d.sp + x];
+    if (v == 0 || v < thr[blockIdx.z]) return;
+    int i = atomicAdd(&cnt1[blockIdx.z], 1);
+    if (i < d.cap1) {
+        cand_xy[d.cand_off + i] = (uint32_t)x | ((uint32_t)y << 16);
+        cand_resp[d.cand_off + i] = (float)v;
+    }
+}
+
+// ---------------------------------------------------------------- K4 Harris ------------------
+// HarrisResponses(blockSize 7, k 0.04) at the candidate (integer gradients, f32 response)
+__global__ __launch_bounds__(256) void harris_kernel(Levels L, const uint8_t* pad, const int* cnt1, const uint32_t* cand_xy, float* cand_resp) {
+    const LevelDesc& d = L.d[blockIdx.y];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int n = min(cnt1[blockIdx.y], d.cap1);
+    if (i >= n) return;
+    uint32_t xy = cand_xy[d.cand_off + i];
+    int x = xy & 0xffff, y = xy >> 16;
+    const int pp = d.pp;
+    const uint8_t* p0 = pad + d.pad_off + (size_t)(y + ORB_BORDER - 3) * pp + (x + ORB_BORDER - 3);
+    int a = 0, b = 0, c = 0;
+    for (int by = 0; by < 7; by++)
+        for (int bx = 0; bx < 7; bx++) {
+            const uint8_t* p = p0 + by * pp + bx;
+            int Ix = (p[1] - p[-1]) * 2 + (p[-pp + 1] - p[-pp - 1]) + (p[pp + 1] - p[pp - 1]);
+            int Iy = (p[pp] - p[-pp]) * 2 + (p[pp - 1] - p[-pp - 1]) + (p[pp + 1] - p[-pp + 1]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    float fa = (float)a, fb = (float)b, fc = (float)c;
+    float s1 = fa * fb, s2 = fc * fc;
+    float s3 = 0.04f * (fa + fb);
+    s3 = s3 * (fa + fb);
+    cand_resp[d.cand_off + i] = ((s1 - s2) - s3) * scale_sq_sq;
+}
+
+// ascending-orderable key of an f32
+__device__ __forceinline__ uint32_t fkey(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// retainBest(N_l) on the Harris response (ties at the cut kept) + canonical order
+// (response desc, y, x) by counting ranks.  One 1024-thread block per level.
+__global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* cnt1, const uint32_t* cand_xy, const float* cand_resp,
+                                                            int* cnt2, uint32_t* fin_xy, float* fin_resp, int* flags, int use_harris) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix, s_mask;
+    __shared__ int s_k, s_m;
+    __shared__ uint32_t kkey[2048], kxy[2048];
+    const int l = blockIdx.x, t = threadIdx.x;
+    const LevelDesc& d = L.d[l];
+    const int n = min(cnt1[l], d.cap1);
+    const uint32_t* xy = cand_xy + d.cand_off;
+    const float* rs = cand_resp + d.cand_off;
+    const int N = d.nfeat;
+    uint32_t cut = 0;  // keep keys >= cut
+    if (use_harris && n > N && N > 0) {
+        // radix select: the N-th largest key
+        if (t == 0) { s_prefix = 0; s_mask = 0; s_k = N; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            uint32_t prefix = s_prefix, mask = s_mask;
+            for (int i = t; i < n; i += 1024) {
+                uint32_t k = fkey(rs[i]);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (t == 0) {
+                int k = s_k, b = 255;
+                for (; b > 0; b--) { if (hist[b] >= k) break; k -= hist[b]; }
+                s_k = k; s_prefix = prefix | ((uint32_t)b << shift); s_mask = mask | (0xffu << shift);
+            }
+            __syncthreads();
+        }
+        cut = s_prefix;
+    }
+    if (N == 0) { if (t == 0) cnt2[l] = 0; return; }
+    // gather the kept set (unordered)
+    if (t == 0) s_m = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        uint32_t k = fkey(rs[i]);
+        if (k >= cut) {
+            int j = atomicAdd(&s_m, 1);
+            if (j < 2048) { kkey[j] = k; kxy[j] = xy[i]; }
+        }
+    }
+    __syncthreads();
+    int m = s_m;
+    if (m > d.cap2 || m > 2048) { if (t == 0) { atomicOr(&flags[0], 2); cnt2[l] = 0; } return; }
+    // rank = number of kept elements that come first: larger key, then smaller y, then smaller x
+    for (int i = t; i < m; i += 1024) {
+        uint32_t ki = kkey[i], pi = kxy[i];
+        uint32_t yi = (pi >> 16), xi = pi & 0xffff;
+        uint32_t oi = (yi << 16) | xi;
+        int r = 0;
+        for (int j = 0; j < m; j++) {
+            uint32_t kj = kkey[j], pj = kxy[j];
+            uint32_t oj = ((pj >> 16) << 16) | (pj & 0xffff);
+            r += (kj > ki) || (kj == ki && oj < oi);
+        }
+        fin_xy[d.fin_off + r] = pi;
+        uint32_t u = (ki & 0x80000000u) ? (ki & 0x7fffffffu) : ~ki;
+        fin_resp[d.fin_off + r] = __uint_as_float(u);
+    }
+    if (t == 0) cnt2[l] = m;
+}
+
+// ---------------------------------------------------------------- K5 assembly + IC angle -----
+// One wave per keypoint: concatenates the per-level segments, evaluates the intensity centroid on
+// the un-blurred level (ICAngles), writes the cv::KeyPoint (pt scaled to level-0 coordinates).
+__global__ __launch_bounds__(256) void assemble_angle_kernel(Levels L, const uint8_t* pad, const int* cnt2, const uint32_t* fin_xy,
+                                                             const float* fin_resp, const int* umax, MisKeyPoint* kps, uint32_t* kp_lxy,
+                                                             int* n_out, int cap_out) {
+    const int l = blockIdx.y;
+    const LevelDesc& d = L.d[l];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int base = 0;
+    for (int k = 0; k < l; k++) base += cnt2[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && l == L.n - 1) *n_out = min(base + cnt2[l], cap_out);
+    if (i >= cnt2[l] || base + i >= cap_out) return;
+    uint32_t xy = fin_xy[d.fin_off + i];
+    int x = xy & 0xffff, y = xy >> 16;
+    const int pp = d.pp, hp = L.half_patch;
+    const uint8_t* ctr = pad + d.pad_off + (size_t)(y + ORB_BORDER) * pp + (x + ORB_BORDER);
+    int m01 = 0, m10 = 0;
+    const int u = lane - hp;  // lanes 0..2hp cover u = -hp..hp
+    if (lane <= 2 * hp) {
+        m10 = u * ctr[u];
+        for (int v = 1; v <= hp; ++v) {
+            if (abs(u) <= umax[v]) {
+                int vp = ctr[u + v * pp], vm = ctr[u - v * pp];
+                m10 += u * (vp + vm);
+                m01 += v * (vp - vm);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m01 += __shfl_xor(m01, o); m10 += __shfl_xor(m10, o); }
+    if (lane == 0) {
+        MisKeyPoint kp;
+        kp.x = (float)x * d.scale; kp.y = (float)y * d.scale;
+        kp.size = (float)L.patch * d.scale;
+        kp.angle = mis_fast_atan2((float)m01, (float)m10);
+        kp.response = fin_resp[d.fin_off + i];
+        kp.octave = l;
+        kps[base + i] = kp;
+        kp_lxy[base + i] = xy;
+    }
+}
+
+// ---------------------------------------------------------------- K6 blur + rBRIEF ------------
+// GaussianBlur 7x7 sigma 2 (Q8 kernel 18 34 48 56 48 34 18, one rounding at bit 16) of the level
+// interior; the border ring keeps the un-blurred reflected pixels (the reference blurs the ROI of
+// the bordered pyramid in place).  64x16 output tile, separable through LDS.
+__global__ __launch_bounds__(256) void blur_kernel(Levels L, const uint8_t* pad, uint8_t* blur) {
+    __shared__ uint8_t tile[22][72];
+    __shared__ uint16_t hbuf[22][64];
+    const LevelDesc& d = L.d[blockIdx.z];
+    const int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
+    // tiles cover the padded extent; tile origin in padded coordinates
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    if (tx0 >= pw || ty0 >= ph) return;
+    const uint8_t* src = pad + d.pad_off;
+    uint8_t* dst = blur + d.pad_off;
+    for (int i = threadIdx.x; i < 22 * 70; i += 256) {
+        int r = i / 70, c = i % 70;
+        int sy = min(max(ty0 + r - 3, 0), ph - 1), sx = min(max(tx0 + c - 3, 0), pw - 1);
+        tile[r][c] = src[(size_t)sy * d.pp + sx];
+    }
+    __syncthreads();
+    const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
+    for (int i = threadIdx.x; i < 22 * 64; i += 256) {
+        int r = i >> 6, c = i & 63, s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += kq[k] * tile[r][c + k];
+        hbuf[r][c] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    for (int r = threadIdx.x >> 6; r < 16; r += 4) {
+        int px = tx0 + c, py = ty0 + r;
+        if (px >= pw || py >= ph) continue;
+        int x = px - ORB_BORDER, y = py - ORB_BORDER;
+        uint8_t o;
+        if ((unsigned)x < (unsigned)d.w && (unsigned)y < (unsigned)d.h) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s += kq[k] * hbuf[r + k][c];
+            o = (uint8_t)((s + (1 << 15)) >> 16);
+        } else o = tile[r + 3][c + 3];
+        dst[(size_t)py * d.pp + px] = o;
+    }
+}
+
+// computeOrbDescriptors, WTA_K = 2: lane b of a 32-lane half-wave builds byte b (8 tests)
+__global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* blur, const MisKeyPoint* kps, const uint32_t* kp_lxy,
+                                                       const int* n_ptr, const int8_t* pattern, uint8_t* desc) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
+    if (i >= *n_ptr) return;
+    const MisKeyPoint kp = kps[i];
+    const LevelDesc& d = L.d[kp.octave];
+    // the keypoint is already in level-0 coordinates; descriptors scale it back (1/scale) and round
+    const float inv = 1.f / d.scale;
+    const int cx = mis_round_f(kp.x * inv), cy = mis_round_f(kp.y * inv);
+    float ang = kp.angle * (float)(3.14159265358979323846 / 180.f);
+    float sa, ca;
+    mis_sincosf(ang, &sa, &ca);
+    const int pp = d.pp;
+    const uint8_t* ctr = blur + d.pad_off + (size_t)(cy + ORB_BORDER) * pp + (cx + ORB_BORDER);
+    const int8_t* pat = pattern + b * 32;  // 16 points x (x, y)
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        float x0 = (float)pat[4 * bit], y0 = (float)pat[4 * bit + 1], x1 = (float)pat[4 * bit + 2], y1 = (float)pat[4 * bit + 3];
+        int ix0 = mis_round_f(x0 * ca - y0 * sa), iy0 = mis_round_f(x0 * sa + y0 * ca);
+        int ix1 = mis_round_f(x1 * ca - y1 * sa), iy1 = mis_round_f(x1 * sa + y1 * ca);
+        int t0 = ctr[iy0 * pp + ix0], t1 = ctr[iy1 * pp + ix1];
+        val |= (t0 < t1) << bit;
+    }
+    desc[(size_t)i * 32 + b] = (uint8_t)val;
+}
+
+}  // namespace
+
+struct MisOrb {
+    MisContext* ctx = nullptr;
+    MisOrbParams p;
+    int max_w = 0, max_h = 0;
+    int cur_w = 0, cur_h = 0;
+    Levels L;
+    Work w;
+    void* mem = nullptr;
+    size_t pad_bytes = 0, map_bytes = 0;
+    int cand_total = 0, fin_total = 0, tab_total = 0, out_cap = 0;
+    std::vector<int> tab_host;
+};
+
+namespace {
+
+void linear_exact_coeffs(int dlen, int slen, int* ofs, int* m1) {
+    double inv = (double)dlen / (double)slen, scale = 1.0 / inv;
+    for (int i = 0; i < dlen; i++) {
+        double v = ((double)i + 0.5) * scale - 0.5;
+        int iv = (int)floor(v);
+        if (iv < 0) { ofs[i] = 0; m1[i] = 0; }
+        else if (iv >= slen - 1) { ofs[i] = slen - 1; m1[i] = 0; }
+        else { ofs[i] = iv; m1[i] = (int)lrint((v - (double)iv) * 256.0); }
+    }
+}
+
+// level geometry + budgets for an image size (orb.cpp: layer sizes, nfeaturesPerLevel)
+void plan_levels(MisOrb* o, int w, int h) {
+    Levels& L = o->L;
+    const MisOrbParams& p = o->p;
+    L.n = p.nlevels; L.fast_t = p.fast_threshold; L.patch = p.patch_size; L.half_patch = p.patch_size / 2; L.edge = p.edge_threshold;
+    double sf = (double)p.scale_factor;
+    size_t pad_off = 0, map_off = 0;
+    int cand_off = 0, fin_off = 0, tab_off = 0;
+    float factor = (float)(1.0 / sf);
+    float nd = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < L.n; l++) {
+        LevelDesc& d = L.d[l];
+        float sc = (float)pow(sf, (double)l);
+        d.scale = sc;
+        d.w = (int)lrint((double)((float)w / sc));
+        d.h = (int)lrint((double)((float)h / sc));
+        d.pp = (int)mis_align_up((size_t)d.w + 2 * ORB_BORDER, 64);
+        d.sp = (int)mis_align_up((size_t)d.w, 64);
+        d.pad_off = pad_off; pad_off += (size_t)d.pp * (d.h + 2 * ORB_BORDER);
+        d.map_off = map_off; map_off += (size_t)d.sp * d.h;
+        if (l < L.n - 1) { d.nfeat = (int)lrintf(nd); sum += d.nfeat; nd *= factor; }
+        else d.nfeat = std::max(p.nfeatures - sum, 0);
+        d.n2 = p.score_type == 0 ? 2 * d.nfeat : d.nfeat;
+        d.cap1 = 4 * d.n2 + 4096;
+        d.cap2 = std::min(d.nfeat + 128, 2048);
+        d.cand_off = cand_off; cand_off += d.cap1;
+        d.fin_off = fin_off; fin_off += d.cap2;
+        d.tab_off = tab_off; tab_off += 2 * d.w + 2 * d.h;
+    }
+    o->pad_bytes = pad_off; o->map_bytes = map_off; o->cand_total = cand_off; o->fin_total = fin_off; o->tab_total = tab_off;
+    o->tab_host.assign(tab_off, 0);
+    for (int l = 1; l < L.n; l++) {
+        int* t = o->tab_host.data() + L.d[l].tab_off;
+        linear_exact_coeffs(L.d[l].w, L.d[l - 1].w, t, t + L.d[l].w);
+        linear_exact_coeffs(L.d[l].h, L.d[l - 1].h, t + 2 * L.d[l].w, t + 2 * L.d[l].w + L.d[l].h);
+    }
+}
+
+int upload_tables(MisOrb* o) {
+    MisContext* ctx = o->ctx;
+    if (o->tab_total)
+        MIS_HIP(ctx, hipMemcpyAsync(o->w.tab, o->tab_host.data(), sizeof(int) * o->tab_total, hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // tab_host may be rebuilt by the next plan
+    return MIS_OK;
+}
+
+struct FeatOwner { void* mem; };
+
+int alloc_features(MisContext* ctx, int cap, int desc_cols, int desc_dtype, MisFeatures* f) {
+    size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)cap, 256), db = mis_align_up((size_t)cap * desc_cols * mis_dtype_size(desc_dtype), 256);
+    size_t lb = mis_align_up(sizeof(uint32_t) * (size_t)cap, 256);
+    void* mem = nullptr;
+    MIS_HIP(ctx, hipMalloc(&mem, kb + db + lb + 256));
+    f->keypoints = (MisKeyPoint*)mem;
+    f->descriptors = (uint8_t*)mem + kb;
+    f->desc_cols = desc_cols; f->desc_dtype = desc_dtype;
+    f->owner_ = mem;
+    f->n = 0;
+    return MIS_OK;
+}
+
+inline uint32_t* feat_lxy(const MisFeatures* f, int cap) {
+    size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)cap, 256), db = mis_align_up((size_t)cap * f->desc_cols * mis_dtype_size(f->desc_dtype), 256);
+    return (uint32_t*)((uint8_t*)f->owner_ + kb + db);
+}
+inline int* feat_count(const MisFeatures* f, int cap) {
+    size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)cap, 256), db = mis_align_up((size_t)cap * f->desc_cols * mis_dtype_size(f->desc_dtype), 256);
+    size_t lb = mis_align_up(sizeof(uint32_t) * (size_t)cap, 256);
+    return (int*)((uint8_t*)f->owner_ + kb + db + lb);
+}
+
+// enqueue the whole detect + describe path of one frame; no host synchronisation
+int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* out) {
+    MisContext* ctx = o->ctx;
+    const Levels& L = o->L;
+    const Work& W = o->w;
+    hipStream_t st = ctx->stream;
+    const LevelDesc& d0 = L.d[0];
+    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * ORB_MAX_LEVELS + 3 * ORB_MAX_LEVELS), st));  // hist, thr, cnt1, cnt2
+    hipLaunchKernelGGL(gray_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, (const uint8_t*)img.data, img.stride, w, h, W.pad + d0.pad_off, d0.pp);
+    for (int l = 1; l < L.n; l++) {
+        const LevelDesc &s = L.d[l - 1], &d = L.d[l];
+        hipLaunchKernelGGL(resize_kernel, dim3((d.w + 255) / 256, d.h), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
+                           d.h, d.pp, W.tab + d.tab_off);
+    }
+    const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
+    hipLaunchKernelGGL(border_kernel, dim3((pw0 + 255) / 256, ph0, L.n), dim3(256), 0, st, L, W.pad);
+    dim3 gmap((d0.w + 63) / 64, (d0.h + 3) / 4, L.n);
+    hipLaunchKernelGGL(fast_score_kernel, gmap, dim3(256), 0, st, L, W.pad, W.score);
+    hipLaunchKernelGGL(nms_hist_kernel, gmap, dim3(256), 0, st, L, W.score, W.nms, W.hist);
+    hipLaunchKernelGGL(fast_cut_kernel, dim3(1), dim3(64), 0, st, L, W.hist, W.thr, W.flags);
+    hipLaunchKernelGGL(compact_kernel, gmap, dim3(256), 0, st, L, W.nms, W.thr, W.cnt1, W.cand_xy, W.cand_resp);
+    const int use_harris = o->p.score_type == 0;
+    if (use_harris)
+        hipLaunchKernelGGL(harris_kernel, dim3((L.d[0].cap1 + 255) / 256, L.n), dim3(256), 0, st, L, W.pad, W.cnt1, W.cand_xy, W.cand_resp);
+    hipLaunchKernelGGL(select_rank_kernel, dim3(L.n), dim3(1024), 0, st, L, W.cnt1, W.cand_xy, W.cand_resp, W.cnt2, W.fin_xy, W.fin_resp, W.flags,
+                       use_harris);
+    uint32_t* lxy = feat_lxy(out, o->out_cap);
+    int* n_dev = feat_count(out, o->out_cap);
+    hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax,
+                       out->keypoints, lxy, n_dev, o->out_cap);
+    hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 15) / 16, L.n), dim3(256), 0, st, L, W.pad, W.blur);
+    hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur, out->keypoints, lxy, n_dev, W.pattern,
+                       (uint8_t*)out->descriptors);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+int check_image(MisOrb* o, const MisImage* bgr) {
+    MisContext* ctx = o->ctx;
+    MIS_CHECK(ctx, bgr && bgr->data, MIS_E_INVALID, "null image");
+    MIS_CHECK(ctx, bgr->dtype == MIS_U8 && bgr->channels == 3, MIS_E_UNSUPPORTED, "ORB input must be 8UC3 (BGR)");
+    MIS_CHECK(ctx, bgr->width <= o->max_w && bgr->height <= o->max_h && bgr->width >= 64 && bgr->height >= 64, MIS_E_INVALID,
+              "image %dx%d outside the finder's range (64x64 .. %dx%d)", bgr->width, bgr->height, o->max_w, o->max_h);
+    return MIS_OK;
+}
+
+int replan_if_needed(MisOrb* o, int w, int h) {
+    if (w == o->cur_w && h == o->cur_h) return MIS_OK;
+    MIS_HIP(o->ctx, hipStreamSynchronize(o->ctx->stream));
+    plan_levels(o, w, h);
+    o->cur_w = w; o->cur_h = h;
+    return upload_tables(o);
+}
+
+}  // namespace
+
+extern "C" void mis_orb_default_params(MisOrbParams* p) {
+    if (p) *p = MisOrbParams{4000, 1.2f, 8, 1, 0, 2, 0, 40, 20};
+}
+
+extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w, int max_h, MisOrb** out) {
+    if (!ctx || !out) return MIS_E_INVALID;
+    MIS_CHECK(ctx, p, MIS_E_INVALID, "null params");
+    MIS_CHECK(ctx, p->nlevels >= 1 && p->nlevels <= ORB_MAX_LEVELS && p->first_level == 0 && p->wta_k == 2 && p->patch_size >= 2 &&
+                       p->patch_size <= 40 && p->nfeatures >= 1 && p->scale_factor > 1.f && (p->score_type == 0 || p->score_type == 1) &&
+                       p->edge_threshold >= 0 && p->fast_threshold >= 1 && p->fast_threshold < 255,
+              MIS_E_UNSUPPORTED, "unsupported ORB parameters (need first_level 0, wta_k 2, patch <= 40, nlevels <= 16)");
+    MIS_CHECK(ctx, max_w >= 64 && max_h >= 64 && max_w <= 32767 && max_h <= 32767, MIS_E_INVALID, "bad maximum size");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MisOrb* o = new MisOrb();
+    o->ctx = ctx; o->p = *p; o->max_w = max_w; o->max_h = max_h;
+    plan_levels(o, max_w, max_h);
+    o->out_cap = o->fin_total;
+    // one allocation, carved into the workspace
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
+    size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
+    size_t o_hist = carve(sizeof(int) * (256 * ORB_MAX_LEVELS + 3 * ORB_MAX_LEVELS)), o_flags = carve(256);
+    size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
+    size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
+    size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
+    if (hipMalloc(&o->mem, off) != hipSuccess) { delete o; return mis_set_error(ctx, MIS_E_NOMEM, "hipMalloc of %zu bytes failed", off); }
+    uint8_t* m = (uint8_t*)o->mem;
+    Work& W = o->w;
+    W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
+    W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
+    W.flags = (int*)(m + o_flags);
+    W.cand_xy = (uint32_t*)(m + o_cxy); W.cand_resp = (float*)(m + o_cr); W.fin_xy = (uint32_t*)(m + o_fxy); W.fin_resp = (float*)(m + o_fr);
+    W.tab = (int*)(m + o_tab); W.umax = (int*)(m + o_umax); W.pattern = (int8_t*)(m + o_pat);
+    // umax (orb.cpp) and the random BRIEF pattern: patchSize != 31 -> RNG(0x34985739), 512 points
+    int umax[64] = {0};
+    {
+        int hp = p->patch_size / 2, v, v0;
+        int vmax = (int)floor((double)((float)hp * sqrtf(2.f) / 2 + 1));
+        int vmin = (int)ceil((double)((float)hp * sqrtf(2.f) / 2));
+        for (v = 0; v <= vmax; ++v) umax[v] = (int)lrint(sqrt((double)hp * hp - (double)v * v));
+        for (v = hp, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+    }
+    int8_t pat[1024];
+    {
+        uint64_t state = 0x34985739u;
+        auto next = [&]() { state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32); return (uint32_t)state; };
+        int hp = p->patch_size / 2;
+        for (int i = 0; i < 1024; i++) pat[i] = (int8_t)(int)(next() % (uint32_t)(2 * hp + 1) + (uint32_t)(-hp));
+    }
+    hipMemcpyAsync(W.umax, umax, sizeof(umax), hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(W.pattern, pat, sizeof(pat), hipMemcpyHostToDevice, ctx->stream);
+    hipMemsetAsync(W.flags, 0, 256, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    o->cur_w = max_w; o->cur_h = max_h;
+    int rc = upload_tables(o);
+    if (rc != MIS_OK) { hipFree(o->mem); delete o; return rc; }
+    *out = o;
+    return MIS_OK;
+}
+
+extern "C" int mis_orb_destroy(MisOrb* o) {
+    if (!o) return MIS_OK;
+    hipSetDevice(o->ctx->device);
+    hipStreamSynchronize(o->ctx->stream);
+    if (o->mem) hipFree(o->mem);
+    delete o;
+    return MIS_OK;
+}
+
+extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisFeatures* out) {
+    if (!o) return MIS_E_INVALID;
+    MisContext* ctx = o->ctx;
+    MIS_CHECK(ctx, imgs && out && n >= 1, MIS_E_INVALID, "null argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    for (int i = 0; i < n; i++) {
+        if ((rc = check_image(o, &imgs[i])) != MIS_OK) return rc;
+        MIS_CHECK(ctx, imgs[i].width == imgs[0].width && imgs[i].height == imgs[0].height, MIS_E_INVALID, "batch frames must share one size");
+    }
+    if ((rc = replan_if_needed(o, imgs[0].width, imgs[0].height)) != MIS_OK) return rc;
+    std::vector<DevImage> dimg(n);
+    for (int i = 0; i < n; i++) {
+        memset(&out[i], 0, sizeof(MisFeatures));
+        out[i].img_idx = i; out[i].img_w = imgs[i].width; out[i].img_h = imgs[i].height;
+        if ((rc = alloc_features(ctx, o->out_cap, 32, MIS_U8, &out[i])) != MIS_OK) return rc;
+        if ((rc = mis_dev_image_in(ctx, &imgs[i], &dimg[i])) != MIS_OK) return rc;
+        if ((rc = enqueue_detect(o, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK) return rc;
+    }
+    // one synchronisation for the whole batch: counts + overflow flag
+    std::vector<int> counts(n);
+    int flags = 0;
+    for (int i = 0; i < n; i++)
+        MIS_HIP(ctx, hipMemcpyAsync(&counts[i], feat_count(&out[i], o->out_cap), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MIS_HIP(ctx, hipMemcpyAsync(&flags, o->w.flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) { out[i].n = counts[i]; mis_dev_image_release(ctx, &dimg[i]); }
+    if (flags) {
+        hipMemsetAsync(o->w.flags, 0, sizeof(int), ctx->stream);
+        return mis_set_error(ctx, MIS_E_OVERFLOW, "ORB candidate buffers overflowed (flags %d): too many tied scores", flags);
+    }
+    return MIS_OK;
+}
+
+extern "C" int mis_orb_detect(MisOrb* o, const MisImage* bgr, MisFeatures* out) { return mis_orb_detect_batch(o, bgr, 1, out); }
+
+extern "C" int mis_features_download(MisContext* ctx, const MisFeatures* f, MisKeyPoint* kps, void* desc) {
+    if (!ctx || !f) return MIS_E_INVALID;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (f->n > 0) {
+        if (kps) MIS_HIP(ctx, hipMemcpyAsync(kps, f->keypoints, sizeof(MisKeyPoint) * (size_t)f->n, hipMemcpyDeviceToHost, ctx->stream));
+        if (desc) MIS_HIP(ctx, hipMemcpyAsync(desc, f->descriptors, (size_t)f->n * f->desc_cols * mis_dtype_size(f->desc_dtype), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
+}
+
+extern "C" int mis_features_upload(MisContext* ctx, int img_w, int img_h, int n, const MisKeyPoint* kps, const void* desc, int desc_cols,
+                                   int desc_dtype, MisFeatures* out) {
+    if (!ctx || !out) return MIS_E_INVALID;
+    MIS_CHECK(ctx, n >= 0 && (n == 0 || (kps && desc)) && desc_cols > 0 && (desc_dtype == MIS_U8 || desc_dtype == MIS_F32), MIS_E_INVALID,
+              "bad feature arrays");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    out->img_w = img_w; out->img_h = img_h;
+    int rc = alloc_features(ctx, std::max(n, 1), desc_cols, desc_dtype, out);
+    if (rc != MIS_OK) return rc;
+    if (n) {
+        MIS_HIP(ctx, hipMemcpyAsync(out->keypoints, kps, sizeof(MisKeyPoint) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        MIS_HIP(ctx, hipMemcpyAsync(out->descriptors, desc, (size_t)n * desc_cols * mis_dtype_size(desc_dtype), hipMemcpyHostToDevice, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    out->n = n;
+    return MIS_OK;
+}
+
+extern "C" int mis_features_free(MisContext* ctx, MisFeatures* f) {
+    if (!ctx || !f) return MIS_E_INVALID;
+    if (f->owner_) {
+        MIS_HIP(ctx, hipSetDevice(ctx->device));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MIS_HIP(ctx, hipFree(f->owner_));
+    }
+    f->owner_ = nullptr; f->keypoints = nullptr; f->descriptors = nullptr; f->n = 0;
+    return MIS_OK;
+}
+
+extern "C" int mis_orb_debug_level(MisOrb* o, int level, int which, uint8_t* host_out, int* width, int* height) {
+    if (!o) return MIS_E_INVALID;
+    MisContext* ctx = o->ctx;
+    MIS_CHECK(ctx, level >= 0 && level < o->L.n && which >= 0 && which <= 2, MIS_E_INVALID, "bad level / selector");
+    const LevelDesc& d = o->L.d[level];
+    int w = which == 2 ? d.w + 2 * ORB_BORDER : d.w, h = which == 2 ? d.h + 2 * ORB_BORDER : d.h;
+    if (width) *width = w;
+    if (height) *height = h;
+    if (!host_out) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint8_t* src;
+    size_t pitch;
+    if (which == 0) { src = o->w.pad + d.pad_off + (size_t)ORB_BORDER * d.pp + ORB_BORDER; pitch = d.pp; }
+    else if (which == 1) { src = o->w.nms + d.map_off; pitch = d.sp; }
+    else { src = o->w.blur + d.pad_off; pitch = d.pp; }
+    MIS_HIP(ctx, hipMemcpy2DAsync(host_out, w, src, pitch, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
+}
