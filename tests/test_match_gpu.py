@@ -1,0 +1,137 @@
+"""GPU parity: exact 2-NN, ratio/union, RANSAC + LM homography, all-pairs matcher vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def _feat_dict(kps, desc, size):
+    return dict(img_w=size[0], img_h=size[1], xy=np.stack([kps["x"], kps["y"]], 1), desc=desc)
+
+
+def test_knn2_hamming_bit_exact(ctx, oracle_mod):
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    for nq, nt in ((700, 1300), (257, 2), (5, 300)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nt > 260:
+            t[7] = q[3]; t[259] = q[3]          # duplicates across LDS tiles: tie -> smaller index
+            t[100] = t[101]
+        fq = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nq, KP_DTYPE), q)
+        ft = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nt, KP_DTYPE), t)
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.float32)
+        ctx.check(ctx.lib.mis_knn2(ctx.h, C.byref(fq.raw), C.byref(ft.raw), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+        oi, od = oracle_mod.knn2_hamming(q, t)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od.astype(np.float32))
+
+
+def _synthetic_correspondences(rng, n, outlier_frac, noise=0.4):
+    H = np.array([[0.97, 0.03, 25.0], [-0.02, 1.03, -14.0], [2e-5, -1e-5, 1.0]])
+    src = rng.uniform(-900, 900, (n, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(n)] @ H.T
+    dst = (p[:, :2] / p[:, 2:] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    no = int(n * outlier_frac)
+    dst[:no] = rng.uniform(-900, 900, (no, 2)).astype(np.float32)
+    return src, dst
+
+
+@pytest.mark.parametrize("n,frac", [(600, 0.1), (900, 0.5), (300, 0.75), (40, 0.3), (2500, 0.2), (5, 0.0), (4, 0.0), (3, 0.0)])
+def test_find_homography_bit_exact(ctx, oracle_mod, n, frac):
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(n * 7 + int(frac * 100))
+    src, dst = _synthetic_correspondences(rng, n, frac)
+    ok_o, H_o, mask_o, iters_o = oracle_mod.find_homography_ransac(src, dst)
+    ok_g, H_g, mask_g = isa.find_homography(ctx, src, dst)
+    assert ok_g == ok_o
+    assert np.array_equal(mask_g, mask_o)
+    if ok_o:
+        assert np.array_equal(_bits(H_g), _bits(H_o)), (H_g - H_o)
+
+
+def test_find_homography_degenerate_inputs(ctx, oracle_mod):
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(77)
+    # all points collinear: checkSubset rejects every subset -> no model
+    x = rng.uniform(-100, 100, 50).astype(np.float32)
+    src = np.stack([x, 2 * x], 1).astype(np.float32)
+    dst = src + 1
+    ok_o, H_o, mask_o, _ = oracle_mod.find_homography_ransac(src, dst, max_iters=50)
+    ok_g, H_g, mask_g = isa.find_homography(ctx, src, dst, max_iters=50)
+    assert ok_g == ok_o and np.array_equal(mask_g, mask_o)
+    # pure noise: RANSAC runs all iterations
+    src = rng.uniform(-500, 500, (200, 2)).astype(np.float32)
+    dst = rng.uniform(-500, 500, (200, 2)).astype(np.float32)
+    ok_o, H_o, mask_o, it = oracle_mod.find_homography_ransac(src, dst, max_iters=300)
+    ok_g, H_g, mask_g = isa.find_homography(ctx, src, dst, max_iters=300)
+    assert ok_g == ok_o and np.array_equal(mask_g, mask_o)
+    if ok_o:
+        assert np.array_equal(_bits(H_g), _bits(H_o))
+
+
+def _compare_matches_info(g, o):
+    assert g.src_img_idx == o["src_img_idx"] and g.dst_img_idx == o["dst_img_idx"]
+    assert np.array_equal(g.matches, o["matches"].astype(g.matches.dtype))
+    assert np.array_equal(g.inliers_mask, o["inliers_mask"])
+    assert g.num_inliers == o["num_inliers"]
+    assert (g.H is not None) == o["has_H"]
+    if o["has_H"]:
+        assert np.array_equal(_bits(g.H), _bits(o["H"]))
+    assert g.confidence == o["confidence"]
+
+
+def test_match_all_pairs_bit_exact(ctx, oracle_mod):
+    """4 synthetic frames (three overlapping, one looking elsewhere): every MatchesInfo field."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    w, h = 480, 270
+    cams = [synth.make_camera(w, h, 60.0, y, p, r) for y, p, r in ((0, 0, 0), (14, 0.6, -0.3), (27, -0.4, 0.5), (150, 0, 0))]
+    frames = [synth.render_frame(c) for c in cams]
+    finder = isa.OrbFeatureFinder(ctx, (w, h))
+    feats = [isa.computeImageFeatures(finder, torch.from_numpy(f).cuda(), i) for i, f in enumerate(frames)]
+    host = [f.download() for f in feats]
+    pm = isa.BestOf2NearestMatcher(ctx, 0.32)(feats)
+    ref = oracle_mod.match_all_pairs([_feat_dict(k, d, (w, h)) for k, d in host])
+    assert len(pm) == 16
+    for g, o in zip(pm, ref):
+        _compare_matches_info(g, o)
+    assert pm[1].confidence > 1.0 and pm[0 * 4 + 3].confidence < 0.95
+    idx_g = isa.leaveBiggestComponent(pm, 4, 0.95)
+    conf = np.array([m["confidence"] for m in ref]).reshape(4, 4)
+    assert list(idx_g) == list(oracle_mod.leave_biggest_component(conf, 0.95)) == [0, 1, 2]
+    # sharded matcher: the union over ranks equals the single-rank result
+    parts = [isa.BestOf2NearestMatcher(ctx, 0.32)(feats, rank=r, world_size=3) for r in range(3)]
+    for k in range(16):
+        owners = [p[k] for p in parts if p[k].src_img_idx >= 0]
+        if pm[k].src_img_idx < 0:
+            assert not owners
+        else:
+            assert len(owners) == 1
+            assert np.array_equal(owners[0].matches, pm[k].matches) and owners[0].confidence == pm[k].confidence
+
+
+def test_match_empty_and_tiny_feature_sets(ctx, oracle_mod):
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    rng = np.random.default_rng(41)
+
+    def mk(n):
+        k = np.zeros(n, KP_DTYPE)
+        k["x"] = rng.uniform(0, 200, n)
+        k["y"] = rng.uniform(0, 100, n)
+        return k, rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sets = [mk(0), mk(1), mk(30), mk(200)]
+    sets[3][1][:30] = sets[2][1]          # 30 identical descriptors -> matches but random geometry
+    feats = [isa.ImageFeatures.upload(ctx, (200, 100), k, d, i) for i, (k, d) in enumerate(sets)]
+    pm = isa.BestOf2NearestMatcher(ctx, 0.32)(feats)
+    ref = oracle_mod.match_all_pairs([_feat_dict(k, d, (200, 100)) for k, d in sets])
+    for g, o in zip(pm, ref):
+        _compare_matches_info(g, o)
