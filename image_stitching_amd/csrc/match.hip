@@ -255,9 +255,7 @@ __device__ __forceinline__ double dlt_ly(int j, double X, double Y, double y) {
 }
 
 // eigenvector of the smallest eigenvalue -> de-normalised, scaled homography
-__device__ void dlt_finish(const Slot s, const double* nrm /* cmx cmy cMx cMy smx smy sMx sMy */, double* H) {
-    for (int j = 0; j < 9; j++) for (int k = 0; k < j; k++) s.a(j * 9 + k) = s.a(k * 9 + j);
-    jacobi_eigen(s, 9);
+__device__ void dlt_denormalise(const Slot s, const double* nrm /* cmx cmy cMx cMy smx smy sMx sMy */, double* H) {
     double H0[9], T[9], R[9];
     for (int i = 0; i < 9; i++) H0[i] = s.v(72 + i);
     const double invHnorm[9] = {1. / nrm[4], 0, nrm[0], 0, 1. / nrm[5], nrm[1], 0, 0, 1};
@@ -274,6 +272,11 @@ __device__ void dlt_finish(const Slot s, const double* nrm /* cmx cmy cMx cMy sm
     }
     double sc = 1. / R[8];
     for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
+}
+__device__ void dlt_finish(const Slot s, const double* nrm, double* H) {
+    for (int j = 0; j < 9; j++) for (int k = 0; k < j; k++) s.a(j * 9 + k) = s.a(k * 9 + j);
+    jacobi_eigen(s, 9);
+    dlt_denormalise(s, nrm, H);
 }
 
 // serial DLT of `count` points by ONE thread (the 4-point RANSAC hypotheses)
@@ -352,11 +355,107 @@ struct HomoShared {
     int valid[CHUNK], good[CHUNK];
     double best[9];
     double nrm[8];
-    double lm[8 + 8 + 64 + 64 + 8 + 8 + 8 + 4];  // x, xd, A, Ap, v, d, D, scalars
+    double lm[8 + 8 + 64 + 64 + 8 + 8 + 8 + 8];  // x, xd, A, Ap, v, d, D, scalars
+    int indR[9], indC[9];
     float Hf[9];
     unsigned long long rng;
     int niters, iter, max_good, n_gen, stop, result, np;
 };
+
+
+// The same Jacobi iteration with the n independent plane rotations of a step spread over n threads
+// and the four index-table scans over four threads; the arithmetic of every element is unchanged.
+// Called by the whole workgroup on slot 0 (threads >= n only take part in the barriers).
+__device__ void jacobi_eigen_coop(HomoShared& S, const int n) {
+    const Slot s = {S.A, S.V, S.W};
+    const int t = threadIdx.x;
+    const double eps = DBL_EPSILON;
+    int i, k, l, m;
+    double mv;
+    if (t < n) {
+        for (int j = 0; j < n; j++) s.v(t * n + j) = (j == t) ? 1. : 0.;
+        s.w(t) = s.a((n + 1) * t);
+        k = t;
+        if (k < n - 1) {
+            for (m = k + 1, mv = fabs(s.a(n * k + m)), i = k + 2; i < n; i++) {
+                double val = fabs(s.a(n * k + i));
+                if (mv < val) mv = val, m = i;
+            }
+            S.indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabs(s.a(k)), i = 1; i < k; i++) {
+                double val = fabs(s.a(n * i + k));
+                if (mv < val) mv = val, m = i;
+            }
+            S.indC[k] = m;
+        }
+    }
+    __syncthreads();
+    const int maxIters = n * n * 30;
+    if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
+        for (k = 0, mv = fabs(s.a(S.indR[0])), i = 1; i < n - 1; i++) {
+            double val = fabs(s.a(n * i + S.indR[i]));
+            if (mv < val) mv = val, k = i;
+        }
+        l = S.indR[k];
+        for (i = 1; i < n; i++) {
+            double val = fabs(s.a(n * S.indC[i] + i));
+            if (mv < val) mv = val, k = S.indC[i], l = i;
+        }
+        const double p = s.a(n * k + l);
+        if (fabs(p) <= eps) break;  // uniform: every thread reads the same LDS words
+        const double y = (s.w(l) - s.w(k)) * 0.5;
+        double tt = fabs(y) + cv_hypot(p, y);
+        double sn = cv_hypot(p, tt);
+        const double c = tt / sn;
+        sn = p / sn; tt = (p / tt) * p;
+        if (y < 0) sn = -sn, tt = -tt;
+        __syncthreads();  // all pivot inputs read before anything is rewritten
+        if (t == 0) { s.a(n * k + l) = 0; s.w(k) -= tt; s.w(l) += tt; }
+        if (t < n) {
+            double a0, b0;
+#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
+            if (t < k) MIS_ROT(s.a(n * t + k), s.a(n * t + l));
+            else if (t > k && t < l) MIS_ROT(s.a(n * k + t), s.a(n * t + l));
+            else if (t > l) MIS_ROT(s.a(n * k + t), s.a(n * l + t));
+            MIS_ROT(s.v(n * k + t), s.v(n * l + t));
+#undef MIS_ROT
+        }
+        __syncthreads();
+        if (t < 4) {
+            const int idx = t < 2 ? k : l;
+            if ((t & 1) == 0) {
+                if (idx < n - 1) {
+                    for (m = idx + 1, mv = fabs(s.a(n * idx + m)), i = idx + 2; i < n; i++) {
+                        double val = fabs(s.a(n * idx + i));
+                        if (mv < val) mv = val, m = i;
+                    }
+                    S.indR[idx] = m;
+                }
+            } else if (idx > 0) {
+                for (m = 0, mv = fabs(s.a(idx)), i = 1; i < idx; i++) {
+                    double val = fabs(s.a(n * i + idx));
+                    if (mv < val) mv = val, m = i;
+                }
+                S.indC[idx] = m;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (k = 0; k < n - 1; k++) {
+            m = k;
+            for (i = k + 1; i < n; i++) if (s.w(m) < s.w(i)) m = i;
+            if (k != m) {
+                double tw = s.w(m); s.w(m) = s.w(k); s.w(k) = tw;
+                for (i = 0; i < n; i++) { double tv = s.v(n * m + i); s.v(n * m + i) = s.v(n * k + i); s.v(n * k + i) = tv; }
+            }
+        }
+    }
+    __syncthreads();
+}
 
 // LM callback of the homography refinement (fundam.cpp HomographyRefineCallback)
 __device__ __forceinline__ void lm_point(const double* h, double Mx, double My, double* ww, double* xi, double* yi) {
@@ -374,7 +473,7 @@ __device__ __forceinline__ void lm_jrow(int row, double Mx, double My, double ww
 // cv::findHomography(src, dst, mask, RANSAC, thresh, maxIters, confidence) by one workgroup.
 // src/dst: n points; mask (may be null); scratch: 4*n floats for the compressed inliers.
 __device__ int find_homography_block(HomoShared& S, const float* src, const float* dst, int n, double thresh, int max_iters, double confidence,
-                                     double* Hout, uint8_t* mask, float* scratch, int* iters_out) {
+                                     double* Hout, uint8_t* mask, float* scratch, double* rec, int* iters_out) {
     const int t = threadIdx.x;
     const Slot slot = {S.A + (t % CHUNK), S.V + (t % CHUNK), S.W + (t % CHUNK)};
     const Slot slot0 = {S.A, S.V, S.W};
@@ -501,7 +600,8 @@ __device__ int find_homography_block(HomoShared& S, const float* src, const floa
     }
     const int np = S.np;
     if (np > 0) {
-        // ---- runKernel on all inliers: every accumulator is summed sequentially by one thread ----
+        // ---- runKernel on all inliers.  Every f64 accumulator is summed in point order by ONE thread
+        // (bit-identical to the sequential CPU loop); the per-point terms are produced in parallel. ----
         if (t < 4) {
             double acc = 0;
             const float* p = t < 2 ? d1 : s1;  // cmx cmy cMx cMy
@@ -521,61 +621,79 @@ __device__ int find_homography_block(HomoShared& S, const float* src, const floa
         if (!degenerate) {
             if (t < 4) S.nrm[4 + t] = np / S.nrm[4 + t];
             __syncthreads();
+            {
+                const double cmx = S.nrm[0], cmy = S.nrm[1], cMx = S.nrm[2], cMy = S.nrm[3], smx = S.nrm[4], smy = S.nrm[5], sMx = S.nrm[6], sMy = S.nrm[7];
+                for (int i = t; i < np; i += HB) {
+                    double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
+                    double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
+                    double* r = rec + 10 * (size_t)i;  // X Y 1 0 -xX -xY -x -yX -yY -y
+                    r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
+                }
+            }
+            __syncthreads();
             if (t < 45) {
                 int j = 0, k = t;  // t-th entry of the upper triangle, row-major
                 while (k >= 9 - j) { k -= 9 - j; j++; }
                 k += j;
-                const double cmx = S.nrm[0], cmy = S.nrm[1], cMx = S.nrm[2], cMy = S.nrm[3], smx = S.nrm[4], smy = S.nrm[5], sMx = S.nrm[6], sMy = S.nrm[7];
+                const int lxi[9] = {0, 1, 2, 3, 3, 3, 4, 5, 6}, lyi[9] = {3, 3, 3, 0, 1, 2, 7, 8, 9};
+                const int xj = lxi[j], xk = lxi[k], yj = lyi[j], yk = lyi[k];
                 double acc = 0;
                 for (int i = 0; i < np; i++) {
-                    double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
-                    double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
-                    acc += dlt_lx(j, X, Y, x) * dlt_lx(k, X, Y, x) + dlt_ly(j, X, Y, y) * dlt_ly(k, X, Y, y);
+                    const double* r = rec + 10 * (size_t)i;
+                    acc += r[xj] * r[xk] + r[yj] * r[yk];
                 }
                 slot0.a(j * 9 + k) = acc;
             }
             __syncthreads();
-            if (t == 0) dlt_finish(slot0, S.nrm, S.best);
+            if (t < 81) { int j = t / 9, k = t % 9; if (k < j) slot0.a(j * 9 + k) = slot0.a(k * 9 + j); }
+            __syncthreads();
+            jacobi_eigen_coop(S, 9);
+            if (t == 0) dlt_denormalise(slot0, S.nrm, S.best);
             __syncthreads();
         }
         // ---- LMSolver, 10 iterations, on the 8 free parameters ----
         double* x = S.lm;            double* xd = x + 8;   double* A = xd + 8;  double* Ap = A + 64;
-        double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // sc: S, Sd, rmax, flag
-        const int rows = 2 * np;
-        // normal equations at h: A = J^T J, v = J^T r, S = |r|^2, rmax = |r|_inf; one thread per entry
+        double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // sc: S, Sd, rmax, flag, lambda, lc
+        // normal equations at h: A = J^T J, v = J^T r, S = |r|^2, rmax = |r|_inf
         auto normal_eq = [&](const double* h, bool with_J) {
+            for (int p = t; p < np; p += HB) {
+                double Mx = (double)s1[2 * p], My = (double)s1[2 * p + 1], ww, xi, yi;
+                lm_point(h, Mx, My, &ww, &xi, &yi);
+                double* r = rec + 10 * (size_t)p;  // a b ww c0 c1 c2 c3 e0 e1 0
+                r[7] = xi - (double)d1[2 * p]; r[8] = yi - (double)d1[2 * p + 1];
+                if (with_J) {
+                    r[0] = Mx * ww; r[1] = My * ww; r[2] = ww;
+                    r[3] = -Mx * ww * xi; r[4] = -My * ww * xi; r[5] = -Mx * ww * yi; r[6] = -My * ww * yi; r[9] = 0;
+                }
+            }
+            __syncthreads();
+            const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
             if (with_J && t < 36) {
                 int i = 0, j = t;
                 while (j >= 8 - i) { j -= 8 - i; i++; }
                 j += i;
+                const int a0 = j0[i], b0 = j0[j], a1 = j1[i], b1 = j1[j];
                 double acc = 0;
                 for (int p = 0; p < np; p++) {
-                    double ww, xi, yi, J[8];
-                    lm_point(h, (double)s1[2 * p], (double)s1[2 * p + 1], &ww, &xi, &yi);
-                    lm_jrow(0, (double)s1[2 * p], (double)s1[2 * p + 1], ww, xi, yi, J);
-                    acc += J[i] * J[j];
-                    lm_jrow(1, (double)s1[2 * p], (double)s1[2 * p + 1], ww, xi, yi, J);
-                    acc += J[i] * J[j];
+                    const double* r = rec + 10 * (size_t)p;
+                    acc += r[a0] * r[b0];
+                    acc += r[a1] * r[b1];
                 }
                 A[i * 8 + j] = acc; A[j * 8 + i] = acc;
             } else if (with_J && t >= 64 && t < 72) {
-                int i = t - 64;
+                const int i = t - 64, a0 = j0[i], a1 = j1[i];
                 double acc = 0;
                 for (int p = 0; p < np; p++) {
-                    double ww, xi, yi, J[8];
-                    lm_point(h, (double)s1[2 * p], (double)s1[2 * p + 1], &ww, &xi, &yi);
-                    lm_jrow(0, (double)s1[2 * p], (double)s1[2 * p + 1], ww, xi, yi, J);
-                    acc += J[i] * (xi - (double)d1[2 * p]);
-                    lm_jrow(1, (double)s1[2 * p], (double)s1[2 * p + 1], ww, xi, yi, J);
-                    acc += J[i] * (yi - (double)d1[2 * p + 1]);
+                    const double* r = rec + 10 * (size_t)p;
+                    acc += r[a0] * r[7];
+                    acc += r[a1] * r[8];
                 }
                 v[i] = acc;
             } else if (t == 128) {
                 double acc = 0, mx = 0;
                 for (int p = 0; p < np; p++) {
-                    double ww, xi, yi;
-                    lm_point(h, (double)s1[2 * p], (double)s1[2 * p + 1], &ww, &xi, &yi);
-                    double e0 = xi - (double)d1[2 * p], e1 = yi - (double)d1[2 * p + 1];
+                    const double* r = rec + 10 * (size_t)p;
+                    double e0 = r[7], e1 = r[8];
                     acc += e0 * e0; acc += e1 * e1;
                     if (fabs(e0) > mx) mx = fabs(e0);
                     if (fabs(e1) > mx) mx = fabs(e1);
@@ -585,21 +703,19 @@ __device__ int find_homography_block(HomoShared& S, const float* src, const floa
             }
             __syncthreads();
         };
+        // SVBkSb thresholding + back substitution pieces shared by solve() and invert() (DECOMP_EIG)
         if (t < 8) x[t] = S.best[t];
         __syncthreads();
         normal_eq(x, true);
         if (t < 8) D[t] = A[t * 8 + t];
-        __syncthreads();
-        (void)rows;
         if (t == 0) { sc[4] = 1; sc[5] = 0.75; }  // lambda, lc
         __syncthreads();
         for (int iter = 0;;) {
+            if (t < 64) slot0.a(t) = (t / 8 == t % 8) ? A[t] + sc[4] * D[t / 8] : A[t];
+            __syncthreads();
+            jacobi_eigen_coop(S, 8);
             if (t == 0) {
-                const double lambda = sc[4];
-                for (int e = 0; e < 64; e++) slot0.a(e) = A[e];
-                for (int i = 0; i < 8; i++) slot0.a(i * 8 + i) += lambda * D[i];
-                // solve(Ap, v, d, DECOMP_EIG): Jacobi + SVBkSb
-                jacobi_eigen(slot0, 8);
+                // solve(Ap, v, d, DECOMP_EIG): SVBkSb
                 double thrw = 0;
                 for (int i = 0; i < 8; i++) thrw += slot0.w(i);
                 thrw *= DBL_EPSILON * 2;
@@ -627,6 +743,7 @@ __device__ int find_homography_block(HomoShared& S, const float* src, const floa
                 }
                 for (int i = 0; i < 8; i++) dS += d[i] * temp_d[i];
                 double R = (Sv - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                sc[6] = 0;  // needs invert()
                 if (R > 0.75) {
                     lambda *= 0.5;
                     if (lambda < lc) lambda = 0;
@@ -635,29 +752,40 @@ __device__ int find_homography_block(HomoShared& S, const float* src, const floa
                     for (int i = 0; i < 8; i++) tt += d[i] * v[i];
                     double nu = (Sd - Sv) / (fabs(tt) > DBL_EPSILON ? tt : 1) + 2;
                     nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
-                    if (lambda == 0) {
-                        // invert(A, Ap, DECOMP_EIG)
-                        for (int e = 0; e < 64; e++) slot0.a(e) = A[e];
-                        jacobi_eigen(slot0, 8);
-                        double thrw = 0;
-                        for (int i = 0; i < 8; i++) thrw += slot0.w(i);
-                        thrw *= DBL_EPSILON * 2;
-                        for (int e = 0; e < 64; e++) Ap[e] = 0;
-                        for (int i = 0; i < 8; i++) {
-                            double wi = slot0.w(i);
-                            if (fabs(wi) <= thrw) continue;
-                            wi = 1 / wi;
-                            for (int r = 0; r < 8; r++)
-                                for (int c = 0; c < 8; c++) Ap[r * 8 + c] = Ap[r * 8 + c] + slot0.v(i * 8 + r) * (slot0.v(i * 8 + c) * wi);
-                        }
-                        double maxval = DBL_EPSILON;
-                        for (int i = 0; i < 8; i++) { double a = fabs(Ap[i * 8 + i]); if (a > maxval) maxval = a; }
-                        lambda = lc = 1. / maxval;
-                        nu *= 0.5;
-                    }
-                    lambda *= nu;
+                    if (lambda == 0) sc[6] = 1;
+                    else lambda *= nu;
+                    sc[7] = nu;
                 }
                 sc[4] = lambda; sc[5] = lc;
+            }
+            __syncthreads();
+            if (sc[6] != 0.) {
+                // invert(A, Ap, DECOMP_EIG) -> lambda = lc = 1 / max |diag|, nu halved
+                if (t < 64) slot0.a(t) = A[t];
+                __syncthreads();
+                jacobi_eigen_coop(S, 8);
+                if (t == 0) {
+                    double thrw = 0;
+                    for (int i = 0; i < 8; i++) thrw += slot0.w(i);
+                    thrw *= DBL_EPSILON * 2;
+                    for (int e = 0; e < 64; e++) Ap[e] = 0;
+                    for (int i = 0; i < 8; i++) {
+                        double wi = slot0.w(i);
+                        if (fabs(wi) <= thrw) continue;
+                        wi = 1 / wi;
+                        for (int r = 0; r < 8; r++)
+                            for (int c = 0; c < 8; c++) Ap[r * 8 + c] = Ap[r * 8 + c] + slot0.v(i * 8 + r) * (slot0.v(i * 8 + c) * wi);
+                    }
+                    double maxval = DBL_EPSILON;
+                    for (int i = 0; i < 8; i++) { double a = fabs(Ap[i * 8 + i]); if (a > maxval) maxval = a; }
+                    double lambda = 1. / maxval, nu = sc[7] * 0.5;
+                    sc[5] = lambda;
+                    sc[4] = lambda * nu;
+                }
+                __syncthreads();
+            }
+            if (t == 0) {
+                double Sv = sc[0], Sd = sc[1];
                 sc[3] = Sd < Sv ? 1. : 0.;
                 if (Sd < Sv) { sc[0] = Sd; for (int i = 0; i < 8; i++) x[i] = xd[i]; }
             }
@@ -690,7 +818,7 @@ __device__ __forceinline__ double det3(const double* H) {
 
 // BestOf2NearestMatcher::match after the 2-NN stage, one workgroup per pair
 __global__ __launch_bounds__(HB) void pair_homography_kernel(const PairDesc* pairs, const int* n_matches, const float* src_xy, const float* dst_xy,
-                                                             uint8_t* masks, float* scratch, PairOut* outs, int thresh1, int thresh2,
+                                                             uint8_t* masks, float* scratch, double* recs, PairOut* outs, int thresh1, int thresh2,
                                                              double ransac_thresh, int max_iters, double confidence) {
     __shared__ HomoShared S;
     __shared__ int s_ninl;
@@ -701,10 +829,11 @@ __global__ __launch_bounds__(HB) void pair_homography_kernel(const PairDesc* pai
     const float* dp = dst_xy + 2 * pd.m_off;
     uint8_t* mask = masks + pd.m_off;
     float* scr = scratch + 8 * pd.m_off;  // 8 floats per potential match: two compressions
+    double* rec = recs + 10 * pd.m_off;   // 10 doubles per potential match: per-point terms of the DLT / LM sums
     if (t == 0) { o->has_H = 0; o->num_inliers = 0; o->ran_ransac = 0; o->iters0 = o->iters1 = 0; o->passed = 0; s_ninl = 0; }
     __syncthreads();
     if (nm < thresh1) return;
-    int ok = find_homography_block(S, sp, dp, nm, ransac_thresh, max_iters, confidence, o->H, mask, scr, &o->iters0);
+    int ok = find_homography_block(S, sp, dp, nm, ransac_thresh, max_iters, confidence, o->H, mask, scr, rec, &o->iters0);
     if (t == 0) { o->ran_ransac = 1; o->has_H = ok; }
     __syncthreads();
     if (!ok || fabs(det3(o->H)) < DBL_EPSILON) return;
@@ -737,15 +866,15 @@ __global__ __launch_bounds__(HB) void pair_homography_kernel(const PairDesc* pai
     }
     const int ninl = s_ninl;
     if (ninl < thresh2) return;
-    ok = find_homography_block(S, s2, d2, ninl, ransac_thresh, max_iters, confidence, o->H, nullptr, scr, &o->iters1);
+    ok = find_homography_block(S, s2, d2, ninl, ransac_thresh, max_iters, confidence, o->H, nullptr, scr, rec, &o->iters1);
     if (t == 0) o->has_H = ok;
 }
 
 // stand-alone findHomography on caller-supplied point lists (stage-test hook, mis_find_homography)
 __global__ __launch_bounds__(HB) void find_homography_kernel(const float* src, const float* dst, int n, double thresh, int max_iters, double confidence,
-                                                             double* H, uint8_t* mask, float* scratch, int* ok_iters) {
+                                                             double* H, uint8_t* mask, float* scratch, double* rec, int* ok_iters) {
     __shared__ HomoShared S;
-    int ok = find_homography_block(S, src, dst, n, thresh, max_iters, confidence, H, mask, scratch, &ok_iters[1]);
+    int ok = find_homography_block(S, src, dst, n, thresh, max_iters, confidence, H, mask, scratch, rec, &ok_iters[1]);
     if (threadIdx.x == 0) ok_iters[0] = ok;
 }
 
@@ -798,7 +927,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if (np == 0) return MIS_OK;
     int maxq = 0;
     for (int i = 0; i < n; i++) maxq = std::max(maxq, feats[i].n);
-    DevBuf d_feats, d_pairs, d_idx, d_dist, d_matches, d_src, d_dst, d_nm, d_mask, d_scr, d_out;
+    DevBuf d_feats, d_pairs, d_idx, d_dist, d_matches, d_src, d_dst, d_nm, d_mask, d_scr, d_rec, d_out;
     MIS_HIP(ctx, d_feats.alloc(sizeof(FeatDev) * n));
     MIS_HIP(ctx, d_pairs.alloc(sizeof(PairDesc) * np));
     MIS_HIP(ctx, d_idx.alloc(sizeof(int) * 2 * knn_total));
@@ -809,6 +938,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, d_nm.alloc(sizeof(int) * np));
     MIS_HIP(ctx, d_mask.alloc(m_total));
     MIS_HIP(ctx, d_scr.alloc(sizeof(float) * 8 * m_total));
+    MIS_HIP(ctx, d_rec.alloc(sizeof(double) * 10 * m_total));
     MIS_HIP(ctx, d_out.alloc(sizeof(PairOut) * np));
     hipStream_t st = ctx->stream;
     MIS_HIP(ctx, hipMemcpyAsync(d_feats.p, fd.data(), sizeof(FeatDev) * n, hipMemcpyHostToDevice, st));
@@ -819,7 +949,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     hipLaunchKernelGGL(ratio_union_kernel, dim3(np), dim3(1024), 0, st, (const FeatDev*)d_feats.p, (const PairDesc*)d_pairs.p, (const int*)d_idx.p,
                        (const int*)d_dist.p, 1.f - p->match_conf, (MisDMatch*)d_matches.p, (float*)d_src.p, (float*)d_dst.p, (int*)d_nm.p);
     hipLaunchKernelGGL(pair_homography_kernel, dim3(np), dim3(HB), 0, st, (const PairDesc*)d_pairs.p, (const int*)d_nm.p, (const float*)d_src.p,
-                       (const float*)d_dst.p, (uint8_t*)d_mask.p, (float*)d_scr.p, (PairOut*)d_out.p, p->num_matches_thresh1, p->num_matches_thresh2,
+                       (const float*)d_dst.p, (uint8_t*)d_mask.p, (float*)d_scr.p, (double*)d_rec.p, (PairOut*)d_out.p, p->num_matches_thresh1, p->num_matches_thresh2,
                        p->ransac_thresh, p->max_iters, p->confidence);
     MIS_HIP(ctx, hipGetLastError());
     std::vector<int> nm(np);
@@ -931,13 +1061,14 @@ extern "C" int mis_find_homography(MisContext* ctx, const float* src, const floa
     if (!ctx) return MIS_E_INVALID;
     MIS_CHECK(ctx, src && dst && H && ok && n >= 0, MIS_E_INVALID, "null argument");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_src, d_dst, d_H, d_mask, d_scr, d_ok;
+    DevBuf d_src, d_dst, d_H, d_mask, d_scr, d_rec, d_ok;
     size_t nn = (size_t)std::max(n, 1);
     MIS_HIP(ctx, d_src.alloc(sizeof(float) * 2 * nn));
     MIS_HIP(ctx, d_dst.alloc(sizeof(float) * 2 * nn));
     MIS_HIP(ctx, d_H.alloc(sizeof(double) * 9));
     MIS_HIP(ctx, d_mask.alloc(nn));
     MIS_HIP(ctx, d_scr.alloc(sizeof(float) * 4 * nn));
+    MIS_HIP(ctx, d_rec.alloc(sizeof(double) * 10 * nn));
     MIS_HIP(ctx, d_ok.alloc(sizeof(int) * 2));
     hipStream_t st = ctx->stream;
     if (n) {
@@ -946,7 +1077,7 @@ extern "C" int mis_find_homography(MisContext* ctx, const float* src, const floa
     }
     MIS_HIP(ctx, hipMemsetAsync(d_H.p, 0, sizeof(double) * 9, st));
     hipLaunchKernelGGL(find_homography_kernel, dim3(1), dim3(HB), 0, st, (const float*)d_src.p, (const float*)d_dst.p, n, thresh, max_iters, confidence,
-                       (double*)d_H.p, (uint8_t*)d_mask.p, (float*)d_scr.p, (int*)d_ok.p);
+                       (double*)d_H.p, (uint8_t*)d_mask.p, (float*)d_scr.p, (double*)d_rec.p, (int*)d_ok.p);
     MIS_HIP(ctx, hipGetLastError());
     int oki[2] = {0, 0};
     MIS_HIP(ctx, hipMemcpyAsync(H, d_H.p, sizeof(double) * 9, hipMemcpyDeviceToHost, st));

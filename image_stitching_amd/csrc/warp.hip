@@ -9,6 +9,8 @@
 // into LDS (128 + 16 evaluations per 2048 pixels).
 #include "common.h"
 #include "dev_math.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -94,6 +96,37 @@ void detect_result_roi(const Projector* p, int sw, int sh, int* tlx, int* tly, i
         }
     }
     *tlx = (int)tl_uf; *tly = (int)tl_vf; *brx = (int)br_uf; *bry = (int)br_vf;
+}
+
+// detectResultRoi walks 2(W+H) border pixels on the host (~0.1 ms at 4K); the compose loop asks for the
+// same (scale, K, R, size) twice (warpRoi, then warp), so the last few answers are cached.
+struct RoiKey {
+    float scale, K[9], R[9];
+    int w, h;
+};
+struct RoiEntry {
+    RoiKey key;
+    Projector proj;
+    int tlx, tly, brx, bry;
+};
+std::mutex g_roi_mutex;
+std::vector<RoiEntry> g_roi_cache;
+
+void projector_and_roi(float scale, const float K[9], const float R[9], int w, int h, Projector* p, int* tlx, int* tly, int* brx, int* bry) {
+    RoiKey key;
+    memset(&key, 0, sizeof(key));
+    key.scale = scale; key.w = w; key.h = h;
+    memcpy(key.K, K, sizeof(key.K)); memcpy(key.R, R, sizeof(key.R));
+    {
+        std::lock_guard<std::mutex> lock(g_roi_mutex);
+        for (const RoiEntry& e : g_roi_cache)
+            if (memcmp(&e.key, &key, sizeof(key)) == 0) { *p = e.proj; *tlx = e.tlx; *tly = e.tly; *brx = e.brx; *bry = e.bry; return; }
+    }
+    projector_set(p, scale, K, R);
+    detect_result_roi(p, w, h, tlx, tly, brx, bry);
+    std::lock_guard<std::mutex> lock(g_roi_mutex);
+    if (g_roi_cache.size() >= 256) g_roi_cache.erase(g_roi_cache.begin());
+    g_roi_cache.push_back(RoiEntry{key, *p, *tlx, *tly, *brx, *bry});
 }
 
 struct WarpArgs {
@@ -241,9 +274,8 @@ int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], c
               "source size %dx%d out of range", src->width, src->height);
     MIS_CHECK(ctx, scale > 0.f, MIS_E_INVALID, "scale must be positive");
     Projector p;
-    projector_set(&p, scale, K, R);
     int tlx, tly;
-    detect_result_roi(&p, src->width, src->height, &tlx, &tly, brx, bry);
+    projector_and_roi(scale, K, R, src->width, src->height, &p, &tlx, &tly, brx, bry);
     for (int i = 0; i < 9; i++) a->m[i] = p.k_rinv[i];
     a->scale = scale; a->tlx = tlx; a->tly = tly;
     a->dw = *brx - tlx + 1; a->dh = *bry - tly + 1;
@@ -257,9 +289,8 @@ int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], c
 extern "C" int mis_warp_roi(float scale, int w, int h, const float K[9], const float R[9], MisRect* roi) {
     if (!K || !R || !roi || w < 1 || h < 1 || !(scale > 0.f)) return MIS_E_INVALID;
     Projector p;
-    projector_set(&p, scale, K, R);
     int tlx, tly, brx, bry;
-    detect_result_roi(&p, w, h, &tlx, &tly, &brx, &bry);
+    projector_and_roi(scale, K, R, w, h, &p, &tlx, &tly, &brx, &bry);
     roi->x = tlx; roi->y = tly; roi->width = brx + 1 - tlx; roi->height = bry + 1 - tly;
     return MIS_OK;
 }

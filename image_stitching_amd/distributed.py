@@ -1,0 +1,268 @@
+"""Panorama job orchestration: one process per GPU, frames sharded in contiguous blocks.
+
+SURVEY.md section 8(e).  The reference is a single process (image_stitching.cpp main()); this module
+spreads the same sequence over N ranks:
+
+  stage                     partition                         exchange (torch.distributed = RCCL over xGMI)
+  detect + describe         frames, contiguous block / rank   none
+  match + RANSAC            pairs dealt round-robin           all-gather of {keypoints, descriptors, counts}
+  component pruning         replicated (n <= 64)              all-reduce (sum) of the n x n confidence matrix
+  warp + blend accumulate   frames (same blocks)              none
+  blend finalise            rank 0                            reduce (sum) of the Laplacian / weight pyramids
+
+16SC3 Laplacian sums are two's-complement wrap-around additions, so they are order independent: the
+pyramids are widened to int32 for the collective (RCCL has no 16-bit integer type) and narrowed with
+wrap afterwards -- bit-exact for any reduction order.  The f32 weight sums are order dependent in the
+last bit, which stays inside the 1-LSB pixel tolerance of the north star.
+
+The orchestration is engine-agnostic: `HipEngine` (the product) drives libmistitch through the C ABI;
+the CPU tests inject an engine of their own to exercise the sharding / collective logic under gloo.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from . import stitching as st
+
+
+def frame_block(n, rank, world):
+    """Contiguous block of frame indices owned by `rank` (blocks differ by at most one frame)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+class Comm:
+    """Thin wrapper over torch.distributed (nccl = RCCL on GPUs, gloo on CPU); identity when world = 1."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def all_gather(self, t):
+        if self.world == 1:
+            return t.unsqueeze(0)
+        import torch.distributed as dist
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def reduce_sum_to_root(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy, no ownership)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(ptr, shape, typestr, device):
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+class HipEngine:
+    """The product engine: every stage runs in libmistitch (HIP) through the C ABI."""
+
+    def __init__(self, ctx, frame_size, config=None):
+        self.ctx = ctx
+        self.cfg = config or st.StitchConfig()
+        self.frame_size = frame_size
+        self.finder = st.OrbFeatureFinder(ctx, frame_size)
+        self.matcher = st.BestOf2NearestMatcher(ctx, self.cfg.match_conf)
+        self.cap = None
+        self.blender = None
+        self._keep = []
+
+    # ---- features ----
+    def detect(self, frames):
+        return self.finder.detect_batch(frames)
+
+    def pack_features(self, feats):
+        """-> (kps u8 [m, cap*24], desc u8 [m, cap*32], counts i32 [m]) device tensors for the all-gather."""
+        cap = self.finder.params.nfeatures + 128 * self.finder.params.nlevels
+        m = len(feats)
+        dev = self.ctx.device
+        kps = torch.zeros((m, cap * 24), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((m, cap * 32), dtype=torch.uint8, device=dev)
+        counts = torch.tensor([len(f) for f in feats], dtype=torch.int32, device=dev)
+        for i, f in enumerate(feats):
+            n = len(f)
+            if n:
+                kps[i, : n * 24] = dev_tensor(f.raw.keypoints, (n * 24,), "|u1", dev)
+                desc[i, : n * 32] = dev_tensor(f.raw.descriptors, (n * 32,), "|u1", dev)
+        self.cap = cap
+        return kps, desc, counts
+
+    def unpack_features(self, kps_all, desc_all, counts_all):
+        """Gathered tensors [n, ...] -> ImageFeatures views (no copies; tensors kept alive)."""
+        self._keep = [kps_all, desc_all, counts_all]
+        counts = counts_all.cpu().tolist()
+        w, h = self.frame_size
+        out = []
+        for i, n in enumerate(counts):
+            raw = capi.MisFeatures()
+            raw.img_idx, raw.img_w, raw.img_h, raw.n = i, w, h, int(n)
+            raw.keypoints = kps_all[i].data_ptr()
+            raw.descriptors = desc_all[i].data_ptr()
+            raw.desc_cols, raw.desc_dtype, raw.owner_ = 32, capi.U8, None
+            out.append(st.ImageFeatures(self.ctx, raw))
+        return out
+
+    def match(self, feats, rank, world):
+        return self.matcher(feats, rank, world)
+
+    def confidence_tensor(self, pm, n):
+        return torch.tensor([m.confidence for m in pm], dtype=torch.float64, device=self.ctx.device).view(n, n)
+
+    # ---- compose ----
+    def warp_roi(self, scale, cam):
+        return st.warp_roi(scale, self.frame_size, cam["K"], cam["R"])
+
+    def begin_compose(self, scale, corners, sizes):
+        x, y, pw, ph = st.result_roi(corners, sizes)
+        btype, bands, sharp = st.blend_config(self.cfg.blend_type, self.cfg.blend_strength, (pw, ph))
+        if self.blender is None or self.blender.type != btype:
+            self.blender = {capi.BLEND_MULTI_BAND: lambda: st.MultiBandBlender(self.ctx, bands),
+                            capi.BLEND_FEATHER: lambda: st.FeatherBlender(self.ctx, sharp), capi.BLEND_NO: lambda: st.Blender(self.ctx)}[btype]()
+        self.blender.prepare(corners, sizes)
+        self.warper = st.SphericalWarper(self.ctx, scale)
+        self.pano_size = (pw, ph)
+        return btype, bands
+
+    def warp_feed(self, frame, cam, roi):
+        tl, img_s, mask = self.warper.warp_fused(frame, cam["K"], cam["R"], roi)
+        self.blender.feed(img_s, mask, tl)
+
+    def accumulators(self):
+        """[(lap int16 tensor, weight f32 tensor)] views of the blender's panorama pyramids."""
+        out = []
+        dev = self.ctx.device
+        nb = self.ctx.lib.mis_blender_num_bands(self.blender.h)
+        for l in range(nb + 1):
+            w, h, lp, wp = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+            self.ctx.check(self.ctx.lib.mis_blender_level_info(self.blender.h, l, C.byref(w), C.byref(h), C.byref(lp), C.byref(wp)))
+            n = w.value * h.value
+            out.append((dev_tensor(lp.value, (n * 3,), "<i2", dev), dev_tensor(wp.value, (n,), "<f4", dev)))
+        return out
+
+    def finalize(self):
+        return self.blender.blend()
+
+    def num_bands(self):
+        return self.ctx.lib.mis_blender_num_bands(self.blender.h)
+
+    def sync(self):
+        torch.cuda.synchronize(self.ctx.device)
+
+
+class StitchJob:
+    """The hot-path sequence of main() (image_stitching.cpp:567-1228) for one panorama, sharded."""
+
+    def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None):
+        self.cfg = config or st.StitchConfig()
+        self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
+        self.cams = cameras
+        self.n = len(cameras)
+        self.rank, self.world = rank, world_size
+        self.comm = Comm(rank, world_size, group)
+        self.my_frames = frame_block(self.n, rank, world_size)
+        self.frame_size = frame_size
+        self.scale = st.Stitcher.warped_image_scale(cameras)
+        counts = {len(frame_block(self.n, r, world_size)) for r in range(world_size)}
+        if len(counts) != 1:
+            raise ValueError("the frame count must divide evenly over the ranks")
+
+    # -- stages -------------------------------------------------------------------------------
+    def stage_features(self, frames):
+        return self.engine.detect([frames[i] for i in self.my_frames])
+
+    def stage_gather(self, local_feats):
+        if self.world == 1:
+            return local_feats
+        kps, desc, counts = self.engine.pack_features(local_feats)
+        kps_all = self.comm.all_gather(kps).flatten(0, 1)
+        desc_all = self.comm.all_gather(desc).flatten(0, 1)
+        counts_all = self.comm.all_gather(counts).flatten(0, 1)
+        return self.engine.unpack_features(kps_all, desc_all, counts_all)
+
+    def stage_match(self, feats):
+        pm = self.engine.match(feats, self.rank, self.world)
+        conf = self.engine.confidence_tensor(pm, self.n)
+        conf = self.comm.all_reduce_sum(conf)          # every pair is owned by exactly one rank
+        return pm, conf
+
+    def stage_prune(self, conf):
+        conf = conf.cpu().numpy()
+        pm = [st.MatchesInfo(confidence=float(c)) for c in conf.reshape(-1)]
+        return list(st.leaveBiggestComponent(pm, self.n, self.cfg.conf_thresh))
+
+    def stage_compose(self, frames, indices):
+        eng = self.engine
+        rois = {i: eng.warp_roi(self.scale, self.cams[i]) for i in indices}
+        corners = [(rois[i][0], rois[i][1]) for i in indices]
+        sizes = [(rois[i][2], rois[i][3]) for i in indices]
+        btype, bands = eng.begin_compose(self.scale, corners, sizes)
+        for i in self.my_frames:
+            if i in rois:
+                eng.warp_feed(frames[i], self.cams[i], rois[i])
+        return btype, bands
+
+    def stage_reduce(self):
+        if self.world == 1:
+            return
+        for lap, wgt in self.engine.accumulators():
+            wide = lap.to(torch.int32)                 # no 16-bit integer type in RCCL: widen, sum, wrap
+            self.comm.reduce_sum_to_root(wide)
+            self.comm.reduce_sum_to_root(wgt)
+            if self.rank == 0:
+                lap.copy_(wide.to(torch.int16))
+
+    def stage_finalize(self):
+        if self.rank == 0:
+            return self.engine.finalize()
+        return None, None
+
+    # -- whole job ---------------------------------------------------------------------------
+    def run(self, frames):
+        feats = self.stage_gather(self.stage_features(frames))
+        pm, conf = self.stage_match(feats)
+        indices = self.stage_prune(conf)
+        btype, bands = self.stage_compose(frames, indices)
+        self.stage_reduce()
+        pano, mask = self.stage_finalize()
+        return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,
+                "pano_size": self.engine.pano_size, "num_bands": bands}
+
+    def breakdown(self, frames, reps=3):
+        """Per-stage wall time (ms, host synchronised between stages) -- diagnostics, not the metric."""
+        out = {}
+
+        def timed(name, fn):
+            self.engine.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            self.engine.sync()
+            out[name] = out.get(name, 0.0) + (time.perf_counter() - t0) * 1e3 / reps
+            return r
+        for _ in range(reps):
+            lf = timed("features (detect+describe)", lambda: self.stage_features(frames))
+            feats = timed("feature all-gather", lambda: self.stage_gather(lf))
+            pm, conf = timed("match + RANSAC", lambda: self.stage_match(feats))
+            idx = timed("prune (host)", lambda: self.stage_prune(conf))
+            timed("warp + blend feed", lambda: self.stage_compose(frames, idx))
+            timed("pyramid reduce", lambda: self.stage_reduce())
+            timed("blend finalise", lambda: self.stage_finalize())
+        return out

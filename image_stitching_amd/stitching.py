@@ -153,20 +153,29 @@ class SphericalWarper:
                                                        C.byref(dimg), C.byref(tl)))
         return (tl.x, tl.y), dst
 
-    def warp_fused(self, src_bgr, K, R, roi=None):
-        """Compose-scale step of main(): warp(img, LINEAR, REFLECT) + warp(mask, NEAREST, CONSTANT) +
-        convertTo(CV_16S) (image_stitching.cpp:1154-1164) -> (tl, img_warped_s, mask_warped)."""
-        simg = as_image(src_bgr)
-        x, y, w, h = roi if roi is not None else warp_roi(self.scale, (simg.width, simg.height), K, R)
-        dst = _empty_image(self.ctx, h, w, 3, torch.int16)
-        msk = _empty_image(self.ctx, h, w, 1, torch.uint8)
-        dimg, mimg = as_image(dst), as_image(msk)
+    def alloc_fused(self, roi):
+        """Output buffers of warp_fused for a roi (16SC3 image, 8U mask), 256-byte aligned rows."""
+        x, y, w, h = roi
+        return _empty_image(self.ctx, h, w, 3, torch.int16), _empty_image(self.ctx, h, w, 1, torch.uint8)
+
+    def warp_fused_into(self, src_bgr, K, R, roi, dst, msk):
+        simg, dimg, mimg = as_image(src_bgr), as_image(dst), as_image(msk)
         ka, kp = _mat9(K)
         ra, rp = _mat9(R)
         tl = capi.MisPoint()
         self.ctx.check(self.ctx.lib.mis_warp_spherical_fused(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(dimg),
                                                              C.byref(mimg), C.byref(tl)))
-        return (tl.x, tl.y), dst, msk
+        return (tl.x, tl.y)
+
+    def warp_fused(self, src_bgr, K, R, roi=None):
+        """Compose-scale step of main(): warp(img, LINEAR, REFLECT) + warp(mask, NEAREST, CONSTANT) +
+        convertTo(CV_16S) (image_stitching.cpp:1154-1164) -> (tl, img_warped_s, mask_warped)."""
+        if roi is None:
+            simg = as_image(src_bgr)
+            roi = warp_roi(self.scale, (simg.width, simg.height), K, R)
+        dst, msk = self.alloc_fused(roi)
+        tl = self.warp_fused_into(src_bgr, K, R, roi, dst, msk)
+        return tl, dst, msk
 
 
 # ------------------------------------------------------------------------------------------------
