@@ -8,8 +8,14 @@
 #include <vector>
 #include "../../include/mistitch.h"
 
+// per-context caches that outlive a call (grow-only device workspaces); freed with the context
+struct MisWorkspace {
+    virtual ~MisWorkspace() {}
+};
+
 struct MisContext {
     int device = 0;
+    MisWorkspace* match_ws = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;

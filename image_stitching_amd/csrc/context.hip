@@ -34,6 +34,7 @@ extern "C" int mis_context_destroy(MisContext* ctx) {
     if (!ctx) return MIS_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    delete ctx->match_ws;
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -1,0 +1,47 @@
+// homography.h -- internal interface of the batched cv::findHomography(RANSAC) engine (homography.hip).
+#pragma once
+#include "common.h"
+
+// One findHomography problem: n correspondences src -> dst (f32 x,y pairs), optional inlier mask.
+struct HomoCall {
+    const float* src;
+    const float* dst;
+    uint8_t* mask;   // n bytes or null
+    long long pt_off;  // offset of this problem's points in the batch-wide scratch arrays
+    int n;
+    int active;      // 0: skipped (result: ok = 0)
+};
+
+struct HomoResult {
+    double H[9];
+    int ok;
+    int iters;   // RANSAC hypotheses evaluated
+    int ninl;    // inliers of the best model
+    int pad;
+};
+
+// Device workspace for a batch of problems (grow-only, owned by the caller).
+struct HomoBatch {
+    int count = 0;            // problems
+    long long points = 0;     // total points over all problems
+    int max_iters = 0;
+    void* mem = nullptr;
+    size_t bytes = 0;
+    // carved pointers (device)
+    HomoCall* calls = nullptr;
+    HomoResult* results = nullptr;
+    void* state = nullptr;
+    int* sub_idx = nullptr;
+    double* Hc = nullptr;
+    int* valid = nullptr;
+    int* good = nullptr;
+    float* scr = nullptr;     // 4 floats per point: compressed inliers
+    double* rec = nullptr;    // 10 doubles per point: per-point terms of the DLT / LM sums
+    unsigned* draw_next = nullptr;  // per problem: stream-position tables of the subset drawing
+    int* draw_idx = nullptr;
+};
+
+int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long points, int max_iters);
+void homo_batch_release(HomoBatch* b);
+// `calls` (device array of b->count entries) must be filled before this is enqueued on ctx->stream.
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence);

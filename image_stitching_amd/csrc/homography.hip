@@ -1,0 +1,890 @@
+// homography.hip -- batched cv::findHomography(src, dst, mask, RANSAC, thresh, maxIters, confidence)
+// (SURVEY K9), the estimator behind BestOf2NearestMatcher::match
+// (image_stitching/image_stitching.cpp:653).  OpenCV sources restated: calib3d fundam.cpp
+// (HomographyEstimatorCallback, HomographyRefineCallback, findHomography), ptsetreg.cpp
+// (RANSACPointSetRegistrator), core lapack.cpp (Jacobi), LMSolver.
+//
+// A batch = many independent problems (one per image pair).  Four kernels, all exact:
+//   draw_kernel       per problem: the RANSAC subset sequence.  cv::RNG(-1)'s output stream is data
+//                     independent; what depends on the data is how many draws each getSubset attempt
+//                     consumes (duplicate redraws) and whether it passes checkSubset.  Every stream
+//                     position is simulated as the start of ONE attempt in parallel, then one thread
+//                     chases start -> end -> ... through the table: the exact sequential sequence.
+//   hyp_kernel        one thread per hypothesis (128 LDS slots per workgroup): 4-point normalised DLT,
+//                     9x9 Jacobi on the upper triangle, inlier count.
+//   scan_tail_kernel  sequential replay of the adaptive loop (niters update) over the scored
+//                     hypotheses; when the loop ends: inlier mask, ordered compaction, DLT on all
+//                     inliers, 10-iteration LM.  f64 sums keep the CPU's order: per-point terms in
+//                     parallel, then ONE thread per accumulator; Jacobi rotations spread over n threads.
+// Phase 0 covers hypotheses [0,128) (overlapping pairs converge there), phase 1 the rest.
+#include "homography.h"
+#include "dev_math.h"
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr int HYP_TPB = 128;      // hypotheses (threads) per workgroup of hyp_kernel
+constexpr int SLOT_DOUBLES = 126; // 36 (strict upper triangle) + 9 (diagonal / eigenvalues) + 81 (eigenvectors)
+constexpr int PHASE0 = 128;       // hypotheses evaluated before the first replay
+constexpr int RNG_TABLE = 1 << 17;
+constexpr int TB = 256;           // threads of draw / scan_tail workgroups
+
+struct RansacState {
+    int mode;      // 0 skip, 1 exactly 4 points, 2 RANSAC
+    int n_sub;     // subsets drawn so far (the sequential getSubset sequence)
+    int iter, niters, max_good, done, best_k, result;
+    int draw_k, draw_fail;   // next iteration to draw; getSubset exhausted its 10000 attempts
+    long long draw_pos;      // RNG stream position after the last drawn subset
+};
+
+// ---------------------------------------------------------------- shared scalar helpers --------
+__device__ __forceinline__ double cv_hypot(double a, double b) {
+    a = fabs(a); b = fabs(b);
+    if (a > b) { b /= a; return a * sqrt(1 + b * b); }
+    if (b > 0) { a /= b; return b * sqrt(1 + a * a); }
+    return 0;
+}
+
+// fundam.cpp haveCollinearPoints (4.5.x: only the last point is tested) + the orientation test
+__device__ bool have_collinear4(const float* p) {
+    const int i = 3;
+    for (int j = 0; j < i; j++) {
+        double dx1 = p[2 * j] - p[2 * i], dy1 = p[2 * j + 1] - p[2 * i + 1];
+        for (int k = 0; k < j; k++) {
+            double dx2 = p[2 * k] - p[2 * i], dy2 = p[2 * k + 1] - p[2 * i + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+__device__ double det3_pts(const float* p, int t0, int t1, int t2) {
+    double a00 = p[2 * t0], a01 = p[2 * t0 + 1], a10 = p[2 * t1], a11 = p[2 * t1 + 1], a20 = p[2 * t2], a21 = p[2 * t2 + 1];
+    return a00 * (a11 * 1. - 1. * a21) - a01 * (a10 * 1. - 1. * a20) + 1. * (a10 * a21 - a11 * a20);
+}
+__device__ bool check_subset(const float* s, const float* d) {
+    if (have_collinear4(s) || have_collinear4(d)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; i++) negative += det3_pts(s, tt[i][0], tt[i][1], tt[i][2]) * det3_pts(d, tt[i][0], tt[i][1], tt[i][2]) < 0;
+    return negative == 0 || negative == 4;
+}
+
+__device__ int ransac_update_num_iters(double p, double ep, int max_iters) {
+    if (p < 0.) p = 0.; if (p > 1.) p = 1.;
+    if (ep < 0.) ep = 0.; if (ep > 1.) ep = 1.;
+    double num = 1. - p; if (num < DBL_MIN) num = DBL_MIN;
+    double w = 1. - ep, w2 = w * w;
+    double denom = 1. - w2 * w2;
+    if (denom < DBL_MIN) return 0;
+    num = mis_log_d(num);
+    denom = mis_log_d(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : mis_round_d(num / denom);
+}
+
+__device__ __forceinline__ int is_inlier(const float* Hf, float Mx, float My, float mx, float my, float t) {
+    float ww = 1.f / ((Hf[6] * Mx + Hf[7] * My) + 1.f);
+    float dx = ((Hf[0] * Mx + Hf[1] * My) + Hf[2]) * ww - mx;
+    float dy = ((Hf[3] * Mx + Hf[4] * My) + Hf[5]) * ww - my;
+    float e = dx * dx + dy * dy;
+    return e <= t;
+}
+
+// eigenvector of the smallest eigenvalue (H0) -> de-normalised, scaled homography
+__device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy cMx cMy smx smy sMx sMy */, double* H) {
+    double T[9], R[9];
+    const double invHnorm[9] = {1. / nrm[4], 0, nrm[0], 0, 1. / nrm[5], nrm[1], 0, 0, 1};
+    const double Hnorm2[9] = {nrm[6], 0, -nrm[2] * nrm[6], 0, nrm[7], -nrm[3] * nrm[7], 0, 0, 1};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double acc = 0;
+        for (int k = 0; k < 3; k++) acc += invHnorm[i * 3 + k] * H0[k * 3 + j];
+        T[i * 3 + j] = acc;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double acc = 0;
+        for (int k = 0; k < 3; k++) acc += T[i * 3 + k] * Hnorm2[k * 3 + j];
+        R[i * 3 + j] = acc;
+    }
+    double sc = 1. / R[8];
+    for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
+}
+
+// ---------------------------------------------------------------- draw_kernel ------------------
+// cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
+struct DrawCtx {
+    const unsigned* U;
+    unsigned long long state_T;  // generator state after RNG_TABLE draws
+    // serial continuation beyond the table (positions are visited in increasing order)
+    unsigned long long cur_state;
+    long long cur_pos;
+};
+__device__ __forceinline__ unsigned draw_at(DrawCtx& d, long long pos) {
+    if (pos < RNG_TABLE) return d.U[pos];
+    unsigned v = 0;
+    while (d.cur_pos <= pos) {
+        d.cur_state = (unsigned long long)(unsigned)d.cur_state * 4164903690u + (unsigned)(d.cur_state >> 32);
+        v = (unsigned)d.cur_state;
+        d.cur_pos++;
+    }
+    return v;
+}
+
+// ONE getSubset attempt starting at stream position pos: four distinct indices (redraw on duplicates),
+// then checkSubset.  Returns the end position; *pass / idx describe the attempt.
+__device__ long long attempt_at(DrawCtx& d, long long pos, const float* src, const float* dst, int n, int* idx, bool* pass) {
+    float ms1[8], ms2[8];
+    for (int i = 0; i < 4; i++) {
+        int idx_i;
+        bool dup;
+        do {
+            idx_i = (int)(draw_at(d, pos++) % (unsigned)n);
+            dup = false;
+            for (int q = 0; q < i; q++) dup |= idx[q] == idx_i;
+        } while (dup);
+        idx[i] = idx_i;
+        const float2 ps = reinterpret_cast<const float2*>(src)[idx_i], pd = reinterpret_cast<const float2*>(dst)[idx_i];
+        ms1[2 * i] = ps.x; ms1[2 * i + 1] = ps.y;
+        ms2[2 * i] = pd.x; ms2[2 * i + 1] = pd.y;
+    }
+    *pass = check_subset(ms1, ms2);
+    return pos;
+}
+
+// Subsets of iterations [st->draw_k, k_hi) of every problem.  Attempt start positions are simulated in
+// chunks of DRAW_CHUNK stream positions by all threads, then thread 0 chases through the chunk; a new
+// chunk starts exactly where the chase left the previous one.
+constexpr int DRAW_CHUNK = 8192;
+__global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
+                                                  unsigned long long state_T, int max_iters, int phase, int k_hi_arg) {
+    __shared__ unsigned char tab[DRAW_CHUNK];  // per position: min(end - start, 127) | pass << 7
+    __shared__ long long s_pos;
+    __shared__ int s_k, s_attempts, s_more;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const HomoCall c = calls[b];
+    RansacState* st = states + b;
+    if (phase == 0) {
+        if (t == 0) {
+            st->mode = (!c.active || c.n < 4) ? 0 : (c.n == 4 ? 1 : 2);
+            st->n_sub = 0; st->iter = 0; st->niters = max_iters > 1 ? max_iters : 1; st->max_good = 0; st->done = 0; st->best_k = -1; st->result = 0;
+            st->draw_k = 0; st->draw_fail = 0; st->draw_pos = 0;
+        }
+        if (!c.active || c.n <= 4) return;
+    } else {
+        if (st->mode != 2 || st->done || st->draw_fail) return;
+    }
+    __syncthreads();
+    const int k_hi = min(k_hi_arg, phase == 0 ? max_iters : st->niters);
+    if (t == 0) { s_pos = st->draw_pos; s_k = st->draw_k; s_attempts = 0; s_more = s_k < k_hi; }
+    __syncthreads();
+    DrawCtx d{U, state_T, state_T, RNG_TABLE};
+    int* didx = draw_idx + (size_t)b * DRAW_CHUNK * 4;
+    int* sidx = sub_idx + (size_t)b * max_iters * 4;
+    while (s_more) {
+        const long long base = s_pos;
+        for (int o = t; o < DRAW_CHUNK; o += TB) {
+            int idx[4];
+            bool pass;
+            long long e = attempt_at(d, base + o, c.src, c.dst, c.n, idx, &pass);
+            long long delta = e - (base + o);
+            tab[o] = (unsigned char)((delta > 127 ? 127 : delta) | (pass ? 0x80 : 0));
+            *reinterpret_cast<int4*>(didx + 4 * o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+        }
+        __syncthreads();
+        if (t == 0) {
+            long long pos = base;
+            int k = s_k, attempts = s_attempts;
+            bool fail = false;
+            while (k < k_hi && pos < base + DRAW_CHUNK) {
+                unsigned char e = tab[pos - base];
+                long long start = pos;
+                bool pass;
+                if ((e & 0x7f) != 127) { pass = (e & 0x80) != 0; pos += e & 0x7f; }
+                else {  // an attempt that consumed > 126 draws (tiny n): redo it serially
+                    int idx[4];
+                    pos = attempt_at(d, pos, c.src, c.dst, c.n, idx, &pass);
+                    if (pass) { sidx[4 * k] = idx[0]; sidx[4 * k + 1] = idx[1]; sidx[4 * k + 2] = idx[2]; sidx[4 * k + 3] = idx[3]; start = -1; }
+                }
+                attempts++;
+                if (pass) {
+                    if (start >= 0) *reinterpret_cast<int4*>(sidx + 4 * k) = *reinterpret_cast<const int4*>(didx + 4 * (start - base));
+                    k++; attempts = 0;
+                } else if (attempts >= 10000) { fail = true; break; }  // getSubset gave up: the RANSAC loop ends here
+            }
+            s_pos = pos; s_k = k; s_attempts = attempts;
+            s_more = !fail && k < k_hi;
+            if (!s_more) { st->draw_pos = pos; st->draw_k = k; st->draw_fail = fail; st->n_sub = k; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- hyp_kernel -------------------
+// per-thread 9x9 symmetric eigen-problem in LDS: element e of the thread's slot at sl[e * HYP_TPB + t]
+struct CSlot {
+    double* base;
+    __device__ __forceinline__ double& u(int r, int c) const { return base[(r * 9 - r * (r + 1) / 2 + (c - r - 1)) * HYP_TPB]; }  // r < c
+    __device__ __forceinline__ double& w(int k) const { return base[(36 + k) * HYP_TPB]; }
+    __device__ __forceinline__ double& v(int e) const { return base[(45 + e) * HYP_TPB]; }
+};
+
+// core/src/lapack.cpp JacobiImpl_<double> for n = 9; the algorithm only ever touches the strict upper
+// triangle and the diagonal (kept in w), eigenvectors are the rows of v, eigenvalues sorted descending
+__device__ void jacobi9_compact(const CSlot s) {
+    const int n = 9;
+    const double eps = DBL_EPSILON;
+    int i, j, k, m, indR[9], indC[9];
+    double mv;
+    for (i = 0; i < n; i++) { for (j = 0; j < n; j++) s.v(i * n + j) = 0; s.v(i * n + i) = 1; }
+    for (k = 0; k < n; k++) {
+        if (k < n - 1) {
+            for (m = k + 1, mv = fabs(s.u(k, m)), i = k + 2; i < n; i++) {
+                double val = fabs(s.u(k, i));
+                if (mv < val) mv = val, m = i;
+            }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabs(s.u(0, k)), i = 1; i < k; i++) {
+                double val = fabs(s.u(i, k));
+                if (mv < val) mv = val, m = i;
+            }
+            indC[k] = m;
+        }
+    }
+    for (int iters = 0; iters < n * n * 30; iters++) {
+        for (k = 0, mv = fabs(s.u(0, indR[0])), i = 1; i < n - 1; i++) {
+            double val = fabs(s.u(i, indR[i]));
+            if (mv < val) mv = val, k = i;
+        }
+        int l = indR[k];
+        for (i = 1; i < n; i++) {
+            double val = fabs(s.u(indC[i], i));
+            if (mv < val) mv = val, k = indC[i], l = i;
+        }
+        double p = s.u(k, l);
+        if (fabs(p) <= eps) break;
+        double y = (s.w(l) - s.w(k)) * 0.5;
+        double t = fabs(y) + cv_hypot(p, y);
+        double sn = cv_hypot(p, t);
+        double c = t / sn;
+        sn = p / sn; t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+        s.u(k, l) = 0;
+        s.w(k) -= t; s.w(l) += t;
+        double a0, b0;
+#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
+        for (i = 0; i < k; i++) MIS_ROT(s.u(i, k), s.u(i, l));
+        for (i = k + 1; i < l; i++) MIS_ROT(s.u(k, i), s.u(i, l));
+        for (i = l + 1; i < n; i++) MIS_ROT(s.u(k, i), s.u(l, i));
+        for (i = 0; i < n; i++) MIS_ROT(s.v(n * k + i), s.v(n * l + i));
+#undef MIS_ROT
+        for (j = 0; j < 2; j++) {
+            int idx = j == 0 ? k : l;
+            if (idx < n - 1) {
+                for (m = idx + 1, mv = fabs(s.u(idx, m)), i = idx + 2; i < n; i++) {
+                    double val = fabs(s.u(idx, i));
+                    if (mv < val) mv = val, m = i;
+                }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                for (m = 0, mv = fabs(s.u(0, idx)), i = 1; i < idx; i++) {
+                    double val = fabs(s.u(i, idx));
+                    if (mv < val) mv = val, m = i;
+                }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (k = 0; k < n - 1; k++) {
+        m = k;
+        for (i = k + 1; i < n; i++) if (s.w(m) < s.w(i)) m = i;
+        if (k != m) {
+            double tw = s.w(m); s.w(m) = s.w(k); s.w(k) = tw;
+            for (i = 0; i < n; i++) { double tv = s.v(n * m + i); s.v(n * m + i) = s.v(n * k + i); s.v(n * k + i) = tv; }
+        }
+    }
+}
+
+// HomographyEstimatorCallback::runKernel on 4 correspondences by one thread
+__device__ int dlt4_compact(const float* M, const float* m, const CSlot s, double* H) {
+    const int count = 4;
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; i++) { cmx += m[2 * i]; cmy += m[2 * i + 1]; cMx += M[2 * i]; cMy += M[2 * i + 1]; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; i++) {
+        smx += fabs(m[2 * i] - cmx); smy += fabs(m[2 * i + 1] - cmy);
+        sMx += fabs(M[2 * i] - cMx); sMy += fabs(M[2 * i + 1] - cMy);
+    }
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double LtL[45];  // upper triangle incl. diagonal, row-major; static indices only -> registers
+#pragma unroll
+    for (int e = 0; e < 45; e++) LtL[e] = 0;
+#pragma unroll
+    for (int i = 0; i < count; i++) {
+        const double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+        const double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++, e++) LtL[e] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    {
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++, e++) {
+                if (k == j) s.w(j) = LtL[e];
+                else s.u(j, k) = LtL[e];
+            }
+    }
+    jacobi9_compact(s);
+    double H0[9];
+    for (int i = 0; i < 9; i++) H0[i] = s.v(72 + i);
+    const double nrm[8] = {cmx, cmy, cMx, cMy, smx, smy, sMx, sMy};
+    dlt_denormalise(H0, nrm, H);
+    return 1;
+}
+
+__global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, const RansacState* states, const int* sub_idx, double* Hc, int* valid,
+                                                      int* good, int lo, int max_iters, float thr) {
+    extern __shared__ double sl[];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const RansacState st = states[b];
+    if (st.mode != 2 || st.done) return;
+    const int limit = min(st.n_sub, st.niters);  // hypotheses at or beyond niters can never be replayed
+    const int k0 = lo + blockIdx.x * HYP_TPB;
+    if (k0 >= limit) return;
+    const int k = k0 + t;
+    if (k >= limit) return;
+    const HomoCall c = calls[b];
+    const int* id = sub_idx + ((size_t)b * max_iters + k) * 4;
+    float ms1[8], ms2[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = id[i];
+        ms1[2 * i] = c.src[2 * q]; ms1[2 * i + 1] = c.src[2 * q + 1];
+        ms2[2 * i] = c.dst[2 * q]; ms2[2 * i + 1] = c.dst[2 * q + 1];
+    }
+    double H[9];
+    const CSlot s{sl + t};
+    int ok = dlt4_compact(ms1, ms2, s, H);
+    int cnt = 0;
+    if (ok) {
+        float Hf[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Hf[i] = (float)H[i];
+        for (int i = 0; i < c.n; i++) cnt += is_inlier(Hf, c.src[2 * i], c.src[2 * i + 1], c.dst[2 * i], c.dst[2 * i + 1], thr);
+        double* o = Hc + ((size_t)b * max_iters + k) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o[i] = H[i];
+    }
+    valid[(size_t)b * max_iters + k] = ok;
+    good[(size_t)b * max_iters + k] = cnt;
+}
+
+// ---------------------------------------------------------------- scan_tail_kernel -------------
+struct TailShared {
+    double A[81], V[81], W[9];
+    double best[9], nrm[8];
+    double lm[8 + 8 + 64 + 64 + 8 + 8 + 8 + 8];  // x, xd, A, Ap, v, d, D, scalars
+    float Hf[9];
+    int indR[9], indC[9];
+    int np, go;
+};
+
+// Jacobi with the n independent plane rotations of a step spread over n threads and the four
+// index-table scans over four threads; the arithmetic of every element is that of the serial loop.
+// Called by the whole workgroup (threads >= n only take part in the barriers).
+__device__ void jacobi_eigen_coop(TailShared& S, const int n) {
+    double* A = S.A; double* V = S.V; double* W = S.W;
+    const int t = threadIdx.x;
+    const double eps = DBL_EPSILON;
+    int i, k, l, m;
+    double mv;
+    if (t < n) {
+        for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
+        W[t] = A[(n + 1) * t];
+        k = t;
+        if (k < n - 1) {
+            for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
+                double val = fabs(A[n * k + i]);
+                if (mv < val) mv = val, m = i;
+            }
+            S.indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
+                double val = fabs(A[n * i + k]);
+                if (mv < val) mv = val, m = i;
+            }
+            S.indC[k] = m;
+        }
+    }
+    __syncthreads();
+    const int maxIters = n * n * 30;
+    if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
+        for (k = 0, mv = fabs(A[S.indR[0]]), i = 1; i < n - 1; i++) {
+            double val = fabs(A[n * i + S.indR[i]]);
+            if (mv < val) mv = val, k = i;
+        }
+        l = S.indR[k];
+        for (i = 1; i < n; i++) {
+            double val = fabs(A[n * S.indC[i] + i]);
+            if (mv < val) mv = val, k = S.indC[i], l = i;
+        }
+        const double p = A[n * k + l];
+        if (fabs(p) <= eps) break;  // uniform: every thread reads the same LDS words
+        const double y = (W[l] - W[k]) * 0.5;
+        double tt = fabs(y) + cv_hypot(p, y);
+        double sn = cv_hypot(p, tt);
+        const double c = tt / sn;
+        sn = p / sn; tt = (p / tt) * p;
+        if (y < 0) sn = -sn, tt = -tt;
+        __syncthreads();  // all pivot inputs read before anything is rewritten
+        if (t == 0) { A[n * k + l] = 0; W[k] -= tt; W[l] += tt; }
+        if (t < n) {
+            double a0, b0;
+#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
+            if (t < k) MIS_ROT(A[n * t + k], A[n * t + l]);
+            else if (t > k && t < l) MIS_ROT(A[n * k + t], A[n * t + l]);
+            else if (t > l) MIS_ROT(A[n * k + t], A[n * l + t]);
+            MIS_ROT(V[n * k + t], V[n * l + t]);
+#undef MIS_ROT
+        }
+        __syncthreads();
+        if (t < 4) {
+            const int idx = t < 2 ? k : l;
+            if ((t & 1) == 0) {
+                if (idx < n - 1) {
+                    for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
+                        double val = fabs(A[n * idx + i]);
+                        if (mv < val) mv = val, m = i;
+                    }
+                    S.indR[idx] = m;
+                }
+            } else if (idx > 0) {
+                for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
+                    double val = fabs(A[n * i + idx]);
+                    if (mv < val) mv = val, m = i;
+                }
+                S.indC[idx] = m;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (k = 0; k < n - 1; k++) {
+            m = k;
+            for (i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
+            if (k != m) {
+                double tw = W[m]; W[m] = W[k]; W[k] = tw;
+                for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// LM callback of the homography refinement (fundam.cpp HomographyRefineCallback)
+__device__ __forceinline__ void lm_point(const double* h, double Mx, double My, double* ww, double* xi, double* yi) {
+    double w = (h[6] * Mx + h[7] * My) + 1.;
+    w = fabs(w) > DBL_EPSILON ? 1. / w : 0;
+    *ww = w;
+    *xi = ((h[0] * Mx + h[1] * My) + h[2]) * w;
+    *yi = ((h[3] * Mx + h[4] * My) + h[5]) * w;
+}
+
+// HomographyEstimatorCallback::runKernel on np points (s1 -> d1) by the whole workgroup; S.best is
+// overwritten unless the configuration is degenerate.  Sums keep the sequential order.
+__device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np, double* rec) {
+    const int t = threadIdx.x;
+    if (t < 4) {
+        double acc = 0;
+        const float* p = t < 2 ? d1 : s1;  // cmx cmy cMx cMy
+        for (int i = 0; i < np; i++) acc += p[2 * i + (t & 1)];
+        S.nrm[t] = acc / np;
+    }
+    __syncthreads();
+    if (t < 4) {
+        double acc = 0, c = S.nrm[t];
+        const float* p = t < 2 ? d1 : s1;  // smx smy sMx sMy
+        for (int i = 0; i < np; i++) acc += fabs(p[2 * i + (t & 1)] - c);
+        S.nrm[4 + t] = acc;
+    }
+    __syncthreads();
+    const bool degenerate = fabs(S.nrm[4]) < DBL_EPSILON || fabs(S.nrm[5]) < DBL_EPSILON || fabs(S.nrm[6]) < DBL_EPSILON || fabs(S.nrm[7]) < DBL_EPSILON;
+    __syncthreads();
+    if (t == 0) S.go = !degenerate;
+    if (degenerate) { __syncthreads(); return; }
+    if (t < 4) S.nrm[4 + t] = np / S.nrm[4 + t];
+    __syncthreads();
+    {
+        const double cmx = S.nrm[0], cmy = S.nrm[1], cMx = S.nrm[2], cMy = S.nrm[3], smx = S.nrm[4], smy = S.nrm[5], sMx = S.nrm[6], sMy = S.nrm[7];
+        for (int i = t; i < np; i += TB) {
+            double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
+            double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
+            double* r = rec + 10 * (size_t)i;  // X Y 1 0 -xX -xY -x -yX -yY -y
+            r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
+        }
+    }
+    __syncthreads();
+    if (t < 45) {
+        int j = 0, k = t;  // t-th entry of the upper triangle, row-major
+        while (k >= 9 - j) { k -= 9 - j; j++; }
+        k += j;
+        const int lxi[9] = {0, 1, 2, 3, 3, 3, 4, 5, 6}, lyi[9] = {3, 3, 3, 0, 1, 2, 7, 8, 9};
+        const int xj = lxi[j], xk = lxi[k], yj = lyi[j], yk = lyi[k];
+        double acc = 0;
+        for (int i = 0; i < np; i++) {
+            const double* r = rec + 10 * (size_t)i;
+            acc += r[xj] * r[xk] + r[yj] * r[yk];
+        }
+        S.A[j * 9 + k] = acc;
+    }
+    __syncthreads();
+    if (t < 81) { int j = t / 9, k = t % 9; if (k < j) S.A[j * 9 + k] = S.A[k * 9 + j]; }
+    __syncthreads();
+    jacobi_eigen_coop(S, 9);
+    if (t == 0) dlt_denormalise(S.V + 72, S.nrm, S.best);
+    __syncthreads();
+}
+
+// createLMSolver(HomographyRefineCallback, 10)->run(H8): OpenCV <= 4.5 LMSolverImpl::run
+__device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, int np, double* rec) {
+    const int t = threadIdx.x;
+    double* x = S.lm;            double* xd = x + 8;   double* A = xd + 8;  double* Ap = A + 64;
+    double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // S, Sd, rmax, accepted, lambda, lc, need_invert, nu
+    auto normal_eq = [&](const double* h, bool with_J) {
+        for (int p = t; p < np; p += TB) {
+            double Mx = (double)s1[2 * p], My = (double)s1[2 * p + 1], ww, xi, yi;
+            lm_point(h, Mx, My, &ww, &xi, &yi);
+            double* r = rec + 10 * (size_t)p;  // a b ww c0 c1 c2 c3 e0 e1 0
+            r[7] = xi - (double)d1[2 * p]; r[8] = yi - (double)d1[2 * p + 1];
+            if (with_J) {
+                r[0] = Mx * ww; r[1] = My * ww; r[2] = ww;
+                r[3] = -Mx * ww * xi; r[4] = -My * ww * xi; r[5] = -Mx * ww * yi; r[6] = -My * ww * yi; r[9] = 0;
+            }
+        }
+        __syncthreads();
+        const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
+        if (with_J && t < 36) {
+            int i = 0, j = t;
+            while (j >= 8 - i) { j -= 8 - i; i++; }
+            j += i;
+            const int a0 = j0[i], b0 = j0[j], a1 = j1[i], b1 = j1[j];
+            double acc = 0;
+            for (int p = 0; p < np; p++) {
+                const double* r = rec + 10 * (size_t)p;
+                acc += r[a0] * r[b0];
+                acc += r[a1] * r[b1];
+            }
+            A[i * 8 + j] = acc; A[j * 8 + i] = acc;
+        } else if (with_J && t >= 64 && t < 72) {
+            const int i = t - 64, a0 = j0[i], a1 = j1[i];
+            double acc = 0;
+            for (int p = 0; p < np; p++) {
+                const double* r = rec + 10 * (size_t)p;
+                acc += r[a0] * r[7];
+                acc += r[a1] * r[8];
+            }
+            v[i] = acc;
+        } else if (t == 128) {
+            double acc = 0, mx = 0;
+            for (int p = 0; p < np; p++) {
+                const double* r = rec + 10 * (size_t)p;
+                double e0 = r[7], e1 = r[8];
+                acc += e0 * e0; acc += e1 * e1;
+                if (fabs(e0) > mx) mx = fabs(e0);
+                if (fabs(e1) > mx) mx = fabs(e1);
+            }
+            sc[with_J ? 0 : 1] = acc;
+            if (with_J) sc[2] = mx;
+        }
+        __syncthreads();
+    };
+    if (t < 8) x[t] = S.best[t];
+    __syncthreads();
+    normal_eq(x, true);
+    if (t < 8) D[t] = A[t * 8 + t];
+    if (t == 0) { sc[4] = 1; sc[5] = 0.75; }  // lambda, lc
+    __syncthreads();
+    for (int iter = 0;;) {
+        if (t < 64) S.A[t] = (t / 8 == t % 8) ? A[t] + sc[4] * D[t / 8] : A[t];
+        __syncthreads();
+        jacobi_eigen_coop(S, 8);
+        if (t == 0) {
+            // solve(Ap, v, d, DECOMP_EIG): Jacobi + SVBkSb back substitution
+            double thrw = 0;
+            for (int i = 0; i < 8; i++) thrw += S.W[i];
+            thrw *= DBL_EPSILON * 2;
+            for (int j = 0; j < 8; j++) d[j] = 0;
+            for (int i = 0; i < 8; i++) {
+                double wi = S.W[i];
+                if (fabs(wi) <= thrw) continue;
+                wi = 1 / wi;
+                double s = 0;
+                for (int j = 0; j < 8; j++) s += S.V[i * 8 + j] * v[j];
+                s *= wi;
+                for (int j = 0; j < 8; j++) d[j] = d[j] + s * S.V[i * 8 + j];
+            }
+            for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
+        }
+        __syncthreads();
+        normal_eq(xd, false);  // Sd
+        if (t == 0) {
+            double Sv = sc[0], Sd = sc[1], lambda = sc[4], lc = sc[5];
+            double temp_d[8], dS = 0;
+            for (int i = 0; i < 8; i++) {
+                double s = 0;
+                for (int j = 0; j < 8; j++) s += A[i * 8 + j] * d[j];
+                temp_d[i] = s * -1. + v[i] * 2.;
+            }
+            for (int i = 0; i < 8; i++) dS += d[i] * temp_d[i];
+            double R = (Sv - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+            sc[6] = 0;
+            if (R > 0.75) {
+                lambda *= 0.5;
+                if (lambda < lc) lambda = 0;
+            } else if (R < 0.25) {
+                double tt = 0;
+                for (int i = 0; i < 8; i++) tt += d[i] * v[i];
+                double nu = (Sd - Sv) / (fabs(tt) > DBL_EPSILON ? tt : 1) + 2;
+                nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+                if (lambda == 0) sc[6] = 1;  // needs invert(A): done by the whole workgroup below
+                else lambda *= nu;
+                sc[7] = nu;
+            }
+            sc[4] = lambda; sc[5] = lc;
+        }
+        __syncthreads();
+        if (sc[6] != 0.) {
+            // invert(A, Ap, DECOMP_EIG) -> lambda = lc = 1 / max |diag|, nu halved
+            if (t < 64) S.A[t] = A[t];
+            __syncthreads();
+            jacobi_eigen_coop(S, 8);
+            if (t == 0) {
+                double thrw = 0;
+                for (int i = 0; i < 8; i++) thrw += S.W[i];
+                thrw *= DBL_EPSILON * 2;
+                for (int e = 0; e < 64; e++) Ap[e] = 0;
+                for (int i = 0; i < 8; i++) {
+                    double wi = S.W[i];
+                    if (fabs(wi) <= thrw) continue;
+                    wi = 1 / wi;
+                    for (int r = 0; r < 8; r++)
+                        for (int c = 0; c < 8; c++) Ap[r * 8 + c] = Ap[r * 8 + c] + S.V[i * 8 + r] * (S.V[i * 8 + c] * wi);
+                }
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < 8; i++) { double a = fabs(Ap[i * 8 + i]); if (a > maxval) maxval = a; }
+                double lambda = 1. / maxval, nu = sc[7] * 0.5;
+                sc[5] = lambda;
+                sc[4] = lambda * nu;
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double Sv = sc[0], Sd = sc[1];
+            sc[3] = Sd < Sv ? 1. : 0.;
+            if (Sd < Sv) { sc[0] = Sd; for (int i = 0; i < 8; i++) x[i] = xd[i]; }
+        }
+        __syncthreads();
+        if (sc[3] != 0.) normal_eq(x, true);
+        iter++;
+        double dmax = 0;
+        for (int i = 0; i < 8; i++) { double a = fabs(d[i]); if (a > dmax) dmax = a; }
+        bool proceed = iter < 10 && dmax >= (double)FLT_EPSILON && sc[2] >= (double)FLT_EPSILON;
+        __syncthreads();
+        if (!proceed) break;
+    }
+    if (t < 8) S.best[t] = x[t];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
+                                                       float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
+                                                       double confidence, float thr) {
+    __shared__ TailShared S;
+    __shared__ int s_done_now;
+    __shared__ int wcnt[TB / 64];
+    __shared__ int s_base;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const HomoCall c = calls[b];
+    RansacState* st = states + b;
+    HomoResult* res = results + b;
+    const int n = c.n;
+    float* s1 = scr_all + 4 * c.pt_off;
+    float* d1 = s1 + 2 * (size_t)(n > 0 ? n : 0);
+    double* rec = rec_all + 10 * c.pt_off;
+    if (st->done) return;  // finished in an earlier phase (uniform)
+    const int mode = st->mode;
+    if (t == 0) s_done_now = 0;
+    __syncthreads();
+    if (mode == 0) {
+        for (int i = t; c.mask && c.active && i < n; i += TB) c.mask[i] = 0;
+        if (t == 0) { res->ok = 0; res->iters = 0; res->ninl = 0; st->done = 1; }
+        return;
+    }
+    if (mode == 1) {
+        // exactly four correspondences: runKernel directly, mask all ones, no refinement
+        if (t == 0) for (int i = 0; i < 9; i++) S.best[i] = 0;
+        __syncthreads();
+        dlt_coop(S, c.src, c.dst, 4, rec);
+        const int ok = S.go;
+        for (int i = t; c.mask && i < n; i += TB) c.mask[i] = ok ? 1 : 0;
+        if (t == 0) { res->ok = ok; res->iters = 0; res->ninl = ok ? 4 : 0; if (ok) for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; st->done = 1; }
+        return;
+    }
+    // ---- replay of RANSACPointSetRegistrator::run over hypotheses [lo, hi) ----
+    if (t == 0) {
+        int iter = st->iter, niters = st->niters, max_good = st->max_good, best_k = st->best_k;
+        const int nsub = st->n_sub;
+        int k = lo;
+        for (; k < hi && k < nsub && iter < niters; k++) {
+            iter++;
+            if (!valid[(size_t)b * max_iters + k]) continue;
+            int g = good[(size_t)b * max_iters + k];
+            if (g > (max_good > 3 ? max_good : 3)) {
+                best_k = k; max_good = g;
+                niters = ransac_update_num_iters(confidence, (double)(n - g) / n, niters);
+            }
+        }
+        st->iter = iter; st->niters = niters; st->max_good = max_good; st->best_k = best_k;
+        // the loop ends when iter reaches niters, when getSubset failed (subsets exhausted) or at maxIters
+        if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; }
+    }
+    __syncthreads();
+    if (!s_done_now) return;
+    const int result = st->max_good > 0;
+    if (t == 0) { res->iters = st->iter; res->ok = result; res->ninl = 0; }
+    if (!result) {
+        for (int i = t; c.mask && i < n; i += TB) c.mask[i] = 0;
+        return;
+    }
+    // best model -> mask, ordered compaction of the inliers (compressElems)
+    if (t == 0) {
+        const double* hb = Hc + ((size_t)b * max_iters + st->best_k) * 9;
+        for (int i = 0; i < 9; i++) { S.best[i] = hb[i]; S.Hf[i] = (float)hb[i]; }
+        s_base = 0;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += TB) {
+        int i = i0 + t, f = 0;
+        if (i < n) f = is_inlier(S.Hf, c.src[2 * i], c.src[2 * i + 1], c.dst[2 * i], c.dst[2 * i + 1], thr);
+        if (c.mask && i < n) c.mask[i] = (uint8_t)f;
+        unsigned long long bal = __ballot(f);
+        int within = __popcll(bal & ((1ull << (t & 63)) - 1ull));
+        if ((t & 63) == 0) wcnt[t >> 6] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int k = 0; k < (t >> 6); k++) off += wcnt[k];
+        if (f) {
+            s1[2 * (off + within)] = c.src[2 * i]; s1[2 * (off + within) + 1] = c.src[2 * i + 1];
+            d1[2 * (off + within)] = c.dst[2 * i]; d1[2 * (off + within) + 1] = c.dst[2 * i + 1];
+        }
+        __syncthreads();
+        if (t == 0) { int s = 0; for (int k = 0; k < TB / 64; k++) s += wcnt[k]; s_base += s; }
+        __syncthreads();
+    }
+    const int np = s_base;
+    if (np > 0) {
+        dlt_coop(S, s1, d1, np, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
+        lm_refine_coop(S, s1, d1, np, rec);
+    }
+    if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; }
+}
+
+// ---------------------------------------------------------------- host side --------------------
+struct RngTable {
+    unsigned* U = nullptr;
+    unsigned long long state_T = 0;
+};
+std::mutex g_rng_mutex;
+RngTable g_rng[64];
+
+int rng_table(MisContext* ctx, RngTable* out) {
+    std::lock_guard<std::mutex> lock(g_rng_mutex);
+    RngTable& r = g_rng[ctx->device & 63];
+    if (!r.U) {
+        std::vector<unsigned> h(RNG_TABLE);
+        unsigned long long st = ~0ull;  // RNG rng((uint64)-1)
+        for (int i = 0; i < RNG_TABLE; i++) {
+            st = (unsigned long long)(unsigned)st * 4164903690u + (unsigned)(st >> 32);
+            h[i] = (unsigned)st;
+        }
+        MIS_HIP(ctx, hipMalloc((void**)&r.U, sizeof(unsigned) * RNG_TABLE));
+        MIS_HIP(ctx, hipMemcpy(r.U, h.data(), sizeof(unsigned) * RNG_TABLE, hipMemcpyHostToDevice));
+        r.state_T = st;
+    }
+    *out = r;
+    return MIS_OK;
+}
+
+}  // namespace
+
+int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long points, int max_iters) {
+    count = std::max(count, 1); points = std::max(points, 1ll); max_iters = std::max(max_iters, 1);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += mis_align_up(bytes, 256); return o; };
+    size_t o_calls = carve(sizeof(HomoCall) * count), o_res = carve(sizeof(HomoResult) * count), o_state = carve(sizeof(RansacState) * count);
+    size_t o_sub = carve(sizeof(int) * 4 * (size_t)count * max_iters), o_hc = carve(sizeof(double) * 9 * (size_t)count * max_iters);
+    size_t o_valid = carve(sizeof(int) * (size_t)count * max_iters), o_good = carve(sizeof(int) * (size_t)count * max_iters);
+    size_t o_scr = carve(sizeof(float) * 4 * (size_t)points), o_rec = carve(sizeof(double) * 10 * (size_t)points);
+    size_t o_dn = carve(256), o_di = carve(sizeof(int) * 4 * (size_t)count * DRAW_CHUNK);
+    if (off > b->bytes) {
+        if (b->mem) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(b->mem)); b->mem = nullptr; b->bytes = 0; }
+        MIS_HIP(ctx, hipMalloc(&b->mem, off));
+        b->bytes = off;
+    }
+    uint8_t* m = (uint8_t*)b->mem;
+    b->calls = (HomoCall*)(m + o_calls); b->results = (HomoResult*)(m + o_res); b->state = m + o_state;
+    b->sub_idx = (int*)(m + o_sub); b->Hc = (double*)(m + o_hc); b->valid = (int*)(m + o_valid); b->good = (int*)(m + o_good);
+    b->scr = (float*)(m + o_scr); b->rec = (double*)(m + o_rec); b->draw_next = (unsigned*)(m + o_dn); b->draw_idx = (int*)(m + o_di);
+    b->count = count; b->points = points; b->max_iters = max_iters;
+    return MIS_OK;
+}
+
+void homo_batch_release(HomoBatch* b) {
+    if (b->mem) hipFree(b->mem);
+    b->mem = nullptr; b->bytes = 0;
+}
+
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence) {
+    MIS_CHECK(ctx, max_iters >= 1 && max_iters <= b->max_iters, MIS_E_INVALID, "max_iters %d outside the reserved range", max_iters);
+    MIS_CHECK(ctx, confidence > 0 && confidence < 1, MIS_E_INVALID, "confidence must be in (0,1)");
+    RngTable rt;
+    int rc = rng_table(ctx, &rt);
+    if (rc != MIS_OK) return rc;
+    if (thresh <= 0) thresh = 3;
+    const float thr = (float)(thresh * thresh);
+    hipStream_t st = ctx->stream;
+    static bool attr_set[64] = {false};
+    const size_t hyp_lds = sizeof(double) * SLOT_DOUBLES * HYP_TPB;
+    if (!attr_set[ctx->device & 63]) {
+        MIS_HIP(ctx, hipFuncSetAttribute((const void*)hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
+        attr_set[ctx->device & 63] = true;
+    }
+    RansacState* states = (RansacState*)b->state;
+    const int p0 = std::min(PHASE0, max_iters);
+    hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
+    hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
+                       b->good, 0, max_iters, thr);
+    hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                       max_iters, confidence, thr);
+    if (max_iters > p0) {
+        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
+        hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
+                           b->Hc, b->valid, b->good, p0, max_iters, thr);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
+                           max_iters, max_iters, confidence, thr);
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
