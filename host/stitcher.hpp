@@ -1,0 +1,71 @@
+// stitcher.hpp -- C++17 host side of the MI355X stitching hot path: the sequence of the reference's
+// main() (image_stitching/image_stitching.cpp:281-1232) re-authored over the C ABI of libmistitch
+// (include/mistitch.h).  No OpenCV: plain PODs, std::vector, and the library's opaque handles.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+#include "../include/mistitch.h"
+#include "rotation.hpp"
+
+namespace mis {
+
+// The reference's globals-as-config (image_stitching.cpp:49-85), same defaults.
+struct StitchConfig {
+    double work_megapix = -1, seam_megapix = 0.1, compose_megapix = -1;  // compose -1: full-resolution warp + blend
+    float conf_thresh = 0.95f;
+    float match_conf = 0.32f;
+    int blend_type = MIS_BLEND_MULTI_BAND;
+    float blend_strength = 5;
+};
+
+// cv::detail::CameraParams as main() fills it (focal, aspect, ppx, ppy, R, t)
+struct CameraParams {
+    double focal = 1, aspect = 1, ppx = 0, ppy = 0;
+    Mat3<double> R;
+    std::array<double, 3> t{};
+    Mat3<double> K() const {
+        Mat3<double> k;
+        k(0, 0) = focal; k(0, 2) = ppx; k(1, 1) = focal * aspect; k(1, 2) = ppy; k(2, 2) = 1;
+        return k;
+    }
+};
+
+struct HostImage {
+    int width = 0, height = 0, channels = 0;
+    std::vector<uint8_t> data;
+};
+
+// "[a,b,...]" -> n x n row-major doubles, n = floor(sqrt(count))  (serializer.cpp:7-36 parseMatrixStr)
+std::vector<double> parseMatrixStr(std::string_view sv, int* side);
+// "isPortrait;compass;[proj4x4];[view4x4];[camTransform4x4];[K3x3]" -> CameraParams (image_stitching.cpp:413-517)
+CameraParams cameraFromImageDescription(const std::string& desc, bool* isPortrait);
+HostImage readPPM(const std::string& path);
+void writePPM(const std::string& path, const HostImage& img);
+
+struct StitchResult {
+    HostImage pano;      // 8UC3 (saturate_cast<uchar> of the 16SC3 result, as imwrite does)
+    HostImage mask;      // 8UC1
+    std::vector<int> indices;          // images kept by the biggest-component pruning
+    std::vector<int> num_features;
+    std::vector<double> confidence;    // n x n
+    double t_features = 0, t_matching = 0, t_compositing = 0;
+};
+
+class Stitcher {
+public:
+    explicit Stitcher(int device = 0, const StitchConfig& cfg = StitchConfig());
+    ~Stitcher();
+    // frames: 8UC3 BGR of one size; cameras: one per frame (sensor / ground-truth K, R)
+    StitchResult stitch(const std::vector<HostImage>& frames, const std::vector<CameraParams>& cameras);
+
+private:
+    void check(int rc, const char* what) const;
+    StitchConfig cfg_;
+    MisContext* ctx_ = nullptr;
+};
+
+}  // namespace mis

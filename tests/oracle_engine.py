@@ -1,0 +1,122 @@
+"""CPU engine for the distributed-orchestration tests: the same engine interface as
+image_stitching_amd.distributed.HipEngine, implemented with the oracle (test infrastructure).
+It exists so that world_size-2 gloo runs can exercise the sharding / collective logic on CPU."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+import oracle
+
+
+@dataclass
+class _MI:
+    confidence: float = 0.0
+    src_img_idx: int = -1
+    dst_img_idx: int = -1
+    num_inliers: int = 0
+
+
+class OracleEngine:
+    CAP = 4000 + 128 * 8
+
+    def __init__(self, frame_size, blend_type=oracle.BLEND_MULTI_BAND, blend_strength=5.0, match_conf=0.32):
+        self.frame_size = frame_size
+        self.orb = oracle.Orb(*frame_size)
+        self.blend_type, self.blend_strength, self.match_conf = blend_type, blend_strength, match_conf
+        self.blender = None
+        self.pano_size = None
+
+    def detect(self, frames):
+        w, h = self.frame_size
+        out = []
+        for f in frames:
+            k, d = self.orb.run(np.asarray(f))
+            out.append(dict(img_w=w, img_h=h, kps=k, xy=np.stack([k["x"], k["y"]], 1), desc=d))
+        return out
+
+    def pack_features(self, feats):
+        m = len(feats)
+        kps = torch.zeros((m, self.CAP * 24), dtype=torch.uint8)
+        desc = torch.zeros((m, self.CAP * 32), dtype=torch.uint8)
+        counts = torch.tensor([len(f["kps"]) for f in feats], dtype=torch.int32)
+        for i, f in enumerate(feats):
+            n = len(f["kps"])
+            kps[i, : n * 24] = torch.from_numpy(np.frombuffer(f["kps"].tobytes(), np.uint8).copy())
+            desc[i, : n * 32] = torch.from_numpy(f["desc"].reshape(-1).copy())
+        return kps, desc, counts
+
+    def unpack_features(self, kps_all, desc_all, counts_all):
+        w, h = self.frame_size
+        out = []
+        for i, n in enumerate(counts_all.tolist()):
+            k = np.frombuffer(kps_all[i, : n * 24].numpy().tobytes(), oracle.KP_DTYPE).copy()
+            d = desc_all[i, : n * 32].numpy().reshape(n, 32).copy()
+            out.append(dict(img_w=w, img_h=h, kps=k, xy=np.stack([k["x"], k["y"]], 1), desc=d))
+        return out
+
+    def match(self, feats, rank, world):
+        n = len(feats)
+        out = [_MI() for _ in range(n * n)]
+        p = oracle.match_default_params(match_conf=self.match_conf)
+        pair = 0
+        for i in range(n):
+            for j in range(i + 1, n):
+                if len(feats[i]["kps"]) == 0 or len(feats[j]["kps"]) == 0:
+                    continue
+                mine = pair % world == rank
+                pair += 1
+                if not mine:
+                    continue
+                r = oracle.match_pair(feats[i], feats[j], p)
+                out[i * n + j] = _MI(r["confidence"], i, j, r["num_inliers"])
+                out[j * n + i] = _MI(r["confidence"], j, i, r["num_inliers"])
+        return out
+
+    def confidence_tensor(self, pm, n):
+        return torch.tensor([m.confidence for m in pm], dtype=torch.float64).view(n, n)
+
+    def warp_roi(self, scale, cam):
+        w, h = self.frame_size
+        return oracle.warp_roi(scale, w, h, cam["K"].astype(np.float32), cam["R"].astype(np.float32))
+
+    def begin_compose(self, scale, corners, sizes):
+        x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)
+        x1 = max(c[0] + s[0] for c, s in zip(corners, sizes)); y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
+        btype, bands, sharp = oracle.blend_config(self.blend_type, self.blend_strength, x1 - x0, y1 - y0)
+        self.blender = oracle.Blender(btype, bands, sharp)
+        self.blender.prepare(corners, sizes)
+        self.scale = scale
+        self.pano_size = (x1 - x0, y1 - y0)
+        return btype, self.blender.num_bands
+
+    def warp_feed(self, frame, cam, roi):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        f = np.asarray(frame)
+        img, tl = oracle.warp_spherical(f, self.scale, K, R)
+        msk, _ = oracle.warp_spherical(np.full(f.shape[:2], 255, np.uint8), self.scale, K, R, oracle.INTER_NEAREST, oracle.BORDER_CONSTANT)
+        self.blender.feed(img.astype(np.int16), msk, tl)
+
+    def accumulators(self):
+        """In-place tensor views of the oracle blender's pyramids (shared memory with the C arrays)."""
+        out = []
+        L = oracle.lib()
+        for l in range(self.blender.num_bands + 1):
+            w, h = C.c_int(), C.c_int()
+            lp = L.mo_blender_level_lap(self.blender.h_, l, C.byref(w), C.byref(h))
+            wp = L.mo_blender_level_weight(self.blender.h_, l, C.byref(w), C.byref(h))
+            n = w.value * h.value
+            lap = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_int16)), shape=(n * 3,))
+            wgt = np.ctypeslib.as_array(C.cast(wp, C.POINTER(C.c_float)), shape=(n,))
+            out.append((torch.from_numpy(lap), torch.from_numpy(wgt)))
+        return out
+
+    def finalize(self):
+        return self.blender.blend()
+
+    def num_bands(self):
+        return self.blender.num_bands
+
+    def sync(self):
+        pass
