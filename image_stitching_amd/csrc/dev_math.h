@@ -52,6 +52,12 @@ MIS_HD int mis_reflect(int p, int len) {
     return q < len ? q : period - 1 - q;
 }
 
+// BORDER_REFLECT for p in [-len, 2 len): one fold, branch free (caller guarantees the range)
+MIS_HD int mis_reflect1(int p, int len) {
+    int r = p ^ (p >> 31);  // p < 0 -> -p - 1
+    return r >= len ? 2 * len - 1 - r : r;
+}
+
 MIS_HD float mis_sin_poly(float x, float z) {
     float y = -1.9515295891E-4f * z + 8.3321608736E-3f;
     y = y * z - 1.6666654611E-1f;

@@ -192,44 +192,196 @@ __device__ __forceinline__ void tile_trig(const WarpArgs& a, int tx0, int ty0, f
     __syncthreads();
 }
 
-// Fused compose-scale warp: 8UC3 source -> 16SC3 image + 8U mask.  256 threads = 4 waves; a wave
-// owns 4 consecutive rows of the 128x16 tile, a lane owns 2 adjacent columns (12-byte store).
-__global__ __launch_bounds__(256) void warp_fused_kernel(WarpArgs a) {
-    __shared__ float su[TILE_W], cu[TILE_W], sv[TILE_H], cv[TILE_H];
-    const int tx0 = blockIdx.x * TILE_W, ty0 = blockIdx.y * TILE_H;
-    tile_trig(a, tx0, ty0, su, cu, sv, cv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cx = 2 * lane, gx = tx0 + cx;
-    if (gx >= a.dw) return;
-    const bool two = gx + 1 < a.dw;
-    const float su0 = su[cx], cu0 = cu[cx], su1 = su[cx + 1], cu1 = cu[cx + 1];
+// Fused compose-scale warp: 8UC3 source -> 16SC3 image + 8U mask.
+//
+// sin/cos of the column angle u = (tlx + x) / scale and of the row angle pi - v are separable, so a
+// tiny pre-kernel tabulates them (dw + dh entries) and the main kernel has no trigonometry at all.
+// One wave per workgroup (no workgroup barriers): the wave owns a 128 x 4 output tile, a lane owns
+// 2 adjacent columns x 4 rows (12-byte stores).  The wave evaluates the map of all its pixels (kept
+// in registers), all-reduces the bounding box of the interior taps with shuffles, stages exactly that
+// box of the source in LDS with coalesced dword loads, and gathers the 12 taps per pixel from LDS.
+// Pixels whose taps need BORDER_REFLECT (outside the frame) and tiles whose box does not fit take the
+// global-memory gather in a cold fix-up pass.
+constexpr int FT_W = 128, FT_H = 4;
+constexpr int STAGE_BYTES = 16 * 512;  // 16 rows x 512 bytes
+
+__global__ __launch_bounds__(256) void warp_trig_kernel(WarpArgs a, float* tab) {
+    // tab: su[dw] cu[dw] sv[dh] cv[dh]
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.dw) {
+        float u = (float)(a.tlx + i) / a.scale;
+        mis_sincosf(u, &tab[i], &tab[a.dw + i]);
+    } else if (i < a.dw + a.dh) {
+        int r = i - a.dw;
+        float v = (float)(a.tly + r) / a.scale;
+        mis_sincosf(MIS_PI_F - v, &tab[2 * a.dw + r], &tab[2 * a.dw + a.dh + r]);
+    }
+}
+
+// cvRound(v) in [0, len): round-half-even maps [-0.5, len - 0.5) into range, and the upper end point
+// len - 0.5 too when len - 1 is even (ties go to the even neighbour)
+__device__ __forceinline__ bool round_in_range(float v, float hi, bool hi_even) { return v >= -0.5f && (v < hi || (hi_even && v == hi)); }
+
+// bilinear gather of 8 pixels from the staged box.  REFLECT = false: every tap is interior, the four
+// taps of a pixel are at fixed offsets from the top-left one.  REFLECT = true: taps are folded once
+// (BORDER_REFLECT, coordinates known to lie in [-len, 2 len)) and addressed individually.
+template <bool REFLECT>
+__device__ __forceinline__ void sample8(const uint8_t* stage, int lbase, int pitch, int sw, int sh, const int* sxq, const int* syq, int (*p)[3]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = wave * 4 + i, gy = ty0 + r;
-        if (gy >= a.dh) break;
-        const float s_v = sv[r], c_v = cv[r];
-        float x, y;
-        int p0[3], p1[3] = {0, 0, 0}, sx, sy;
-        map_backward(a.m, su0, cu0, s_v, c_v, &x, &y);
-        sample_linear<3>(a.src, a.sstride, a.sw, a.sh, x, y, p0);
-        unsigned m0 = nearest_inside(a.sw, a.sh, x, y, &sx, &sy) ? 255u : 0u, m1 = 0u;
-        if (two) {
-            map_backward(a.m, su1, cu1, s_v, c_v, &x, &y);
-            sample_linear<3>(a.src, a.sstride, a.sw, a.sh, x, y, p1);
-            m1 = nearest_inside(a.sw, a.sh, x, y, &sx, &sy) ? 255u : 0u;
+    for (int q = 0; q < 8; q++) {
+        const int fx = sxq[q] & 31, fy = syq[q] & 31;
+        const int sx = sxq[q] >> 5, sy = syq[q] >> 5;
+        const int wa = 32 - fx, wb = 32 - fy;
+        const uint8_t *t00, *t01, *t10, *t11;
+        if (!REFLECT) {
+            t00 = stage + (lbase + sy * pitch + sx * 3); t01 = t00 + 3; t10 = t00 + pitch; t11 = t10 + 3;
+        } else {
+            const int x0 = mis_reflect1(sx, sw) * 3, x1 = mis_reflect1(sx + 1, sw) * 3;
+            const int y0 = lbase + mis_reflect1(sy, sh) * pitch, y1 = lbase + mis_reflect1(sy + 1, sh) * pitch;
+            t00 = stage + (y0 + x0); t01 = stage + (y0 + x1); t10 = stage + (y1 + x0); t11 = stage + (y1 + x1);
         }
+        // sum(w_ij * p_ij) with w_ij = 32 * a_i * b_j factors exactly: two horizontal lerps, one vertical
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int h0 = t00[c] * wa + t01[c] * fx, h1 = t10[c] * wa + t11[c] * fx;
+            p[q][c] = (h0 * wb + h1 * fy + 512) >> 10;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
+    const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H;
+    const int lane = threadIdx.x;
+    const int gxr = tx0 + 2 * lane;
+    const bool col_ok = gxr < a.dw, two = gxr + 1 < a.dw;
+    const int gx = col_ok ? gxr : a.dw - 1;  // out-of-roi lanes shadow the last column (never stored)
+    const float xhi = (float)a.sw - 0.5f, yhi = (float)a.sh - 0.5f;  // exact: sizes < 2^15
+    const bool xe = ((a.sw - 1) & 1) == 0, ye = ((a.sh - 1) & 1) == 0;
+    int sxq[8], syq[8];
+    unsigned msk = 0;  // bit q: nearest source pixel of pixel q lies inside the frame
+    {
+        const int gx1 = two ? gx + 1 : gx;
+        const float su0 = tab[gx], cu0 = tab[a.dw + gx], su1 = tab[gx1], cu1 = tab[a.dw + gx1];
+#pragma unroll
+        for (int i = 0; i < FT_H; i++) {
+            const int gy = min(ty0 + i, a.dh - 1);  // wave-uniform: scalar loads; rows past the roi shadow the last one
+            const float s_v = tab[2 * a.dw + gy], c_v = tab[2 * a.dw + a.dh + gy];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int q = 2 * i + k;
+                float x, y;
+                map_backward(a.m, k ? su1 : su0, k ? cu1 : cu0, s_v, c_v, &x, &y);
+                // saturate_cast<short> of the integer part, the 5 fraction bits are kept below it
+                const int xq = mis_round_sat_f(x * 32.f), yq = mis_round_sat_f(y * 32.f);
+                sxq[q] = (mis_sat_short(xq >> 5) << 5) | (xq & 31);
+                syq[q] = (mis_sat_short(yq >> 5) << 5) | (yq & 31);
+                msk |= (round_in_range(x, xhi, xe) && round_in_range(y, yhi, ye)) ? (1u << q) : 0u;
+            }
+        }
+    }
+    // bounding box of the top-left taps; all taps interior <=> 0 <= min and max + 1 <= len - 1
+    int xmin = sxq[0] >> 5, xmax = xmin, ymin = syq[0] >> 5, ymax = ymin;
+#pragma unroll
+    for (int q = 1; q < 8; q++) {
+        xmin = min(xmin, sxq[q] >> 5); xmax = max(xmax, sxq[q] >> 5);
+        ymin = min(ymin, syq[q] >> 5); ymax = max(ymax, syq[q] >> 5);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+    }
+    // wave-uniform classification
+    const bool interior = xmin >= 0 && ymin >= 0 && xmax + 1 <= a.sw - 1 && ymax + 1 <= a.sh - 1;
+    const bool foldable = xmin >= -a.sw && xmax + 1 < 2 * a.sw && ymin >= -a.sh && ymax + 1 < 2 * a.sh;
+    int bx0 = xmin, bx1 = xmax + 1, by0 = ymin, by1 = ymax + 1;  // box of source columns / rows to stage
+    if (!interior && foldable) {
+        // fold the tap range once: the box of reflected coordinates of [lo, hi]
+        auto fold = [](int lo, int hi, int len, int* o0, int* o1) {
+            if (lo >= 0 && hi < len) { *o0 = lo; *o1 = hi; }
+            else if (hi < 0) { *o0 = -hi - 1; *o1 = -lo - 1; }
+            else if (lo >= len) { *o0 = 2 * len - 1 - hi; *o1 = 2 * len - 1 - lo; }
+            else if (lo < 0) { *o0 = 0; *o1 = max(-lo - 1, min(hi, len - 1)); if (hi >= len) *o1 = len - 1; }
+            else { *o0 = min(lo, 2 * len - 1 - hi); *o1 = len - 1; }
+        };
+        fold(xmin, xmax + 1, a.sw, &bx0, &bx1);
+        fold(ymin, ymax + 1, a.sh, &by0, &by1);
+    }
+    // With a 4-byte-multiple stride every row has the same alignment shift, so LDS offsets are 32-bit
+    // and affine in the source coordinates.
+    const int shift = (bx0 * 3) & 3;
+    const int pitch = ((bx1 - bx0 + 1) * 3 + shift + 3) & ~3;
+    const int nrows = by1 - by0 + 1;
+    constexpr int MAXR = 16;  // rows of the staged box; a row is at most 128 dwords (two per lane)
+    const bool staged = (interior || foldable) && (a.sstride & 3) == 0 && nrows <= MAXR && pitch <= 512;
+    if (staged) {
+        // all loads of the box are issued before the first LDS write: one memory latency per tile
+        const int dwords_per_row = pitch >> 2;
+        const size_t total_bytes = (size_t)(a.sh - 1) * a.sstride + (size_t)a.sw * 3;  // last valid byte + 1
+        const size_t gbase = (size_t)by0 * a.sstride + (size_t)(bx0 * 3 - shift) + 4 * (size_t)lane;
+        const bool c0 = lane < dwords_per_row, c1 = lane + 64 < dwords_per_row;
+        unsigned v0[MAXR], v1[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            const size_t g0 = gbase + (size_t)r * a.sstride;
+            v0[r] = 0; v1[r] = 0;
+            if (r < nrows) {
+                if (c0) {
+                    if (g0 + 4 <= total_bytes) v0[r] = *reinterpret_cast<const unsigned*>(a.src + g0);
+                    else for (int k = 0; k < 4; k++) if (g0 + k < total_bytes) v0[r] |= (unsigned)a.src[g0 + k] << (8 * k);
+                }
+                if (c1) {
+                    if (g0 + 256 + 4 <= total_bytes) v1[r] = *reinterpret_cast<const unsigned*>(a.src + g0 + 256);
+                    else for (int k = 0; k < 4; k++) if (g0 + 256 + k < total_bytes) v1[r] |= (unsigned)a.src[g0 + 256 + k] << (8 * k);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            if (r < nrows) {
+                if (c0) *reinterpret_cast<unsigned*>(stage + r * pitch + 4 * lane) = v0[r];
+                if (c1) *reinterpret_cast<unsigned*>(stage + r * pitch + 4 * lane + 256) = v1[r];
+            }
+        }
+    }
+    __syncthreads();  // single-wave workgroup: an LDS fence
+    if (!col_ok) return;
+    const int lbase = shift - by0 * pitch - bx0 * 3;  // LDS byte offset of source pixel (0, 0)
+    int p[8][3];
+    if (staged && interior) sample8<false>(stage, lbase, pitch, a.sw, a.sh, sxq, syq, p);
+    else if (staged) sample8<true>(stage, lbase, pitch, a.sw, a.sh, sxq, syq, p);
+    else {
+        // box too large for LDS or coordinates far outside the frame: gather from global memory
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int fx = sxq[q] & 31, fy = syq[q] & 31, sx = sxq[q] >> 5, sy = syq[q] >> 5;
+            const int x0 = mis_reflect(sx, a.sw), x1 = mis_reflect(sx + 1, a.sw), y0 = mis_reflect(sy, a.sh), y1 = mis_reflect(sy + 1, a.sh);
+            const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+            const uint8_t* r0 = a.src + (size_t)y0 * a.sstride;
+            const uint8_t* r1 = a.src + (size_t)y1 * a.sstride;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                p[q][c] = (r0[x0 * 3 + c] * w00 + r0[x1 * 3 + c] * w01 + r1[x0 * 3 + c] * w10 + r1[x1 * 3 + c] * w11 + (1 << 14)) >> 15;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FT_H; i++) {
+        const int gy = ty0 + i;
+        if (gy >= a.dh) break;
         uint8_t* drow = (uint8_t*)a.dst + (size_t)gy * a.dstride + (size_t)gx * 6;
         uint8_t* mrow = a.mask + (size_t)gy * a.mstride + gx;
+        const unsigned m0 = (msk >> (2 * i) & 1) ? 255u : 0u, m1 = (msk >> (2 * i + 1) & 1) ? 255u : 0u;
         if (two) {
             uint3 w;
-            w.x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
-            w.y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
-            w.z = (unsigned)p1[1] | ((unsigned)p1[2] << 16);
+            w.x = (unsigned)p[2 * i][0] | ((unsigned)p[2 * i][1] << 16);
+            w.y = (unsigned)p[2 * i][2] | ((unsigned)p[2 * i + 1][0] << 16);
+            w.z = (unsigned)p[2 * i + 1][1] | ((unsigned)p[2 * i + 1][2] << 16);
             *reinterpret_cast<uint3*>(drow) = w;
             *reinterpret_cast<unsigned short*>(mrow) = (unsigned short)(m0 | (m1 << 8));
         } else {
             int16_t* d = reinterpret_cast<int16_t*>(drow);
-            d[0] = (int16_t)p0[0]; d[1] = (int16_t)p0[1]; d[2] = (int16_t)p0[2];
+            d[0] = (int16_t)p[2 * i][0]; d[1] = (int16_t)p[2 * i][1]; d[2] = (int16_t)p[2 * i][2];
             mrow[0] = (uint8_t)m0;
         }
     }
@@ -340,8 +492,17 @@ extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, fl
               MIS_E_INVALID, "fused warp outputs need 4-byte (image) / 2-byte (mask) aligned rows");
     a.src = (const uint8_t*)din.data; a.sstride = din.stride;
     a.dst = dout.data; a.dstride = dout.stride; a.mask = (uint8_t*)dm.data; a.mstride = dm.stride;
-    dim3 grid((a.dw + TILE_W - 1) / TILE_W, (a.dh + TILE_H - 1) / TILE_H), block(256);
-    hipLaunchKernelGGL(warp_fused_kernel, grid, block, 0, ctx->stream, a);
+    // separable trig tables live in the context's grow-only scratch
+    const size_t tab_bytes = sizeof(float) * 2 * ((size_t)a.dw + a.dh);
+    if (ctx->stage_bytes < tab_bytes) {
+        if (ctx->stage) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+        MIS_HIP(ctx, hipMalloc(&ctx->stage, tab_bytes * 2 + 4096));
+        ctx->stage_bytes = tab_bytes * 2 + 4096;
+    }
+    float* tab = (float*)ctx->stage;
+    hipLaunchKernelGGL(warp_trig_kernel, dim3((a.dw + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
+    dim3 grid((a.dw + FT_W - 1) / FT_W, (a.dh + FT_H - 1) / FT_H), block(64);
+    hipLaunchKernelGGL(warp_fused_kernel, grid, block, 0, ctx->stream, a, (const float*)tab);
     MIS_HIP(ctx, hipGetLastError());
     if ((rc = mis_dev_image_commit(ctx, dst, &dout)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_commit(ctx, dmask, &dm)) != MIS_OK) return rc;

@@ -1,0 +1,19 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+import image_stitching_amd as isa, synth
+ctx = isa.Context(0)
+cams = synth.workload("config3")
+cam = cams[8]
+frame = synth.render_frame_gpu(cam)
+scale = isa.Stitcher.warped_image_scale(cams)
+w = isa.SphericalWarper(ctx, scale)
+roi = w.warpRoi((3840, 2160), cam["K"], cam["R"])
+dst, msk = w.alloc_fused(roi)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for _ in range(3): w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(n): w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
+e1.record(); torch.cuda.synchronize()
+print("roi", roi, "avg us", e0.elapsed_time(e1) / n * 1e3)
