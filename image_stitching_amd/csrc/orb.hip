@@ -29,6 +29,7 @@ struct LevelDesc {
     float scale;       // 1.2^l
     int nfeat;         // N_l
     int n2;            // retainBest #1 size (2 N_l with the Harris score)
+    int tiles_x, tiles_y, tile_off;  // FAST tile grid of the level and its first slot (512 survivors per tile)
     int cap1, cand_off;  // candidate capacity / offset
     int cap2, fin_off;   // final capacity / offset (per level segment before concatenation)
     int tab_off;       // offset of the resize coefficient tables (x then y) of this level
@@ -44,6 +45,9 @@ struct Work {  // device pointers of one MisOrb workspace
     uint8_t *pad, *blur, *score, *nms;
     int* hist;      // nlevels x 256
     int* thr;       // nlevels: FAST score cut
+    int* tile_cnt;      // per tile: NMS survivors
+    uint32_t* surv_xy;  // per tile slot of 512: x | y << 16
+    uint8_t* surv_sc;   // survivor FAST score
     int* cnt1;      // nlevels: candidates written by the compaction
     int* cnt2;      // nlevels: final keypoints per level
     int* flags;     // [0] overflow flag
@@ -58,11 +62,23 @@ struct Work {  // device pointers of one MisOrb workspace
 
 // ---------------------------------------------------------------- K1 gray --------------------
 // cvtColor BGR2GRAY, Q14: (B*1868 + G*9617 + R*4899 + 8192) >> 14, written into the padded level 0
-__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* dst, int pp) {
-    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* dst, int pp, int aligned) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
-    dst[(size_t)(y + ORB_BORDER) * pp + ORB_BORDER + x] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+    uint8_t* o = dst + (size_t)(y + ORB_BORDER) * pp + ORB_BORDER + x;
+    if (aligned && x + 4 <= w) {
+        // 12 bytes = 4 BGR pixels in three dwords; the destination is dword aligned (border 32, pitch % 64 == 0)
+        const unsigned* sp = reinterpret_cast<const unsigned*>(s);
+        const unsigned w0 = sp[0], w1 = sp[1], w2 = sp[2];
+        const unsigned g0 = ((w0 & 255) * 1868 + ((w0 >> 8) & 255) * 9617 + ((w0 >> 16) & 255) * 4899 + (1 << 13)) >> 14;
+        const unsigned g1 = ((w0 >> 24) * 1868 + (w1 & 255) * 9617 + ((w1 >> 8) & 255) * 4899 + (1 << 13)) >> 14;
+        const unsigned g2 = (((w1 >> 16) & 255) * 1868 + (w1 >> 24) * 9617 + (w2 & 255) * 4899 + (1 << 13)) >> 14;
+        const unsigned g3 = (((w2 >> 8) & 255) * 1868 + ((w2 >> 16) & 255) * 9617 + (w2 >> 24) * 4899 + (1 << 13)) >> 14;
+        *reinterpret_cast<unsigned*>(o) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)((s[3 * k] * 1868 + s[3 * k + 1] * 9617 + s[3 * k + 2] * 4899 + (1 << 13)) >> 14);
+    }
 }
 
 // ---------------------------------------------------------------- K2 pyramid -----------------
@@ -81,111 +97,229 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* src, int sw,
     dst[(size_t)(y + ORB_BORDER) * dpp + ORB_BORDER + x] = (uint8_t)((h0 * my0 + h1 * my1 + (1u << 15)) >> 16);
 }
 
-// copyMakeBorder(BORDER_REFLECT_101) of every level, one launch (grid.z = level)
+// copyMakeBorder(BORDER_REFLECT_101) of every level (grid.z = level); only the border ring is visited:
+// SIDES = false walks the top / bottom strips (2B rows, full padded width), SIDES = true the left /
+// right strips (2B columns of the interior rows).
+template <bool SIDES>
 __global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad) {
     const LevelDesc& d = L.d[blockIdx.z];
-    int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
-    int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
-    if (px >= pw || py >= ph) return;
-    int x = px - ORB_BORDER, y = py - ORB_BORDER;
-    if ((unsigned)x < (unsigned)d.w && (unsigned)y < (unsigned)d.h) return;
+    const int B = ORB_BORDER, pw = d.w + 2 * B, ph = d.h + 2 * B;
+    int px, py;
+    if (!SIDES) {
+        px = blockIdx.x * 256 + threadIdx.x;
+        py = blockIdx.y < B ? blockIdx.y : ph - 2 * B + blockIdx.y;
+        if (px >= pw) return;
+    } else {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+        if (row >= d.h) return;
+        py = row + B;
+        px = c < B ? c : pw - 2 * B + c;
+    }
+    const int x = px - B, y = py - B;
     uint8_t* p = pad + d.pad_off;
-    p[(size_t)py * d.pp + px] = p[(size_t)(mis_reflect101(y, d.h) + ORB_BORDER) * d.pp + mis_reflect101(x, d.w) + ORB_BORDER];
+    p[(size_t)py * d.pp + px] = p[(size_t)(mis_reflect101(y, d.h) + B) * d.pp + mis_reflect101(x, d.w) + B];
 }
 
 // ---------------------------------------------------------------- K3 FAST-9/16 ---------------
 // score = largest threshold for which the pixel is still a corner = max(best dark arc, best bright
 // arc) - 1 (cornerScore<16>), 0 when it is not a corner at `t`.
-__device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) {
+// Necessary condition for a 9-arc on the 16-pixel circle: every run of 9 consecutive positions holds 4
+// consecutive even positions (0,2,..,14), so a corner needs 4 consecutive even-position pixels all
+// brighter than v + t or all darker than v - t.  Checked on the 4 compass pixels first (2 adjacent).
+__device__ __forceinline__ bool fast_pretest(const uint8_t* p, int pp, int t) {
+    const int v = p[0], hi = v + t, lo = v - t;
+    const int c0 = p[3 * pp], c4 = p[3], c8 = p[-3 * pp], c12 = p[-3];
+    unsigned br = (c0 > hi) | ((c4 > hi) << 2) | ((c8 > hi) << 4) | ((c12 > hi) << 6);   // bit k: even position 2k brighter
+    unsigned dk = (c0 < lo) | ((c4 < lo) << 2) | ((c8 < lo) << 4) | ((c12 < lo) << 6);
+    // two adjacent compass pixels (positions 0-4, 4-8, 8-12, 12-0) of one kind
+    const unsigned adj_b = br & ((br >> 2) | (br << 6)), adj_d = dk & ((dk >> 2) | (dk << 6));
+    if (!((adj_b | adj_d) & 0x55)) return false;
+    const int c2 = p[2 * pp + 2], c6 = p[-2 * pp + 2], c10 = p[-2 * pp - 2], c14 = p[2 * pp - 2];
+    br |= ((c2 > hi) << 1) | ((c6 > hi) << 3) | ((c10 > hi) << 5) | ((c14 > hi) << 7);
+    dk |= ((c2 < lo) << 1) | ((c6 < lo) << 3) | ((c10 < lo) << 5) | ((c14 < lo) << 7);
+    // 4 consecutive set bits in the circular 8-bit masks
+    const unsigned b2 = br | (br << 8), d2 = dk | (dk << 8);
+    const unsigned rb = b2 & (b2 >> 1) & (b2 >> 2) & (b2 >> 3), rd = d2 & (d2 >> 1) & (d2 >> 2) & (d2 >> 3);
+    return ((rb | rd) & 0xff) != 0;
+}
+__device__ __forceinline__ int fast_score_full(const uint8_t* p, int pp, int t) {
     const int v = p[0];
-    // a 9-arc contains one pixel of every opposite pair: reject when both ends of a pair are similar
-    int a = v - p[3 * pp], b = v - p[-3 * pp];
-    if (abs(a) <= t && abs(b) <= t) return 0;
-    int c = v - p[3], e = v - p[-3];
-    if (abs(c) <= t && abs(e) <= t) return 0;
     int d[16];
-    d[0] = a; d[8] = b; d[4] = c; d[12] = e;
-    d[1] = v - p[3 * pp + 1]; d[2] = v - p[2 * pp + 2]; d[3] = v - p[pp + 3];
-    d[5] = v - p[-pp + 3]; d[6] = v - p[-2 * pp + 2]; d[7] = v - p[-3 * pp + 1];
-    d[9] = v - p[-3 * pp - 1]; d[10] = v - p[-2 * pp - 2]; d[11] = v - p[-pp - 3];
-    d[13] = v - p[pp - 3]; d[14] = v - p[2 * pp - 2]; d[15] = v - p[3 * pp - 1];
+    d[0] = v - p[3 * pp]; d[1] = v - p[3 * pp + 1]; d[2] = v - p[2 * pp + 2]; d[3] = v - p[pp + 3];
+    d[4] = v - p[3]; d[5] = v - p[-pp + 3]; d[6] = v - p[-2 * pp + 2]; d[7] = v - p[-3 * pp + 1];
+    d[8] = v - p[-3 * pp]; d[9] = v - p[-3 * pp - 1]; d[10] = v - p[-2 * pp - 2]; d[11] = v - p[-pp - 3];
+    d[12] = v - p[-3]; d[13] = v - p[pp - 3]; d[14] = v - p[2 * pp - 2]; d[15] = v - p[3 * pp - 1];
+    // window-9 minima / maxima of the circular sequence from window-3 ones (min3 / max3 instructions)
+    int n3[16], x3[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        n3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        x3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+    }
     int A = -512, Bm = 512;  // A = max over arcs of min(d), Bm = min over arcs of max(d)
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-        int mn = d[s], mx = d[s];
-#pragma unroll
-        for (int k = 1; k < 9; k++) {
-            int q = d[(s + k) & 15];
-            mn = min(mn, q); mx = max(mx, q);
-        }
-        A = max(A, mn); Bm = min(Bm, mx);
+    for (int i = 0; i < 16; i++) {
+        A = max(A, min(min(n3[i], n3[(i + 3) & 15]), n3[(i + 6) & 15]));
+        Bm = min(Bm, max(max(x3[i], x3[(i + 3) & 15]), x3[(i + 6) & 15]));
     }
-    int best = max(A, -Bm);
+    const int best = max(A, -Bm);
     return best > t ? best - 1 : 0;
 }
+__device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) { return fast_pretest(p, pp, t) ? fast_score_full(p, pp, t) : 0; }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(Levels L, const uint8_t* pad, uint8_t* score) {
-    const LevelDesc& d = L.d[blockIdx.z];
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= d.w || y >= d.h) return;
-    int s = 0;
-    if (x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3)
-        s = fast_score_px(pad + d.pad_off + (size_t)(y + ORB_BORDER) * d.pp + x + ORB_BORDER, d.pp, L.fast_t);
-    score[d.map_off + (size_t)y * d.sp + x] = (uint8_t)s;
-}
-
-// 3x3 strict non-max suppression + per-level histogram of the surviving scores
-__global__ __launch_bounds__(256) void nms_hist_kernel(Levels L, const uint8_t* score, uint8_t* nms, int* hist) {
+// FAST-9/16 score + 3x3 strict non-max suppression of a 64 x 32 tile in one pass through LDS.
+// The gray tile (+4 halo) is staged with coalesced dword loads issued up front, the scores of the tile
+// (+1 halo) are computed from LDS, and the survivors go to a per-level list (x | y << 16, score) and a
+// per-level histogram: the score map never exists in HBM.
+constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80;
+__global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc) {
+    __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 8) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75
+    __shared__ uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
     __shared__ int lh[256];
+    __shared__ int lcount;
+    __shared__ uint32_t lxy[512];  // at most 2048 / 4 strict local maxima per tile
+    __shared__ uint8_t lsc[512];
+    __shared__ unsigned short queue[(FT_ROWS + 2) * (FT_COLS + 2)];  // pixels that pass the cheap pre-test
+    __shared__ int qcount;
     const LevelDesc& d = L.d[blockIdx.z];
-    lh[threadIdx.x] = 0;
-    __syncthreads();
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < d.w && y < d.h) {
-        const uint8_t* s = score + d.map_off + (size_t)y * d.sp + x;
-        int v = s[0], keep = 0;
-        if (v && x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3) {
-            const int sp = d.sp;
-            keep = v > s[-1] && v > s[1] && v > s[-sp - 1] && v > s[-sp] && v > s[-sp + 1] && v > s[sp - 1] && v > s[sp] && v > s[sp + 1];
-            // KeyPointsFilter::runByImageBorder(edgeThreshold)
-            keep = keep && x >= L.edge && x < d.w - L.edge && y >= L.edge && y < d.h - L.edge;
+    const int x0 = blockIdx.x * FT_COLS, y0 = blockIdx.y * FT_ROWS, t = threadIdx.x;
+    if (x0 >= d.w || y0 >= d.h) return;
+    lh[t] = 0;
+    if (t == 0) { lcount = 0; qcount = 0; }
+    {
+        // padded coordinates of the tile origin are dword aligned (x0 multiple of 64, border 32)
+        const int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
+        const uint8_t* src = pad + d.pad_off;
+        const int px0 = x0 - 4 + ORB_BORDER, py0 = y0 - 4 + ORB_BORDER;
+        for (int i = t; i < (FT_ROWS + 8) * (FG_PITCH / 4); i += 256) {
+            const int r = i / (FG_PITCH / 4), c = i - r * (FG_PITCH / 4);
+            const int py = min(py0 + r, ph - 1);
+            int px = px0 + 4 * c;
+            if (px + 3 >= d.pp) px = d.pp - 4;  // past the row: any in-buffer dword (those pixels are never scored)
+            (void)pw;
+            reinterpret_cast<unsigned*>(g)[i] = *reinterpret_cast<const unsigned*>(src + (size_t)py * d.pp + px);
         }
-        nms[d.map_off + (size_t)y * d.sp + x] = (uint8_t)(keep ? v : 0);
-        if (keep) atomicAdd(&lh[v], 1);
     }
     __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&hist[blockIdx.z * 256 + threadIdx.x], lh[threadIdx.x]);
-}
-
-// retainBest(2 N_l) on the integer FAST score: cut = the n2-th best score (1 = keep everything)
-__global__ void fast_cut_kernel(Levels L, const int* hist, int* thr, int* flags) {
-    int l = threadIdx.x;
-    if (l >= L.n) return;
-    const int* h = hist + l * 256;
-    int total = 0;
-    for (int v = 1; v < 256; v++) total += h[v];
-    int n2 = L.d[l].n2, t = 1;
-    if (n2 == 0) t = 256;  // keep nothing
-    else if (total > n2) {
-        int acc = 0;
-        for (int v = 255; v >= 1; v--) { acc += h[v]; if (acc >= n2) { t = v; break; } }
+    const int SP = FT_COLS + 4;
+    // cheap pre-test of every pixel; the few that pass are queued so the expensive arc evaluation runs
+    // on dense wavefronts instead of diverging inside the scan
+    for (int i = t; i < (FT_ROWS + 2) * (FT_COLS + 2); i += 256) {
+        const int r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);
+        const int x = x0 - 1 + c, y = y0 - 1 + r;
+        sc[r * SP + c] = 0;
+        const bool pass = x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3 && fast_pretest(g + (r + 3) * FG_PITCH + (c + 3), FG_PITCH, L.fast_t);
+        // wave-aggregated append: one LDS atomic per wave instead of one per pixel on a single address
+        const unsigned long long m = __ballot(pass);
+        int base = 0;
+        if ((t & 63) == 0 && m) base = atomicAdd(&qcount, __popcll(m));
+        base = __shfl(base, 0);
+        if (pass) queue[base + __popcll(m & ((1ull << (t & 63)) - 1ull))] = (unsigned short)i;
     }
-    int kept = 0;
-    for (int v = t < 256 ? t : 256; v < 256; v++) kept += h[v];
-    if (kept > L.d[l].cap1) atomicOr(&flags[0], 1);
-    thr[l] = t;
+    __syncthreads();
+    for (int q = t; q < qcount; q += 256) {
+        const int i = queue[q], r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);
+        const int fsv = fast_score_full(g + (r + 3) * FG_PITCH + (c + 3), FG_PITCH, L.fast_t);
+        sc[r * SP + c] = (uint8_t)fsv;
+    }
+    __syncthreads();
+    {
+        // every lane takes part in every ballot: survivors are appended with one LDS atomic per wave
+        const int c = t & 63, x = x0 + c;
+        const bool xok = x >= 3 && x < d.w - 3 && x >= L.edge && x < d.w - L.edge;
+#pragma unroll
+        for (int k = 0; k < FT_ROWS / 4; k++) {
+            const int r = (t >> 6) * (FT_ROWS / 4) + k, y = y0 + r;
+            const uint8_t* s = sc + (r + 1) * SP + (c + 1);
+            const int v = s[0];
+            const bool keep = xok && v && y >= 3 && y < d.h - 3 && y >= L.edge && y < d.h - L.edge &&  // runByImageBorder(edgeThreshold)
+                              v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] && v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+            const unsigned long long m = __ballot(keep);
+            int base = 0;
+            if ((t & 63) == 0 && m) base = atomicAdd(&lcount, __popcll(m));
+            base = __shfl(base, 0);
+            if (keep) {
+                const int j = base + __popcll(m & ((1ull << (t & 63)) - 1ull));
+                lxy[j] = (uint32_t)x | ((uint32_t)y << 16); lsc[j] = (uint8_t)v;
+            }
+        }
+    }
+    __syncthreads();
+    // every tile owns a fixed slot of the survivor arrays: no global counter to contend on
+    const int n = lcount;
+    const int tile = d.tile_off + blockIdx.y * d.tiles_x + blockIdx.x;
+    if (t == 0) tile_cnt[tile] = n;
+    if (n == 0) return;  // uniform
+    for (int j = t; j < n; j += 256) {
+        atomicAdd(&lh[lsc[j]], 1);  // histogram from the list: spread over bins
+        surv_xy[(size_t)tile * 512 + j] = lxy[j]; surv_sc[(size_t)tile * 512 + j] = lsc[j];
+    }
+    __syncthreads();
+    if (lh[t]) atomicAdd(&hist[blockIdx.z * 256 + t], lh[t]);
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(Levels L, const uint8_t* nms, const int* thr, int* cnt1, uint32_t* cand_xy, float* cand_resp) {
-    const LevelDesc& d = L.d[blockIdx.z];
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= d.w || y >= d.h) return;
-    int v = nms[d.map_off + (size_t)y * d.sp + x];
-    if (v == 0 || v < thr[blockIdx.z]) return;
-    int i = atomicAdd(&cnt1[blockIdx.z], 1);
-    if (i < d.cap1) {
-        cand_xy[d.cand_off + i] = (uint32_t)x | ((uint32_t)y << 16);
-        cand_resp[d.cand_off + i] = (float)v;
+// retainBest(2 N_l) on the integer FAST score: cut = the n2-th best score (1 = keep everything), found
+// from the level histogram by every block, then the survivor list is filtered against it
+__global__ __launch_bounds__(256) void fast_cut_kernel(Levels L, const int* hist, int* thr, int* flags) {
+    __shared__ int suf[256];
+    __shared__ int s_thr;
+    const int l = blockIdx.x, t = threadIdx.x;
+    const LevelDesc& d = L.d[l];
+    // suffix sums of the histogram: suf[v] = number of survivors with score >= v
+    suf[t] = t ? hist[l * 256 + t] : 0;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int add = t + o < 256 ? suf[t + o] : 0;
+        __syncthreads();
+        suf[t] += add;
+        __syncthreads();
+    }
+    if (t == 0) s_thr = d.n2 == 0 ? 256 : 1;
+    __syncthreads();
+    // the cut is the largest v with suf[v] >= n2 (when more than n2 survivors exist)
+    if (d.n2 > 0 && suf[1] > d.n2 && t >= 1 && suf[t] >= d.n2 && (t == 255 || suf[t + 1] < d.n2)) s_thr = t;
+    __syncthreads();
+    if (t == 0) {
+        thr[l] = s_thr;
+        if (s_thr < 256 && suf[s_thr] > d.cap1) atomicOr(&flags[0], 1);
+    }
+}
+
+// one wave per tile slot filters its survivors against the level's cut; candidates are appended with one
+// global atomic per wave
+__global__ __launch_bounds__(256) void compact_kernel(Levels L, const int* tile_cnt, const uint32_t* surv_xy, const uint8_t* surv_sc, const int* thr,
+                                                      int* cnt1, uint32_t* cand_xy, float* cand_resp) {
+    const int l = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const LevelDesc& d = L.d[l];
+    const int tile_in_level = blockIdx.x * 4 + (t >> 6);
+    if (tile_in_level >= d.tiles_x * d.tiles_y) return;
+    const int tile = d.tile_off + tile_in_level;
+    const int n = tile_cnt[tile], th = thr[l];
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const int v = j < n ? surv_sc[(size_t)tile * 512 + j] : 0;
+        const bool keep = v >= th && v > 0;
+        const unsigned long long m = __ballot(keep);
+        if (!m) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cnt1[l], __popcll(m));
+        base = __shfl(base, 0);
+        if (keep) {
+            const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (i < d.cap1) { cand_xy[d.cand_off + i] = surv_xy[(size_t)tile * 512 + j]; cand_resp[d.cand_off + i] = (float)v; }
+        }
+    }
+}
+
+// debug view (mis_orb_debug_level which = 1): rasterise the survivor list into the NMS score map
+__global__ void nms_raster_kernel(LevelDesc d, const int* tile_cnt, const uint32_t* surv_xy, const uint8_t* surv_sc, uint8_t* nms) {
+    const int ntiles = d.tiles_x * d.tiles_y;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tile = d.tile_off + tl, n = tile_cnt[tile];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            uint32_t xy = surv_xy[(size_t)tile * 512 + j];
+            nms[d.map_off + (size_t)(xy >> 16) * d.sp + (xy & 0xffff)] = surv_sc[(size_t)tile * 512 + j];
+        }
     }
 }
 
@@ -230,15 +364,57 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* 
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k, s_m;
-    __shared__ uint32_t kkey[2048], kxy[2048];
+    __shared__ uint32_t kkey[4096], kxy[4096];
     const int l = blockIdx.x, t = threadIdx.x;
     const LevelDesc& d = L.d[l];
     const int n = min(cnt1[l], d.cap1);
     const uint32_t* xy = cand_xy + d.cand_off;
     const float* rs = cand_resp + d.cand_off;
     const int N = d.nfeat;
+    if (N == 0) { if (t == 0) cnt2[l] = 0; return; }
+    if (n <= 4096) {
+        // the usual case (~2N + ties candidates): bitonic sort of (key desc, y, x) in LDS; the cut is the key
+        // at position N-1, the kept set is the sorted prefix up to the last key >= cut -- already in the
+        // canonical order, no ranking pass and no atomics
+        int P = 1;
+        while (P < n) P <<= 1;
+        for (int i = t; i < P; i += 1024) {
+            if (i < n) { kkey[i] = fkey(rs[i]); kxy[i] = xy[i]; }
+            else { kkey[i] = 0; kxy[i] = 0xffffffffu; }  // sentinels sort last
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < P; i += 1024) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint32_t ka = kkey[i], kb = kkey[ixj], pa = kxy[i], pb = kxy[ixj];
+                        const bool a_first = ka > kb || (ka == kb && pa < pb);  // a precedes b in the canonical order
+                        const bool descending_block = (i & k) == 0;
+                        if (a_first != descending_block) { kkey[i] = kb; kkey[ixj] = ka; kxy[i] = pb; kxy[ixj] = pa; }
+                    }
+                }
+                __syncthreads();
+            }
+        const uint32_t cutk = (use_harris && n > N) ? kkey[N - 1] : 0u;
+        if (t == 0) s_m = 0;
+        __syncthreads();
+        // m = number of keys >= cut: the boundary index in the sorted array
+        for (int i = t; i < n; i += 1024)
+            if (kkey[i] >= cutk && (i == n - 1 || kkey[i + 1] < cutk)) s_m = i + 1;
+        __syncthreads();
+        const int m = s_m;
+        if (m > d.cap2) { if (t == 0) { atomicOr(&flags[0], 2); cnt2[l] = 0; } return; }
+        for (int i = t; i < m; i += 1024) {
+            fin_xy[d.fin_off + i] = kxy[i];
+            const uint32_t ki = kkey[i], uu = (ki & 0x80000000u) ? (ki & 0x7fffffffu) : ~ki;
+            fin_resp[d.fin_off + i] = __uint_as_float(uu);
+        }
+        if (t == 0) cnt2[l] = m;
+        return;
+    }
     uint32_t cut = 0;  // keep keys >= cut
-    if (use_harris && n > N && N > 0) {
+    if (use_harris && n > N) {
         // radix select: the N-th largest key
         if (t == 0) { s_prefix = 0; s_mask = 0; s_k = N; }
         __syncthreads();
@@ -260,7 +436,6 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* 
         }
         cut = s_prefix;
     }
-    if (N == 0) { if (t == 0) cnt2[l] = 0; return; }
     // gather the kept set (unordered)
     if (t == 0) s_m = 0;
     __syncthreads();
@@ -268,12 +443,12 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* 
         uint32_t k = fkey(rs[i]);
         if (k >= cut) {
             int j = atomicAdd(&s_m, 1);
-            if (j < 2048) { kkey[j] = k; kxy[j] = xy[i]; }
+            if (j < 4096) { kkey[j] = k; kxy[j] = xy[i]; }
         }
     }
     __syncthreads();
     int m = s_m;
-    if (m > d.cap2 || m > 2048) { if (t == 0) { atomicOr(&flags[0], 2); cnt2[l] = 0; } return; }
+    if (m > d.cap2 || m > 4096) { if (t == 0) { atomicOr(&flags[0], 2); cnt2[l] = 0; } return; }
     // rank = number of kept elements that come first: larger key, then smaller y, then smaller x
     for (int i = t; i < m; i += 1024) {
         uint32_t ki = kkey[i], pi = kxy[i];
@@ -340,41 +515,63 @@ __global__ __launch_bounds__(256) void assemble_angle_kernel(Levels L, const uin
 // interior; the border ring keeps the un-blurred reflected pixels (the reference blurs the ROI of
 // the bordered pyramid in place).  64x16 output tile, separable through LDS.
 __global__ __launch_bounds__(256) void blur_kernel(Levels L, const uint8_t* pad, uint8_t* blur) {
-    __shared__ uint8_t tile[22][72];
-    __shared__ uint16_t hbuf[22][64];
+    constexpr int TR = 32, TP = 80;                     // tile rows; LDS pitch (dword aligned, >= 64 + 6 + 3)
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(TR + 6) * TP];  // rows ty0-3 .. ty0+34, cols tx0-4 .. tx0+75
+    __shared__ __attribute__((aligned(16))) uint16_t hbuf[(TR + 6) * 64];
     const LevelDesc& d = L.d[blockIdx.z];
     const int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
-    // tiles cover the padded extent; tile origin in padded coordinates
-    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    // tiles cover the padded extent; tile origin in padded coordinates (multiple of 64 -> dword aligned)
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TR, t = threadIdx.x;
     if (tx0 >= pw || ty0 >= ph) return;
     const uint8_t* src = pad + d.pad_off;
     uint8_t* dst = blur + d.pad_off;
-    for (int i = threadIdx.x; i < 22 * 70; i += 256) {
-        int r = i / 70, c = i % 70;
-        int sy = min(max(ty0 + r - 3, 0), ph - 1), sx = min(max(tx0 + c - 3, 0), pw - 1);
-        tile[r][c] = src[(size_t)sy * d.pp + sx];
+    for (int i = t; i < (TR + 6) * (TP / 4); i += 256) {
+        const int r = i / (TP / 4), c = i - r * (TP / 4);
+        const int sy = min(max(ty0 + r - 3, 0), ph - 1);
+        int sx = tx0 - 4 + 4 * c;
+        sx = min(max(sx, 0), d.pp - 4);  // clamped dwords only feed pixels of the un-blurred border ring
+        reinterpret_cast<unsigned*>(tile)[i] = *reinterpret_cast<const unsigned*>(src + (size_t)sy * d.pp + sx);
     }
     __syncthreads();
     const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
-    for (int i = threadIdx.x; i < 22 * 64; i += 256) {
-        int r = i >> 6, c = i & 63, s = 0;
+    // horizontal pass: 4 adjacent outputs per work item from three aligned dwords (12 bytes)
+    for (int i = t; i < (TR + 6) * 16; i += 256) {
+        const int r = i >> 4, cg = i & 15;
+        const unsigned* p = reinterpret_cast<const unsigned*>(tile + r * TP + 4 * cg);
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+        int b[12];
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += kq[k] * tile[r][c + k];
-        hbuf[r][c] = (uint16_t)s;
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 255; b[4 + k] = (w1 >> (8 * k)) & 255; b[8 + k] = (w2 >> (8 * k)) & 255; }
+        unsigned short o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // output column 4 cg + k reads tile columns 4 cg + k + 1 .. + 7
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) acc += kq[j] * b[k + 1 + j];
+            o[k] = (unsigned short)acc;
+        }
+        *reinterpret_cast<uint2*>(hbuf + r * 64 + 4 * cg) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
     __syncthreads();
-    const int c = threadIdx.x & 63;
-    for (int r = threadIdx.x >> 6; r < 16; r += 4) {
-        int px = tx0 + c, py = ty0 + r;
-        if (px >= pw || py >= ph) continue;
-        int x = px - ORB_BORDER, y = py - ORB_BORDER;
+    // vertical pass: a thread slides down 8 rows of one column (14 reads for 8 outputs)
+    const int c = t & 63, px = tx0 + c;
+    if (px >= pw) return;
+    const int r0 = (t >> 6) * (TR / 4);
+    int hv[TR / 4 + 6];
+#pragma unroll
+    for (int j = 0; j < TR / 4 + 6; j++) hv[j] = hbuf[(r0 + j) * 64 + c];
+#pragma unroll
+    for (int k = 0; k < TR / 4; k++) {
+        const int r = r0 + k, py = ty0 + r;
+        if (py >= ph) break;
+        const int x = px - ORB_BORDER, y = py - ORB_BORDER;
         uint8_t o;
         if ((unsigned)x < (unsigned)d.w && (unsigned)y < (unsigned)d.h) {
-            int s = 0;
+            int acc = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) s += kq[k] * hbuf[r + k][c];
-            o = (uint8_t)((s + (1 << 15)) >> 16);
-        } else o = tile[r + 3][c + 3];
+            for (int j = 0; j < 7; j++) acc += kq[j] * hv[k + j];
+            o = (uint8_t)((acc + (1 << 15)) >> 16);
+        } else o = tile[(r + 3) * TP + c + 4];
         dst[(size_t)py * d.pp + px] = o;
     }
 }
@@ -418,7 +615,7 @@ struct MisOrb {
     Work w;
     void* mem = nullptr;
     size_t pad_bytes = 0, map_bytes = 0;
-    int cand_total = 0, fin_total = 0, tab_total = 0, out_cap = 0;
+    int cand_total = 0, fin_total = 0, tab_total = 0, surv_total = 0, out_cap = 0;
     std::vector<int> tab_host;
 };
 
@@ -442,7 +639,7 @@ void plan_levels(MisOrb* o, int w, int h) {
     L.n = p.nlevels; L.fast_t = p.fast_threshold; L.patch = p.patch_size; L.half_patch = p.patch_size / 2; L.edge = p.edge_threshold;
     double sf = (double)p.scale_factor;
     size_t pad_off = 0, map_off = 0;
-    int cand_off = 0, fin_off = 0, tab_off = 0;
+    int cand_off = 0, fin_off = 0, tab_off = 0, surv_off = 0;
     float factor = (float)(1.0 / sf);
     float nd = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.nlevels));
     int sum = 0;
@@ -459,13 +656,15 @@ void plan_levels(MisOrb* o, int w, int h) {
         if (l < L.n - 1) { d.nfeat = (int)lrintf(nd); sum += d.nfeat; nd *= factor; }
         else d.nfeat = std::max(p.nfeatures - sum, 0);
         d.n2 = p.score_type == 0 ? 2 * d.nfeat : d.nfeat;
+        d.tiles_x = (d.w + FT_COLS - 1) / FT_COLS; d.tiles_y = (d.h + FT_ROWS - 1) / FT_ROWS;
+        d.tile_off = surv_off; surv_off += d.tiles_x * d.tiles_y;
         d.cap1 = 4 * d.n2 + 4096;
         d.cap2 = std::min(d.nfeat + 128, 2048);
         d.cand_off = cand_off; cand_off += d.cap1;
         d.fin_off = fin_off; fin_off += d.cap2;
         d.tab_off = tab_off; tab_off += 2 * d.w + 2 * d.h;
     }
-    o->pad_bytes = pad_off; o->map_bytes = map_off; o->cand_total = cand_off; o->fin_total = fin_off; o->tab_total = tab_off;
+    o->pad_bytes = pad_off; o->map_bytes = map_off; o->cand_total = cand_off; o->fin_total = fin_off; o->tab_total = tab_off; o->surv_total = surv_off;
     o->tab_host.assign(tab_off, 0);
     for (int l = 1; l < L.n; l++) {
         int* t = o->tab_host.data() + L.d[l].tab_off;
@@ -514,20 +713,22 @@ int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* ou
     const Work& W = o->w;
     hipStream_t st = ctx->stream;
     const LevelDesc& d0 = L.d[0];
-    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * ORB_MAX_LEVELS + 3 * ORB_MAX_LEVELS), st));  // hist, thr, cnt1, cnt2
-    hipLaunchKernelGGL(gray_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, (const uint8_t*)img.data, img.stride, w, h, W.pad + d0.pad_off, d0.pp);
+    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), st));  // hist, thr, cnt0, cnt1, cnt2
+    const int aligned = (img.stride % 4 == 0) && ((uintptr_t)img.data % 4 == 0);
+    hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h), dim3(256), 0, st, (const uint8_t*)img.data, img.stride, w, h, W.pad + d0.pad_off, d0.pp, aligned);
     for (int l = 1; l < L.n; l++) {
         const LevelDesc &s = L.d[l - 1], &d = L.d[l];
         hipLaunchKernelGGL(resize_kernel, dim3((d.w + 255) / 256, d.h), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
                            d.h, d.pp, W.tab + d.tab_off);
     }
     const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
-    hipLaunchKernelGGL(border_kernel, dim3((pw0 + 255) / 256, ph0, L.n), dim3(256), 0, st, L, W.pad);
-    dim3 gmap((d0.w + 63) / 64, (d0.h + 3) / 4, L.n);
-    hipLaunchKernelGGL(fast_score_kernel, gmap, dim3(256), 0, st, L, W.pad, W.score);
-    hipLaunchKernelGGL(nms_hist_kernel, gmap, dim3(256), 0, st, L, W.score, W.nms, W.hist);
-    hipLaunchKernelGGL(fast_cut_kernel, dim3(1), dim3(64), 0, st, L, W.hist, W.thr, W.flags);
-    hipLaunchKernelGGL(compact_kernel, gmap, dim3(256), 0, st, L, W.nms, W.thr, W.cnt1, W.cand_xy, W.cand_resp);
+    hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h + 3) / 4, 1, L.n), dim3(256), 0, st, L, W.pad);   // sides first: the corners mirror them
+    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 255) / 256, 2 * ORB_BORDER, L.n), dim3(256), 0, st, L, W.pad);
+    dim3 gmap((d0.w + FT_COLS - 1) / FT_COLS, (d0.h + FT_ROWS - 1) / FT_ROWS, L.n);
+    hipLaunchKernelGGL(fast_nms_kernel, gmap, dim3(256), 0, st, L, W.pad, W.hist, W.tile_cnt, W.surv_xy, W.surv_sc);
+    hipLaunchKernelGGL(fast_cut_kernel, dim3(L.n), dim3(256), 0, st, L, W.hist, W.thr, W.flags);
+    hipLaunchKernelGGL(compact_kernel, dim3((d0.tiles_x * d0.tiles_y + 3) / 4, L.n), dim3(256), 0, st, L, W.tile_cnt, W.surv_xy, W.surv_sc, W.thr, W.cnt1,
+                       W.cand_xy, W.cand_resp);
     const int use_harris = o->p.score_type == 0;
     if (use_harris)
         hipLaunchKernelGGL(harris_kernel, dim3((L.d[0].cap1 + 255) / 256, L.n), dim3(256), 0, st, L, W.pad, W.cnt1, W.cand_xy, W.cand_resp);
@@ -537,7 +738,7 @@ int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* ou
     int* n_dev = feat_count(out, o->out_cap);
     hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax,
                        out->keypoints, lxy, n_dev, o->out_cap);
-    hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 15) / 16, L.n), dim3(256), 0, st, L, W.pad, W.blur);
+    hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, L.n), dim3(256), 0, st, L, W.pad, W.blur);
     hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur, out->keypoints, lxy, n_dev, W.pattern,
                        (uint8_t*)out->descriptors);
     MIS_HIP(ctx, hipGetLastError());
@@ -584,7 +785,8 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
     size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
-    size_t o_hist = carve(sizeof(int) * (256 * ORB_MAX_LEVELS + 3 * ORB_MAX_LEVELS)), o_flags = carve(256);
+    size_t o_hist = carve(sizeof(int) * (256 * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
+    size_t o_sxy = carve(sizeof(uint32_t) * 512 * (size_t)o->surv_total), o_ssc = carve(512 * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
     size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
     size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
     size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
@@ -593,6 +795,7 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     Work& W = o->w;
     W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
     W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
+    W.surv_xy = (uint32_t*)(m + o_sxy); W.surv_sc = m + o_ssc; W.tile_cnt = (int*)(m + o_tc);
     W.flags = (int*)(m + o_flags);
     W.cand_xy = (uint32_t*)(m + o_cxy); W.cand_resp = (float*)(m + o_cr); W.fin_xy = (uint32_t*)(m + o_fxy); W.fin_resp = (float*)(m + o_fr);
     W.tab = (int*)(m + o_tab); W.umax = (int*)(m + o_umax); W.pattern = (int8_t*)(m + o_pat);
@@ -726,7 +929,11 @@ extern "C" int mis_orb_debug_level(MisOrb* o, int level, int which, uint8_t* hos
     const uint8_t* src;
     size_t pitch;
     if (which == 0) { src = o->w.pad + d.pad_off + (size_t)ORB_BORDER * d.pp + ORB_BORDER; pitch = d.pp; }
-    else if (which == 1) { src = o->w.nms + d.map_off; pitch = d.sp; }
+    else if (which == 1) {
+        MIS_HIP(ctx, hipMemsetAsync(o->w.nms + d.map_off, 0, (size_t)d.sp * d.h, ctx->stream));
+        hipLaunchKernelGGL(nms_raster_kernel, dim3(256), dim3(64), 0, ctx->stream, d, o->w.tile_cnt, o->w.surv_xy, o->w.surv_sc, o->w.nms);
+        src = o->w.nms + d.map_off; pitch = d.sp;
+    }
     else { src = o->w.blur + d.pad_off; pitch = d.pp; }
     MIS_HIP(ctx, hipMemcpy2DAsync(host_out, w, src, pitch, w, h, hipMemcpyDeviceToHost, ctx->stream));
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
