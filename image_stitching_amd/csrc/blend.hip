@@ -28,6 +28,7 @@ struct MisBlender {
     float* wgt[MIS_MAX_BANDS + 1];
     uint8_t* dst_mask = nullptr;  // plain blender
     void* pano_mem = nullptr;
+    size_t pano_bytes = 0;  // capacity kept across prepare() calls (grow-only)
     bool prepared = false;
     // grow-only scratch of one feed: Gaussian pyramids of the frame (levels 1..nb) and of its weights
     void* scratch = nullptr;
@@ -63,29 +64,37 @@ __device__ __forceinline__ float view_w(const FrameView& v, int tx, int ty) {
 }
 
 // ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101, s16: (v + 128) >> 8 ----
-// one thread per destination pixel (3 channels)
+// A block produces a 32 x 16 destination tile: the 67 x 35 source footprint is staged in LDS once (the
+// reflect index maps of the padded view are evaluated once per source pixel instead of 25 times per
+// output), then the separable 5-tap filter runs out of LDS (integer, so the pass order is free).
+constexpr int PD_W = 32, PD_H = 16, PD_SW = 2 * PD_W + 3, PD_SH = 2 * PD_H + 3;
 template <bool FROM_VIEW>
 __global__ __launch_bounds__(256) void pyr_down_s16x3_kernel(FrameView v, const int16_t* src, int sw, int sh, int16_t* dst, int dw, int dh) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    int acc[3] = {0, 0, 0};
-    const int kw[5] = {1, 4, 6, 4, 1};
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        int sy = mis_reflect101(2 * y - 2 + j, sh);
-        int row[3] = {0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            int sx = mis_reflect101(2 * x - 2 + i, sw);
-            int c[3];
-            if (FROM_VIEW) view_px(v, sx, sy, c);
-            else { const int16_t* p = src + ((size_t)sy * sw + sx) * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
-            row[0] += kw[i] * c[0]; row[1] += kw[i] * c[1]; row[2] += kw[i] * c[2];
-        }
-        acc[0] += kw[j] * row[0]; acc[1] += kw[j] * row[1]; acc[2] += kw[j] * row[2];
+    __shared__ int16_t tile[PD_SH * PD_SW * 3];
+    __shared__ int hbuf[PD_SH * PD_W * 3];
+    const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
+    for (int i = t; i < PD_SH * PD_SW; i += 256) {
+        const int r = i / PD_SW, c = i - r * PD_SW;
+        const int sy = mis_reflect101(2 * y0 - 2 + r, sh), sx = mis_reflect101(2 * x0 - 2 + c, sw);
+        int px[3];
+        if (FROM_VIEW) view_px(v, sx, sy, px);
+        else { const int16_t* p = src + ((size_t)sy * sw + sx) * 3; px[0] = p[0]; px[1] = p[1]; px[2] = p[2]; }
+        tile[3 * i] = (int16_t)px[0]; tile[3 * i + 1] = (int16_t)px[1]; tile[3 * i + 2] = (int16_t)px[2];
     }
-    int16_t* d = dst + ((size_t)y * dw + x) * 3;
-    d[0] = (int16_t)((acc[0] + 128) >> 8); d[1] = (int16_t)((acc[1] + 128) >> 8); d[2] = (int16_t)((acc[2] + 128) >> 8);
+    __syncthreads();
+    for (int i = t; i < PD_SH * PD_W * 3; i += 256) {
+        const int r = i / (PD_W * 3), rem = i - r * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
+        const int16_t* p = tile + (r * PD_SW + 2 * x) * 3 + ch;
+        hbuf[i] = p[6] * 6 + (p[3] + p[9]) * 4 + p[0] + p[12];
+    }
+    __syncthreads();
+    for (int i = t; i < PD_H * PD_W * 3; i += 256) {
+        const int y = i / (PD_W * 3), rem = i - y * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
+        if (x0 + x >= dw || y0 + y >= dh) continue;
+        const int* p = hbuf + (2 * y) * (PD_W * 3) + rem;
+        const int acc = p[2 * PD_W * 3] * 6 + (p[PD_W * 3] + p[3 * PD_W * 3]) * 4 + p[0] + p[4 * PD_W * 3];
+        dst[((size_t)(y0 + y) * dw + x0 + x) * 3 + ch] = (int16_t)((acc + 128) >> 8);
+    }
 }
 
 // ---- pyrDown f32: row = s[2x]*6 + (s[2x-1]+s[2x+1])*4 + s[2x-2] + s[2x+2]; same vertically; * 1/256 ----
@@ -256,12 +265,12 @@ __global__ __launch_bounds__(256) void feed_feather_kernel(const int16_t* img, s
 
 inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
-int release(MisBlender* b) {
+int release(MisBlender* b, bool free_memory) {
     MisContext* ctx = b->ctx;
-    if (b->pano_mem) {
+    if (free_memory && b->pano_mem) {
         MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         MIS_HIP(ctx, hipFree(b->pano_mem));
-        b->pano_mem = nullptr;
+        b->pano_mem = nullptr; b->pano_bytes = 0;
     }
     b->prepared = false;
     return MIS_OK;
@@ -318,11 +327,12 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
     dim3 blk(256);
     for (int i = 0; i < nb; i++) {
         dim3 g = grid2d(tw[i + 1], th[i + 1]);
+        dim3 gp((tw[i + 1] + PD_W - 1) / PD_W, (th[i + 1] + PD_H - 1) / PD_H);
         if (i == 0) {
-            hipLaunchKernelGGL((pyr_down_s16x3_kernel<true>), g, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], G(1), tw[1], th[1]);
+            hipLaunchKernelGGL((pyr_down_s16x3_kernel<true>), gp, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], G(1), tw[1], th[1]);
             hipLaunchKernelGGL((pyr_down_f32_kernel<true>), g, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], W(1), tw[1], th[1]);
         } else {
-            hipLaunchKernelGGL((pyr_down_s16x3_kernel<false>), g, blk, 0, ctx->stream, v, G(i), tw[i], th[i], G(i + 1), tw[i + 1], th[i + 1]);
+            hipLaunchKernelGGL((pyr_down_s16x3_kernel<false>), gp, blk, 0, ctx->stream, v, G(i), tw[i], th[i], G(i + 1), tw[i + 1], th[i + 1]);
             hipLaunchKernelGGL((pyr_down_f32_kernel<false>), g, blk, 0, ctx->stream, v, W(i), tw[i], th[i], W(i + 1), tw[i + 1], th[i + 1]);
         }
     }
@@ -402,7 +412,7 @@ extern "C" int mis_blender_create(MisContext* ctx, int type, int num_bands, floa
 extern "C" int mis_blender_destroy(MisBlender* b) {
     if (!b) return MIS_OK;
     hipSetDevice(b->ctx->device);
-    release(b);
+    release(b, true);
     if (b->scratch) { hipStreamSynchronize(b->ctx->stream); hipFree(b->scratch); }
     delete b;
     return MIS_OK;
@@ -415,7 +425,7 @@ extern "C" int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const
     MisContext* ctx = b->ctx;
     MIS_CHECK(ctx, corners && sizes && n >= 1, MIS_E_INVALID, "prepare needs at least one corner/size");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = release(b);
+    int rc = release(b, false);
     if (rc != MIS_OK) return rc;
     mis_result_roi(corners, sizes, n, &b->roi);
     MIS_CHECK(ctx, b->roi.width > 0 && b->roi.height > 0, MIS_E_INVALID, "empty panorama roi");
@@ -439,7 +449,11 @@ extern "C" int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const
         woff[i] = total; total += mis_align_up(px * 4, 256);
     }
     if (b->type == MIS_BLEND_NO) { moff = total; total += mis_align_up((size_t)b->lw[0] * b->lh[0], 256); }
-    MIS_HIP(ctx, hipMalloc(&b->pano_mem, total));
+    if (total > b->pano_bytes) {
+        if ((rc = release(b, true)) != MIS_OK) return rc;
+        MIS_HIP(ctx, hipMalloc(&b->pano_mem, total));
+        b->pano_bytes = total;
+    }
     MIS_HIP(ctx, hipMemsetAsync(b->pano_mem, 0, total, ctx->stream));
     for (int i = 0; i <= b->num_bands; i++) {
         b->lap[i] = (int16_t*)((uint8_t*)b->pano_mem + loff[i]);

@@ -16,6 +16,9 @@ struct MisWorkspace {
 struct MisContext {
     int device = 0;
     MisWorkspace* match_ws = nullptr;
+    // recycled device blocks (size, pointer): feature sets are allocated and released every frame, and a
+    // hipFree would synchronise the whole device each time
+    std::vector<std::pair<size_t, void*>> pool;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -25,6 +28,8 @@ struct MisContext {
 };
 
 int mis_set_error(MisContext* ctx, int code, const char* fmt, ...);
+int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got);
+void mis_pool_free(MisContext* ctx, void* p, size_t bytes);
 
 #define MIS_HIP(ctx, call)                                                                             \
     do {                                                                                               \

@@ -12,6 +12,26 @@ int mis_set_error(MisContext* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got) {
+    // best fit among the recycled blocks (at most 2x the request), else a fresh allocation
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); i++)
+        if (ctx->pool[i].first >= bytes && ctx->pool[i].first <= 2 * bytes && (best < 0 || ctx->pool[i].first < ctx->pool[best].first)) best = i;
+    if (best >= 0) {
+        *out = ctx->pool[best].second; *got = ctx->pool[best].first;
+        ctx->pool.erase(ctx->pool.begin() + best);
+        return MIS_OK;
+    }
+    MIS_HIP(ctx, hipMalloc(out, bytes));
+    *got = bytes;
+    return MIS_OK;
+}
+
+void mis_pool_free(MisContext* ctx, void* p, size_t bytes) {
+    // stream-ordered reuse: every consumer of the block was enqueued on ctx->stream before this call
+    if (p) ctx->pool.emplace_back(bytes, p);
+}
+
 extern "C" const char* mis_version(void) { return "mistitch 0.1 (gfx950)"; }
 
 extern "C" int mis_context_create(int device, void* stream, MisContext** out) {
@@ -35,6 +55,7 @@ extern "C" int mis_context_destroy(MisContext* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     delete ctx->match_ws;
+    for (auto& b : ctx->pool) hipFree(b.second);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -114,12 +114,16 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
     const unsigned* U;
+    const unsigned* win;         // LDS copy of U[win_base .. win_base + DRAW_UWIN)
+    long long win_base;
     unsigned long long state_T;  // generator state after RNG_TABLE draws
     // serial continuation beyond the table (positions are visited in increasing order)
     unsigned long long cur_state;
     long long cur_pos;
 };
 __device__ __forceinline__ unsigned draw_at(DrawCtx& d, long long pos) {
+    const long long w = pos - d.win_base;
+    if (w >= 0 && w < 4096 + 512) return d.win[w];
     if (pos < RNG_TABLE) return d.U[pos];
     unsigned v = 0;
     while (d.cur_pos <= pos) {
@@ -154,12 +158,17 @@ __device__ long long attempt_at(DrawCtx& d, long long pos, const float* src, con
 // Subsets of iterations [st->draw_k, k_hi) of every problem.  Attempt start positions are simulated in
 // chunks of DRAW_CHUNK stream positions by all threads, then thread 0 chases through the chunk; a new
 // chunk starts exactly where the chase left the previous one.
-constexpr int DRAW_CHUNK = 8192;
+constexpr int DRAW_CHUNK = 4096;
+constexpr int DRAW_PTS = 2048;
+constexpr int DRAW_UWIN = DRAW_CHUNK + 512;  // RNG outputs staged in LDS per chunk (an attempt rarely runs 512 draws past its start)
 __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
                                                   unsigned long long state_T, int max_iters, int phase, int k_hi_arg) {
     __shared__ unsigned char tab[DRAW_CHUNK];  // per position: min(end - start, 127) | pass << 7
+    __shared__ float2 pts[2 * DRAW_PTS];       // src then dst of small problems: the random gathers stay on chip
+    __shared__ unsigned uwin[DRAW_UWIN];       // RNG outputs of the current chunk
     __shared__ long long s_pos;
-    __shared__ int s_k, s_attempts, s_more;
+    __shared__ int s_k, s_attempts, s_more, s_kfirst, s_nacc;
+    __shared__ unsigned short acc_o[DRAW_CHUNK / 4];  // chunk offsets of the accepted attempts
     const int b = blockIdx.x, t = threadIdx.x;
     const HomoCall c = calls[b];
     RansacState* st = states + b;
@@ -177,15 +186,25 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     const int k_hi = min(k_hi_arg, phase == 0 ? max_iters : st->niters);
     if (t == 0) { s_pos = st->draw_pos; s_k = st->draw_k; s_attempts = 0; s_more = s_k < k_hi; }
     __syncthreads();
-    DrawCtx d{U, state_T, state_T, RNG_TABLE};
+    DrawCtx d{U, uwin, -(1ll << 40), state_T, state_T, RNG_TABLE};
+    const float* psrc = c.src;
+    const float* pdst = c.dst;
+    if (c.n <= DRAW_PTS) {
+        for (int i = t; i < c.n; i += TB) { pts[i] = reinterpret_cast<const float2*>(c.src)[i]; pts[DRAW_PTS + i] = reinterpret_cast<const float2*>(c.dst)[i]; }
+        psrc = reinterpret_cast<const float*>(pts); pdst = reinterpret_cast<const float*>(pts + DRAW_PTS);
+        __syncthreads();
+    }
     int* didx = draw_idx + (size_t)b * DRAW_CHUNK * 4;
     int* sidx = sub_idx + (size_t)b * max_iters * 4;
     while (s_more) {
         const long long base = s_pos;
+        for (int i = t; i < DRAW_UWIN; i += TB) uwin[i] = base + i < RNG_TABLE ? U[base + i] : 0u;
+        d.win_base = base + DRAW_UWIN <= RNG_TABLE ? base : -(1ll << 40);  // windows past the table fall back to the serial generator
+        __syncthreads();
         for (int o = t; o < DRAW_CHUNK; o += TB) {
             int idx[4];
             bool pass;
-            long long e = attempt_at(d, base + o, c.src, c.dst, c.n, idx, &pass);
+            long long e = attempt_at(d, base + o, psrc, pdst, c.n, idx, &pass);
             long long delta = e - (base + o);
             tab[o] = (unsigned char)((delta > 127 ? 127 : delta) | (pass ? 0x80 : 0));
             *reinterpret_cast<int4*>(didx + 4 * o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
@@ -193,27 +212,33 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
         __syncthreads();
         if (t == 0) {
             long long pos = base;
-            int k = s_k, attempts = s_attempts;
+            int k = s_k, attempts = s_attempts, nacc = 0;
             bool fail = false;
             while (k < k_hi && pos < base + DRAW_CHUNK) {
                 unsigned char e = tab[pos - base];
-                long long start = pos;
                 bool pass;
-                if ((e & 0x7f) != 127) { pass = (e & 0x80) != 0; pos += e & 0x7f; }
-                else {  // an attempt that consumed > 126 draws (tiny n): redo it serially
+                if ((e & 0x7f) != 127) {
+                    pass = (e & 0x80) != 0;
+                    if (pass) acc_o[nacc++] = (unsigned short)(pos - base);  // indices copied in parallel after the chase
+                    pos += e & 0x7f;
+                } else {  // an attempt that consumed > 126 draws (tiny n): redo it serially
                     int idx[4];
-                    pos = attempt_at(d, pos, c.src, c.dst, c.n, idx, &pass);
-                    if (pass) { sidx[4 * k] = idx[0]; sidx[4 * k + 1] = idx[1]; sidx[4 * k + 2] = idx[2]; sidx[4 * k + 3] = idx[3]; start = -1; }
+                    pos = attempt_at(d, pos, psrc, pdst, c.n, idx, &pass);
+                    if (pass) { acc_o[nacc++] = 0xffff; sidx[4 * k] = idx[0]; sidx[4 * k + 1] = idx[1]; sidx[4 * k + 2] = idx[2]; sidx[4 * k + 3] = idx[3]; }
                 }
                 attempts++;
-                if (pass) {
-                    if (start >= 0) *reinterpret_cast<int4*>(sidx + 4 * k) = *reinterpret_cast<const int4*>(didx + 4 * (start - base));
-                    k++; attempts = 0;
-                } else if (attempts >= 10000) { fail = true; break; }  // getSubset gave up: the RANSAC loop ends here
+                if (pass) { k++; attempts = 0; }
+                else if (attempts >= 10000) { fail = true; break; }  // getSubset gave up: the RANSAC loop ends here
             }
+            s_kfirst = s_k; s_nacc = nacc;
             s_pos = pos; s_k = k; s_attempts = attempts;
             s_more = !fail && k < k_hi;
             if (!s_more) { st->draw_pos = pos; st->draw_k = k; st->draw_fail = fail; st->n_sub = k; }
+        }
+        __syncthreads();
+        for (int j = t; j < s_nacc; j += TB) {
+            const unsigned o = acc_o[j];
+            if (o != 0xffff) *reinterpret_cast<int4*>(sidx + 4 * (s_kfirst + j)) = *reinterpret_cast<const int4*>(didx + 4 * o);
         }
         __syncthreads();
     }
@@ -397,96 +422,104 @@ struct TailShared {
     float Hf[9];
     int indR[9], indC[9];
     int np, go;
+    double chunk[TB * 10];  // per-point terms of the current 256-point chunk of a sequential sum
 };
 
-// Jacobi with the n independent plane rotations of a step spread over n threads and the four
-// index-table scans over four threads; the arithmetic of every element is that of the serial loop.
-// Called by the whole workgroup (threads >= n only take part in the barriers).
+// Jacobi with the n independent plane rotations of a step spread over n lanes and the four
+// index-table scans over four lanes; the arithmetic of every element is that of the serial loop.
+// Runs on wave 0 only: the lanes of one wave execute LDS instructions in order, so a wavefront-scope
+// fence (no s_barrier) is all the synchronisation the steps need; the other waves wait at the end.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
     double* A = S.A; double* V = S.V; double* W = S.W;
     const int t = threadIdx.x;
-    const double eps = DBL_EPSILON;
-    int i, k, l, m;
-    double mv;
-    if (t < n) {
-        for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
-        W[t] = A[(n + 1) * t];
-        k = t;
-        if (k < n - 1) {
-            for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
-                double val = fabs(A[n * k + i]);
-                if (mv < val) mv = val, m = i;
-            }
-            S.indR[k] = m;
-        }
-        if (k > 0) {
-            for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
-                double val = fabs(A[n * i + k]);
-                if (mv < val) mv = val, m = i;
-            }
-            S.indC[k] = m;
-        }
-    }
-    __syncthreads();
-    const int maxIters = n * n * 30;
-    if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
-        for (k = 0, mv = fabs(A[S.indR[0]]), i = 1; i < n - 1; i++) {
-            double val = fabs(A[n * i + S.indR[i]]);
-            if (mv < val) mv = val, k = i;
-        }
-        l = S.indR[k];
-        for (i = 1; i < n; i++) {
-            double val = fabs(A[n * S.indC[i] + i]);
-            if (mv < val) mv = val, k = S.indC[i], l = i;
-        }
-        const double p = A[n * k + l];
-        if (fabs(p) <= eps) break;  // uniform: every thread reads the same LDS words
-        const double y = (W[l] - W[k]) * 0.5;
-        double tt = fabs(y) + cv_hypot(p, y);
-        double sn = cv_hypot(p, tt);
-        const double c = tt / sn;
-        sn = p / sn; tt = (p / tt) * p;
-        if (y < 0) sn = -sn, tt = -tt;
-        __syncthreads();  // all pivot inputs read before anything is rewritten
-        if (t == 0) { A[n * k + l] = 0; W[k] -= tt; W[l] += tt; }
+    if (t < 64) {
+        const double eps = DBL_EPSILON;
+        int i, k, l, m;
+        double mv;
         if (t < n) {
-            double a0, b0;
-#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
-            if (t < k) MIS_ROT(A[n * t + k], A[n * t + l]);
-            else if (t > k && t < l) MIS_ROT(A[n * k + t], A[n * t + l]);
-            else if (t > l) MIS_ROT(A[n * k + t], A[n * l + t]);
-            MIS_ROT(V[n * k + t], V[n * l + t]);
-#undef MIS_ROT
-        }
-        __syncthreads();
-        if (t < 4) {
-            const int idx = t < 2 ? k : l;
-            if ((t & 1) == 0) {
-                if (idx < n - 1) {
-                    for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
-                        double val = fabs(A[n * idx + i]);
-                        if (mv < val) mv = val, m = i;
-                    }
-                    S.indR[idx] = m;
-                }
-            } else if (idx > 0) {
-                for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
-                    double val = fabs(A[n * i + idx]);
+            for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
+            W[t] = A[(n + 1) * t];
+            k = t;
+            if (k < n - 1) {
+                for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
+                    double val = fabs(A[n * k + i]);
                     if (mv < val) mv = val, m = i;
                 }
-                S.indC[idx] = m;
+                S.indR[k] = m;
+            }
+            if (k > 0) {
+                for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
+                    double val = fabs(A[n * i + k]);
+                    if (mv < val) mv = val, m = i;
+                }
+                S.indC[k] = m;
             }
         }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (t == 0) {
-        for (k = 0; k < n - 1; k++) {
-            m = k;
-            for (i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
-            if (k != m) {
-                double tw = W[m]; W[m] = W[k]; W[k] = tw;
-                for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+        wave_sync();
+        const int maxIters = n * n * 30;
+        if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
+            for (k = 0, mv = fabs(A[S.indR[0]]), i = 1; i < n - 1; i++) {
+                double val = fabs(A[n * i + S.indR[i]]);
+                if (mv < val) mv = val, k = i;
+            }
+            l = S.indR[k];
+            for (i = 1; i < n; i++) {
+                double val = fabs(A[n * S.indC[i] + i]);
+                if (mv < val) mv = val, k = S.indC[i], l = i;
+            }
+            const double p = A[n * k + l];
+            if (fabs(p) <= eps) break;  // uniform: every lane reads the same LDS words
+            const double y = (W[l] - W[k]) * 0.5;
+            double tt = fabs(y) + cv_hypot(p, y);
+            double sn = cv_hypot(p, tt);
+            const double c = tt / sn;
+            sn = p / sn; tt = (p / tt) * p;
+            if (y < 0) sn = -sn, tt = -tt;
+            wave_sync();  // all pivot inputs read before anything is rewritten
+            if (t == 0) { A[n * k + l] = 0; W[k] -= tt; W[l] += tt; }
+            if (t < n) {
+                double a0, b0;
+#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
+                if (t < k) MIS_ROT(A[n * t + k], A[n * t + l]);
+                else if (t > k && t < l) MIS_ROT(A[n * k + t], A[n * t + l]);
+                else if (t > l) MIS_ROT(A[n * k + t], A[n * l + t]);
+                MIS_ROT(V[n * k + t], V[n * l + t]);
+#undef MIS_ROT
+            }
+            wave_sync();
+            if (t < 4) {
+                const int idx = t < 2 ? k : l;
+                if ((t & 1) == 0) {
+                    if (idx < n - 1) {
+                        for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
+                            double val = fabs(A[n * idx + i]);
+                            if (mv < val) mv = val, m = i;
+                        }
+                        S.indR[idx] = m;
+                    }
+                } else if (idx > 0) {
+                    for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
+                        double val = fabs(A[n * i + idx]);
+                        if (mv < val) mv = val, m = i;
+                    }
+                    S.indC[idx] = m;
+                }
+            }
+            wave_sync();
+        }
+        wave_sync();
+        if (t == 0) {
+            for (k = 0; k < n - 1; k++) {
+                m = k;
+                for (i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
+                if (k != m) {
+                    double tw = W[m]; W[m] = W[k]; W[k] = tw;
+                    for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+                }
             }
         }
     }
@@ -527,27 +560,32 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
     if (t < 4) S.nrm[4 + t] = np / S.nrm[4 + t];
     __syncthreads();
     {
+        // L^T L: 256 points at a time -- every thread produces the terms of one point into LDS, then the 45
+        // accumulator threads add the chunk in point order (the sequential order of the CPU loop)
         const double cmx = S.nrm[0], cmy = S.nrm[1], cMx = S.nrm[2], cMy = S.nrm[3], smx = S.nrm[4], smy = S.nrm[5], sMx = S.nrm[6], sMy = S.nrm[7];
-        for (int i = t; i < np; i += TB) {
-            double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
-            double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
-            double* r = rec + 10 * (size_t)i;  // X Y 1 0 -xX -xY -x -yX -yY -y
-            r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
-        }
-    }
-    __syncthreads();
-    if (t < 45) {
-        int j = 0, k = t;  // t-th entry of the upper triangle, row-major
-        while (k >= 9 - j) { k -= 9 - j; j++; }
+        int j = 0, k = t;  // t-th entry of the upper triangle, row-major (t < 45)
+        while (t < 45 && k >= 9 - j) { k -= 9 - j; j++; }
         k += j;
         const int lxi[9] = {0, 1, 2, 3, 3, 3, 4, 5, 6}, lyi[9] = {3, 3, 3, 0, 1, 2, 7, 8, 9};
-        const int xj = lxi[j], xk = lxi[k], yj = lyi[j], yk = lyi[k];
+        const int xj = t < 45 ? lxi[j] : 0, xk = t < 45 ? lxi[k] : 0, yj = t < 45 ? lyi[j] : 0, yk = t < 45 ? lyi[k] : 0;
         double acc = 0;
-        for (int i = 0; i < np; i++) {
-            const double* r = rec + 10 * (size_t)i;
-            acc += r[xj] * r[xk] + r[yj] * r[yk];
+        for (int base = 0; base < np; base += TB) {
+            const int i = base + t, cnt = min(TB, np - base);
+            if (i < np) {
+                double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
+                double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
+                double* r = S.chunk + 10 * t;  // X Y 1 0 -xX -xY -x -yX -yY -y
+                r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
+            }
+            __syncthreads();
+            if (t < 45)
+                for (int q = 0; q < cnt; q++) {
+                    const double* r = S.chunk + 10 * q;
+                    acc += r[xj] * r[xk] + r[yj] * r[yk];
+                }
+            __syncthreads();
         }
-        S.A[j * 9 + k] = acc;
+        if (t < 45) S.A[j * 9 + k] = acc;
     }
     __syncthreads();
     if (t < 81) { int j = t / 9, k = t % 9; if (k < j) S.A[j * 9 + k] = S.A[k * 9 + j]; }
@@ -563,51 +601,45 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
     double* x = S.lm;            double* xd = x + 8;   double* A = xd + 8;  double* Ap = A + 64;
     double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // S, Sd, rmax, accepted, lambda, lc, need_invert, nu
     auto normal_eq = [&](const double* h, bool with_J) {
-        for (int p = t; p < np; p += TB) {
-            double Mx = (double)s1[2 * p], My = (double)s1[2 * p + 1], ww, xi, yi;
-            lm_point(h, Mx, My, &ww, &xi, &yi);
-            double* r = rec + 10 * (size_t)p;  // a b ww c0 c1 c2 c3 e0 e1 0
-            r[7] = xi - (double)d1[2 * p]; r[8] = yi - (double)d1[2 * p + 1];
-            if (with_J) {
+        // thread roles of the sequential sums: 36 entries of J^T J, 8 of J^T r, one for |r|^2 and |r|_inf
+        const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
+        int ai = 0, aj = t;
+        while (t < 36 && aj >= 8 - ai) { aj -= 8 - ai; ai++; }
+        aj += ai;
+        int a0 = 9, b0 = 9, a1 = 9, b1 = 9;
+        if (t < 36) { a0 = j0[ai]; b0 = j0[aj]; a1 = j1[ai]; b1 = j1[aj]; }
+        else if (t >= 64 && t < 72) { a0 = j0[t - 64]; b0 = 7; a1 = j1[t - 64]; b1 = 8; }
+        double acc = 0, mx = 0;
+        for (int base = 0; base < np; base += TB) {
+            const int p = base + t, cnt = min(TB, np - base);
+            if (p < np) {
+                double Mx = (double)s1[2 * p], My = (double)s1[2 * p + 1], ww, xi, yi;
+                lm_point(h, Mx, My, &ww, &xi, &yi);
+                double* r = S.chunk + 10 * t;  // a b ww c0 c1 c2 c3 e0 e1 0
+                r[7] = xi - (double)d1[2 * p]; r[8] = yi - (double)d1[2 * p + 1];
                 r[0] = Mx * ww; r[1] = My * ww; r[2] = ww;
                 r[3] = -Mx * ww * xi; r[4] = -My * ww * xi; r[5] = -Mx * ww * yi; r[6] = -My * ww * yi; r[9] = 0;
             }
+            __syncthreads();
+            if (with_J && (t < 36 || (t >= 64 && t < 72))) {
+                for (int q = 0; q < cnt; q++) {
+                    const double* r = S.chunk + 10 * q;
+                    acc += r[a0] * r[b0];
+                    acc += r[a1] * r[b1];
+                }
+            } else if (t == 128) {
+                for (int q = 0; q < cnt; q++) {
+                    const double e0 = S.chunk[10 * q + 7], e1 = S.chunk[10 * q + 8];
+                    acc += e0 * e0; acc += e1 * e1;
+                    if (fabs(e0) > mx) mx = fabs(e0);
+                    if (fabs(e1) > mx) mx = fabs(e1);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
-        if (with_J && t < 36) {
-            int i = 0, j = t;
-            while (j >= 8 - i) { j -= 8 - i; i++; }
-            j += i;
-            const int a0 = j0[i], b0 = j0[j], a1 = j1[i], b1 = j1[j];
-            double acc = 0;
-            for (int p = 0; p < np; p++) {
-                const double* r = rec + 10 * (size_t)p;
-                acc += r[a0] * r[b0];
-                acc += r[a1] * r[b1];
-            }
-            A[i * 8 + j] = acc; A[j * 8 + i] = acc;
-        } else if (with_J && t >= 64 && t < 72) {
-            const int i = t - 64, a0 = j0[i], a1 = j1[i];
-            double acc = 0;
-            for (int p = 0; p < np; p++) {
-                const double* r = rec + 10 * (size_t)p;
-                acc += r[a0] * r[7];
-                acc += r[a1] * r[8];
-            }
-            v[i] = acc;
-        } else if (t == 128) {
-            double acc = 0, mx = 0;
-            for (int p = 0; p < np; p++) {
-                const double* r = rec + 10 * (size_t)p;
-                double e0 = r[7], e1 = r[8];
-                acc += e0 * e0; acc += e1 * e1;
-                if (fabs(e0) > mx) mx = fabs(e0);
-                if (fabs(e1) > mx) mx = fabs(e1);
-            }
-            sc[with_J ? 0 : 1] = acc;
-            if (with_J) sc[2] = mx;
-        }
+        if (with_J && t < 36) { A[ai * 8 + aj] = acc; A[aj * 8 + ai] = acc; }
+        else if (with_J && t >= 64 && t < 72) v[t - 64] = acc;
+        else if (t == 128) { sc[with_J ? 0 : 1] = acc; if (with_J) sc[2] = mx; }
         __syncthreads();
     };
     if (t < 8) x[t] = S.best[t];

@@ -14,6 +14,8 @@
 #include "dev_math.h"
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <unordered_map>
 
 #define ORB_MAX_LEVELS 16
 #define ORB_BORDER 32
@@ -681,18 +683,24 @@ int upload_tables(MisOrb* o) {
     return MIS_OK;
 }
 
-struct FeatOwner { void* mem; };
+std::mutex g_feat_mutex;
+std::unordered_map<void*, size_t> g_feat_sizes;  // block sizes of live feature sets (for the pool)
 
+// one device block per feature set: [size header 256 B][keypoints][descriptors][level xy][count]
 int alloc_features(MisContext* ctx, int cap, int desc_cols, int desc_dtype, MisFeatures* f) {
     size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)cap, 256), db = mis_align_up((size_t)cap * desc_cols * mis_dtype_size(desc_dtype), 256);
     size_t lb = mis_align_up(sizeof(uint32_t) * (size_t)cap, 256);
     void* mem = nullptr;
-    MIS_HIP(ctx, hipMalloc(&mem, kb + db + lb + 256));
+    size_t got = 0;
+    int rc = mis_pool_alloc(ctx, kb + db + lb + 256, &mem, &got);
+    if (rc != MIS_OK) return rc;
     f->keypoints = (MisKeyPoint*)mem;
     f->descriptors = (uint8_t*)mem + kb;
     f->desc_cols = desc_cols; f->desc_dtype = desc_dtype;
     f->owner_ = mem;
     f->n = 0;
+    std::lock_guard<std::mutex> lock(g_feat_mutex);
+    g_feat_sizes[mem] = got;
     return MIS_OK;
 }
 
@@ -908,9 +916,18 @@ extern "C" int mis_features_upload(MisContext* ctx, int img_w, int img_h, int n,
 extern "C" int mis_features_free(MisContext* ctx, MisFeatures* f) {
     if (!ctx || !f) return MIS_E_INVALID;
     if (f->owner_) {
-        MIS_HIP(ctx, hipSetDevice(ctx->device));
-        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        MIS_HIP(ctx, hipFree(f->owner_));
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> lock(g_feat_mutex);
+            auto it = g_feat_sizes.find(f->owner_);
+            if (it != g_feat_sizes.end()) { bytes = it->second; g_feat_sizes.erase(it); }
+        }
+        if (bytes) mis_pool_free(ctx, f->owner_, bytes);  // recycled without synchronising the device
+        else {
+            MIS_HIP(ctx, hipSetDevice(ctx->device));
+            MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            MIS_HIP(ctx, hipFree(f->owner_));
+        }
     }
     f->owner_ = nullptr; f->keypoints = nullptr; f->descriptors = nullptr; f->n = 0;
     return MIS_OK;
