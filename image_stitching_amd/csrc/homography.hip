@@ -114,16 +114,12 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
     const unsigned* U;
-    const unsigned* win;         // LDS copy of U[win_base .. win_base + DRAW_UWIN)
-    long long win_base;
     unsigned long long state_T;  // generator state after RNG_TABLE draws
     // serial continuation beyond the table (positions are visited in increasing order)
     unsigned long long cur_state;
     long long cur_pos;
 };
 __device__ __forceinline__ unsigned draw_at(DrawCtx& d, long long pos) {
-    const long long w = pos - d.win_base;
-    if (w >= 0 && w < 4096 + 512) return d.win[w];
     if (pos < RNG_TABLE) return d.U[pos];
     unsigned v = 0;
     while (d.cur_pos <= pos) {
@@ -160,15 +156,18 @@ __device__ long long attempt_at(DrawCtx& d, long long pos, const float* src, con
 // chunk starts exactly where the chase left the previous one.
 constexpr int DRAW_CHUNK = 4096;
 constexpr int DRAW_PTS = 2048;
-constexpr int DRAW_UWIN = DRAW_CHUNK + 512;  // RNG outputs staged in LDS per chunk (an attempt rarely runs 512 draws past its start)
 __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
                                                   unsigned long long state_T, int max_iters, int phase, int k_hi_arg) {
     __shared__ unsigned char tab[DRAW_CHUNK];  // per position: min(end - start, 127) | pass << 7
     __shared__ float2 pts[2 * DRAW_PTS];       // src then dst of small problems: the random gathers stay on chip
-    __shared__ unsigned uwin[DRAW_UWIN];       // RNG outputs of the current chunk
     __shared__ long long s_pos;
     __shared__ int s_k, s_attempts, s_more, s_kfirst, s_nacc;
-    __shared__ unsigned short acc_o[DRAW_CHUNK / 4];  // chunk offsets of the accepted attempts
+    __shared__ unsigned short acc_o[DRAW_CHUNK / 4];  // chunk offsets of the accepted attempts (serial path)
+    __shared__ unsigned short nxtA[DRAW_CHUNK + 1], nxtB[DRAW_CHUNK + 1];  // J^(2^r): start of the attempt 2^r hops ahead
+    __shared__ unsigned char reach[DRAW_CHUNK];
+    __shared__ int scan[TB];
+    __shared__ int s_big, s_firstvis, s_lastaccvis;
+    __shared__ long long s_endpos;
     const int b = blockIdx.x, t = threadIdx.x;
     const HomoCall c = calls[b];
     RansacState* st = states + b;
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     const int k_hi = min(k_hi_arg, phase == 0 ? max_iters : st->niters);
     if (t == 0) { s_pos = st->draw_pos; s_k = st->draw_k; s_attempts = 0; s_more = s_k < k_hi; }
     __syncthreads();
-    DrawCtx d{U, uwin, -(1ll << 40), state_T, state_T, RNG_TABLE};
+    DrawCtx d{U, state_T, state_T, RNG_TABLE};
     const float* psrc = c.src;
     const float* pdst = c.dst;
     if (c.n <= DRAW_PTS) {
@@ -198,9 +197,6 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     int* sidx = sub_idx + (size_t)b * max_iters * 4;
     while (s_more) {
         const long long base = s_pos;
-        for (int i = t; i < DRAW_UWIN; i += TB) uwin[i] = base + i < RNG_TABLE ? U[base + i] : 0u;
-        d.win_base = base + DRAW_UWIN <= RNG_TABLE ? base : -(1ll << 40);  // windows past the table fall back to the serial generator
-        __syncthreads();
         for (int o = t; o < DRAW_CHUNK; o += TB) {
             int idx[4];
             bool pass;
@@ -208,6 +204,75 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
             long long delta = e - (base + o);
             tab[o] = (unsigned char)((delta > 127 ? 127 : delta) | (pass ? 0x80 : 0));
             *reinterpret_cast<int4*>(didx + 4 * o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+        }
+        if (t == 0) s_big = 0;
+        __syncthreads();
+        // ---- which attempts does the sequential chain visit?  start -> end -> ... by pointer doubling ----
+        constexpr int C = DRAW_CHUNK;
+        for (int q = t; q < C; q += TB) {
+            const unsigned char e = tab[q];
+            if ((e & 0x7f) == 127) s_big = 1;  // an attempt longer than 126 draws: take the serial path for this chunk
+            nxtA[q] = (unsigned short)(q + (e & 0x7f));
+            reach[q] = q == 0;
+        }
+        if (t == 0) { nxtA[C] = C; nxtB[C] = C; }
+        __syncthreads();
+        if (!s_big) {
+            unsigned short* cur = nxtA;
+            unsigned short* oth = nxtB;
+            for (int r = 0; r < 11; r++) {  // 2^11 hops > C / 4 attempts
+                for (int q = t; q < C; q += TB) if (reach[q]) { const int j = cur[q]; if (j < C) reach[j] = 1; }
+                __syncthreads();
+                for (int q = t; q < C; q += TB) { const int j = min((int)cur[q], C); oth[q] = j < C ? cur[j] : (unsigned short)C; }
+                __syncthreads();
+                unsigned short* tmp = cur; cur = oth; oth = tmp;
+            }
+            // ranks of the visited / accepted attempts in stream order (each thread owns 16 consecutive positions)
+            int lv = 0, la = 0;
+            const int q0 = t * (C / TB);
+            for (int q = q0; q < q0 + C / TB; q++) { const int rv = reach[q]; lv += rv; la += rv && (tab[q] & 0x80); }
+            scan[t] = (lv << 16) | la;
+            __syncthreads();
+            for (int o = 1; o < TB; o <<= 1) {
+                const int add = t >= o ? scan[t - o] : 0;
+                __syncthreads();
+                scan[t] += add;
+                __syncthreads();
+            }
+            const int incl = scan[t], total = scan[TB - 1];
+            const int total_v = total >> 16, total_a = total & 0xffff;
+            int vr = (incl >> 16) - lv, ar = (incl & 0xffff) - la;  // exclusive ranks at q0
+            const int need = k_hi - s_k, cut = min(total_a, need);
+            if (t == 0) { s_firstvis = -1; s_lastaccvis = -1; s_endpos = -1; }
+            __syncthreads();
+            for (int q = q0; q < q0 + C / TB; q++) {
+                if (!reach[q]) continue;
+                const unsigned char e = tab[q];
+                if (e & 0x80) {
+                    if (ar == 0) s_firstvis = vr;
+                    if (ar < cut) *reinterpret_cast<int4*>(sidx + 4 * (s_k + ar)) = *reinterpret_cast<const int4*>(didx + 4 * q);
+                    if (ar == cut - 1) { s_lastaccvis = vr; if (cut == need) s_endpos = base + q + (e & 0x7f); }
+                    ar++;
+                }
+                if (vr == total_v - 1 && cut < need) s_endpos = base + q + (e & 0x7f);  // the chain leaves the chunk here
+                vr++;
+            }
+            __syncthreads();
+            if (t == 0) {
+                int attempts = s_attempts;
+                bool fail = false;
+                if (total_a == 0 || cut == 0) { attempts += total_v; fail = attempts >= 10000; }
+                else {
+                    fail = attempts + s_firstvis >= 10000;                 // getSubset gave up before the first accept
+                    attempts = cut == need ? 0 : total_v - (s_lastaccvis + 1);  // failures trailing the last accepted attempt
+                }
+                const int k = fail ? s_k : s_k + cut;
+                s_pos = s_endpos; s_k = k; s_attempts = attempts;
+                s_more = !fail && k < k_hi;
+                if (!s_more) { st->draw_pos = s_pos; st->draw_k = k; st->draw_fail = fail; st->n_sub = k; }
+            }
+            __syncthreads();
+            continue;
         }
         __syncthreads();
         if (t == 0) {

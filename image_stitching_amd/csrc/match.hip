@@ -31,7 +31,7 @@ struct PairDesc {
 
 // ---------------------------------------------------------------- K7: exact 2-NN, Hamming-256 --
 constexpr int KNN_TILE = 256;
-__global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats, const PairDesc* pairs, int* idx2, int* dist2) {
+__global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats, const PairDesc* pairs, int* idx2, float* dist2) {
     __shared__ uint4 tr[KNN_TILE * 2];
     const PairDesc pd = pairs[blockIdx.y >> 1];
     const bool fwd = (blockIdx.y & 1) == 0;
@@ -65,7 +65,114 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
     }
     if (active) {
         idx2[(off + q) * 2] = i0; idx2[(off + q) * 2 + 1] = i1;
-        dist2[(off + q) * 2] = d0; dist2[(off + q) * 2 + 1] = d1;
+        dist2[(off + q) * 2] = (float)d0; dist2[(off + q) * 2 + 1] = (float)d1;
+    }
+}
+
+// ---------------------------------------------------------------- K8: exact 2-NN, L2 on MFMA ----
+// SIFT descriptors are integer valued (0..255, stored as f32): they are exact in fp16, every dot
+// product of two 128-D descriptors is an integer < 2^24 and therefore exact in the f32 accumulator of
+// v_mfma_f32_32x32x16_f16, so |a-b|^2 = |a|^2 + |b|^2 - 2 a.b comes out bit-exact and the 2-NN order
+// (distance, trainIdx) equals the CPU's.  A workgroup of 4 waves owns 64 queries; each wave a 32 x 32
+// (query x train) tile per step; the top-2 is kept per accumulator register and merged across the 32
+// lanes of a row at the end.
+struct L2Set {
+    const _Float16* h;  // n x 128 fp16
+    const float* nrm;   // n squared norms (exact integers)
+    int n;
+};
+__global__ __launch_bounds__(256) void l2_prep_kernel(const float* desc, int n, int dim, _Float16* h, float* nrm, int* bad) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float s = 0;
+    for (int k = lane; k < 128; k += 64) {
+        float v = k < dim ? desc[(size_t)i * dim + k] : 0.f;
+        if (!(v >= 0.f && v <= 255.f && v == floorf(v))) atomicOr(bad, 1);  // not a SIFT-style integer descriptor
+        h[(size_t)i * 128 + k] = (_Float16)v;
+        s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) nrm[i] = s;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void top2_insert(float d, int i, float& d0, int& i0, float& d1, int& i1) {
+    if (d < d0 || (d == d0 && i < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+    else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
+}
+
+__global__ __launch_bounds__(256) void l2_knn2_mfma_kernel(L2Set Q, L2Set T, int* idx2, float* dist2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = blockIdx.x * 64 + (wave >> 1) * 32;   // this wave's 32 queries
+    if (blockIdx.x * 64 >= Q.n) return;
+    // A fragments: lane holds A[row r][k = 16 s + 8 hh + j] for the 8 k-steps
+    half8 a[8];
+    const int qa = min(q0 + r, Q.n - 1);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const half8*>(Q.h + (size_t)qa * 128 + 16 * s8 + 8 * hh);
+    // per accumulator register: running best two of the trains this lane's column class has seen
+    float d0[16], d1[16];
+    int i0[16], i1[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) { d0[g] = 3.0e38f; d1[g] = 3.0e38f; i0[g] = 0x7fffffff; i1[g] = 0x7fffffff; }
+    float qn[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) { const int row = (g & 3) + 8 * (g >> 2) + 4 * hh; qn[g] = Q.nrm[min(q0 + row, Q.n - 1)]; }
+    // the two waves of a query half interleave the train tiles
+    for (int t0 = (wave & 1) * 32; t0 < T.n; t0 += 64) {
+        const int tc = t0 + r;                     // this lane's train column
+        const int tb = min(tc, T.n - 1);
+        float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const half8 b = *reinterpret_cast<const half8*>(T.h + (size_t)tb * 128 + 16 * s8 + 8 * hh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s8], b, acc, 0, 0, 0);
+        }
+        if (tc < T.n) {
+            const float tn = T.nrm[tc];
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const float d2 = (qn[g] + tn) - 2.f * acc[g];  // exact integers below 2^24
+                top2_insert(d2, tc, d0[g], i0[g], d1[g], i1[g]);
+            }
+        }
+    }
+    // merge across the 32 lanes (columns) that share a row, then across the two waves through LDS
+    __shared__ float sd[2][32][4];
+    __shared__ int si[2][32][4];
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float od0 = __shfl_xor(d0[g], o), od1 = __shfl_xor(d1[g], o);
+            const int oi0 = __shfl_xor(i0[g], o), oi1 = __shfl_xor(i1[g], o);
+            top2_insert(od0, oi0, d0[g], i0[g], d1[g], i1[g]);
+            top2_insert(od1, oi1, d0[g], i0[g], d1[g], i1[g]);
+        }
+    }
+    const int qhalf = wave >> 1;
+    if ((wave & 1) == 1 && r == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int row = (g & 3) + 8 * (g >> 2) + 4 * hh;
+            sd[qhalf][row][0] = d0[g]; sd[qhalf][row][1] = d1[g]; si[qhalf][row][0] = i0[g]; si[qhalf][row][1] = i1[g];
+        }
+    }
+    __syncthreads();
+    if ((wave & 1) == 0 && r == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, q = q0 + row;
+            top2_insert(sd[qhalf][row][0], si[qhalf][row][0], d0[g], i0[g], d1[g], i1[g]);
+            top2_insert(sd[qhalf][row][1], si[qhalf][row][1], d0[g], i0[g], d1[g], i1[g]);
+            if (q < Q.n) {
+                idx2[2 * (size_t)q] = i0[g] == 0x7fffffff ? -1 : i0[g]; idx2[2 * (size_t)q + 1] = i1[g] == 0x7fffffff ? -1 : i1[g];
+                dist2[2 * (size_t)q] = sqrtf(d0[g]); dist2[2 * (size_t)q + 1] = sqrtf(d1[g]);
+            }
+        }
     }
 }
 
@@ -93,7 +200,7 @@ __device__ __forceinline__ int block_scan_flag(int flag, int* total) {
 
 // CpuMatcher::match: accepted 1->2 matches in query order, then 2->1 matches that are not already
 // in the set; BestOf2NearestMatcher::match: point lists shifted by half the image size.
-__global__ __launch_bounds__(1024) void ratio_union_kernel(const FeatDev* feats, const PairDesc* pairs, const int* idx2, const int* dist2, float ratio,
+__global__ __launch_bounds__(1024) void ratio_union_kernel(const FeatDev* feats, const PairDesc* pairs, const int* idx2, const float* dist2, float ratio,
                                                            MisDMatch* matches, float* src_xy, float* dst_xy, int* n_matches) {
     const PairDesc pd = pairs[blockIdx.x];
     const FeatDev F1 = feats[pd.i], F2 = feats[pd.j];
@@ -101,19 +208,19 @@ __global__ __launch_bounds__(1024) void ratio_union_kernel(const FeatDev* feats,
     float* sp = src_xy + 2 * pd.m_off;
     float* dp = dst_xy + 2 * pd.m_off;
     const int* i12 = idx2 + pd.knn_off12 * 2;
-    const int* d12 = dist2 + pd.knn_off12 * 2;
+    const float* d12 = dist2 + pd.knn_off12 * 2;
     const int* i21 = idx2 + pd.knn_off21 * 2;
-    const int* d21 = dist2 + pd.knn_off21 * 2;
+    const float* d21 = dist2 + pd.knn_off21 * 2;
     const float hw1 = (float)F1.w * 0.5f, hh1 = (float)F1.h * 0.5f, hw2 = (float)F2.w * 0.5f, hh2 = (float)F2.h * 0.5f;
     int base = 0;
     if (F2.n >= 2)
         for (int q0 = 0; q0 < F1.n; q0 += 1024) {
             int q = q0 + threadIdx.x, ok = 0;
-            if (q < F1.n) ok = (float)d12[2 * q] < ratio * (float)d12[2 * q + 1];
+            if (q < F1.n) ok = d12[2 * q] < ratio * d12[2 * q + 1];
             int tot, off = block_scan_flag(ok, &tot);
             if (ok) {
                 int t = i12[2 * q];
-                MisDMatch mm = {q, t, 0, (float)d12[2 * q]};
+                MisDMatch mm = {q, t, 0, d12[2 * q]};
                 m[base + off] = mm;
                 sp[2 * (base + off)] = F1.kps[q].x - hw1; sp[2 * (base + off) + 1] = F1.kps[q].y - hh1;
                 dp[2 * (base + off)] = F2.kps[t].x - hw2; dp[2 * (base + off) + 1] = F2.kps[t].y - hh2;
@@ -124,16 +231,16 @@ __global__ __launch_bounds__(1024) void ratio_union_kernel(const FeatDev* feats,
         for (int q0 = 0; q0 < F2.n; q0 += 1024) {
             int q = q0 + threadIdx.x, ok = 0, t1 = 0;
             if (q < F2.n) {
-                ok = (float)d21[2 * q] < ratio * (float)d21[2 * q + 1];
+                ok = d21[2 * q] < ratio * d21[2 * q + 1];
                 if (ok) {
                     t1 = i21[2 * q];
-                    bool acc12 = F2.n >= 2 && (float)d12[2 * t1] < ratio * (float)d12[2 * t1 + 1];
+                    bool acc12 = F2.n >= 2 && d12[2 * t1] < ratio * d12[2 * t1 + 1];
                     if (acc12 && i12[2 * t1] == q) ok = 0;  // (t1, q) already in the 1->2 set
                 }
             }
             int tot, off = block_scan_flag(ok, &tot);
             if (ok) {
-                MisDMatch mm = {t1, q, -1, (float)d21[2 * q]};
+                MisDMatch mm = {t1, q, -1, d21[2 * q]};
                 m[base + off] = mm;
                 sp[2 * (base + off)] = F1.kps[t1].x - hw1; sp[2 * (base + off) + 1] = F1.kps[t1].y - hh1;
                 dp[2 * (base + off)] = F2.kps[q].x - hw2; dp[2 * (base + off) + 1] = F2.kps[q].y - hh2;
@@ -215,10 +322,10 @@ struct Arena {
 };
 
 struct MatchWorkspace : MisWorkspace {
-    Arena dev, pinned;
+    Arena dev, pinned, l2;
     HomoBatch b1, b2;
     MatchWorkspace() { pinned.host = true; }
-    ~MatchWorkspace() override { dev.release(); pinned.release(); homo_batch_release(&b1); homo_batch_release(&b2); }
+    ~MatchWorkspace() override { dev.release(); pinned.release(); l2.release(); homo_batch_release(&b1); homo_batch_release(&b2); }
 };
 
 MatchWorkspace* workspace(MisContext* ctx) {
@@ -245,9 +352,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     std::vector<PairDesc> pairs;
     std::vector<FeatDev> fd(n);
     size_t knn_total = 0, m_total = 0;
+    bool use_l2 = false, use_bin = false;
     for (int i = 0; i < n; i++) {
-        MIS_CHECK(ctx, feats[i].n == 0 || (feats[i].desc_dtype == MIS_U8 && feats[i].desc_cols == 32), MIS_E_UNSUPPORTED,
-                  "all-pairs matching supports 32-byte binary descriptors");
+        const bool bin_i = feats[i].desc_dtype == MIS_U8 && feats[i].desc_cols == 32;
+        const bool l2_i = feats[i].desc_dtype == MIS_F32 && feats[i].desc_cols >= 1 && feats[i].desc_cols <= 128;
+        MIS_CHECK(ctx, feats[i].n == 0 || bin_i || l2_i, MIS_E_UNSUPPORTED,
+                  "all-pairs matching supports 32-byte binary descriptors (Hamming) or f32 descriptors of <= 128 columns (L2)");
+        if (feats[i].n > 0) { if (l2_i) use_l2 = true; else use_bin = true; }
         fd[i] = FeatDev{(const uint8_t*)feats[i].descriptors, feats[i].keypoints, feats[i].n, feats[i].img_w, feats[i].img_h};
     }
     int pair_index = 0;
@@ -262,6 +373,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             pd.m_off = m_total; pd.cap = feats[i].n + feats[j].n; m_total += pd.cap;
             pairs.push_back(pd);
         }
+    MIS_CHECK(ctx, !(use_l2 && use_bin), MIS_E_INVALID, "binary and float descriptors cannot be mixed in one matcher call");
     const int np = (int)pairs.size();
     if (np == 0) return MIS_OK;
     int maxq = 0;
@@ -276,7 +388,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, ws->dev.reserve(dc.off));
     uint8_t* D = (uint8_t*)ws->dev.p;
     FeatDev* d_feats = (FeatDev*)(D + o_feats); PairDesc* d_pairs = (PairDesc*)(D + o_pairs);
-    int* d_idx = (int*)(D + o_idx); int* d_dist = (int*)(D + o_dist);
+    int* d_idx = (int*)(D + o_idx); float* d_dist = (float*)(D + o_dist);
     MisDMatch* d_matches = (MisDMatch*)(D + o_matches); float* d_src = (float*)(D + o_src); float* d_dst = (float*)(D + o_dst);
     int* d_nm = (int*)(D + o_nm); uint8_t* d_mask = D + o_mask; PairOut* d_out = (PairOut*)(D + o_out);
     int rc;
@@ -293,9 +405,31 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     memcpy(h_pairs, pairs.data(), sizeof(PairDesc) * np);
     MIS_HIP(ctx, hipMemcpyAsync(d_feats, Hh + h_in, sizeof(FeatDev) * n, hipMemcpyHostToDevice, st));
     MIS_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(PairDesc) * np, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(knn2_hamming_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, d_idx, d_dist);
+    int l2_bad = 0;
+    if (!use_l2) {
+        hipLaunchKernelGGL(knn2_hamming_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, d_idx, d_dist);
+    } else {
+        // fp16 copies + squared norms of every image once, then one MFMA distance pass per directed pair
+        std::vector<size_t> hoff(n), noff(n);
+        Carver lc;
+        for (int i = 0; i < n; i++) { hoff[i] = lc.take((size_t)std::max(feats[i].n, 1) * 256); noff[i] = lc.take((size_t)std::max(feats[i].n, 1) * 4); }
+        const size_t o_bad = lc.take(4);
+        MIS_HIP(ctx, ws->l2.reserve(lc.off));
+        uint8_t* L = (uint8_t*)ws->l2.p;
+        MIS_HIP(ctx, hipMemsetAsync(L + o_bad, 0, 4, st));
+        for (int i = 0; i < n; i++)
+            if (feats[i].n > 0)
+                hipLaunchKernelGGL(l2_prep_kernel, dim3((feats[i].n + 3) / 4), dim3(256), 0, st, (const float*)feats[i].descriptors, feats[i].n,
+                                   feats[i].desc_cols, (_Float16*)(L + hoff[i]), (float*)(L + noff[i]), (int*)(L + o_bad));
+        for (const PairDesc& pd : pairs) {
+            L2Set A{(const _Float16*)(L + hoff[pd.i]), (const float*)(L + noff[pd.i]), feats[pd.i].n}, B{(const _Float16*)(L + hoff[pd.j]), (const float*)(L + noff[pd.j]), feats[pd.j].n};
+            hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((A.n + 63) / 64), dim3(256), 0, st, A, B, d_idx + 2 * pd.knn_off12, d_dist + 2 * pd.knn_off12);
+            hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((B.n + 63) / 64), dim3(256), 0, st, B, A, d_idx + 2 * pd.knn_off21, d_dist + 2 * pd.knn_off21);
+        }
+        MIS_HIP(ctx, hipMemcpyAsync(&l2_bad, L + o_bad, 4, hipMemcpyDeviceToHost, st));
+    }
     hipLaunchKernelGGL(ratio_union_kernel, dim3(np), dim3(1024), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, (const int*)d_idx,
-                       (const int*)d_dist, 1.f - p->match_conf, d_matches, d_src, d_dst, d_nm);
+                       (const float*)d_dist, 1.f - p->match_conf, d_matches, d_src, d_dst, d_nm);
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
                        (const float*)d_dst, d_mask, p->num_matches_thresh1, ws->b1.calls, d_out);
     if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence)) != MIS_OK) return rc;
@@ -316,6 +450,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipMemcpyAsync(hm, d_matches, sizeof(MisDMatch) * m_total, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(hmask, d_mask, m_total, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipStreamSynchronize(st));
+    MIS_CHECK(ctx, !l2_bad, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style)");
     // assemble MatchesInfo (host): confidence, mirror entry with H^-1 and swapped indices
     for (int k = 0; k < np; k++) {
         const PairDesc& pd = pairs[k];
@@ -385,33 +520,47 @@ extern "C" int mis_matches_free(MisMatchesInfo* m, int count) {
 extern "C" int mis_knn2(MisContext* ctx, const MisFeatures* q, const MisFeatures* t, int* idx2, float* dist2) {
     if (!ctx) return MIS_E_INVALID;
     MIS_CHECK(ctx, q && t && idx2 && dist2, MIS_E_INVALID, "null argument");
-    MIS_CHECK(ctx, q->desc_dtype == MIS_U8 && q->desc_cols == 32 && t->desc_dtype == MIS_U8 && t->desc_cols == 32, MIS_E_UNSUPPORTED,
-              "mis_knn2 supports 32-byte binary descriptors");
+    const bool binary = q->desc_dtype == MIS_U8 && q->desc_cols == 32 && t->desc_dtype == MIS_U8 && t->desc_cols == 32;
+    const bool l2 = q->desc_dtype == MIS_F32 && t->desc_dtype == MIS_F32 && q->desc_cols == t->desc_cols && q->desc_cols >= 1 && q->desc_cols <= 128;
+    MIS_CHECK(ctx, binary || l2, MIS_E_UNSUPPORTED, "mis_knn2 supports 32-byte binary descriptors (Hamming) and f32 descriptors of <= 128 columns (L2)");
     if (q->n <= 0) return MIS_OK;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    FeatDev fd[2] = {{(const uint8_t*)q->descriptors, q->keypoints, q->n, q->img_w, q->img_h},
-                     {(const uint8_t*)t->descriptors, t->keypoints, t->n, t->img_w, t->img_h}};
-    PairDesc pd;
-    pd.i = 0; pd.j = 1; pd.knn_off12 = 0; pd.knn_off21 = q->n; pd.m_off = 0; pd.cap = q->n + t->n;
-    size_t tot = (size_t)q->n + (size_t)std::max(t->n, 0);
     MatchWorkspace* ws = workspace(ctx);
     hipStream_t st = ctx->stream;
     MIS_HIP(ctx, hipStreamSynchronize(st));
+    const size_t nq = (size_t)q->n, nt = (size_t)std::max(t->n, 0);
     Carver dc;
-    const size_t o_feats = dc.take(sizeof(fd)), o_pairs = dc.take(sizeof(pd)), o_idx = dc.take(sizeof(int) * 2 * tot), o_dist = dc.take(sizeof(int) * 2 * tot);
+    const size_t o_feats = dc.take(2 * sizeof(FeatDev)), o_pairs = dc.take(sizeof(PairDesc)), o_idx = dc.take(sizeof(int) * 2 * nq), o_dist = dc.take(sizeof(float) * 2 * nq);
+    const size_t o_qh = dc.take(nq * 256), o_th = dc.take(nt * 256), o_qn = dc.take(nq * 4), o_tn = dc.take(nt * 4), o_bad = dc.take(4);
     MIS_HIP(ctx, ws->dev.reserve(dc.off));
     uint8_t* D = (uint8_t*)ws->dev.p;
-    struct { void* p; } d_feats{D + o_feats}, d_pairs{D + o_pairs}, d_idx{D + o_idx}, d_dist{D + o_dist};
-    MIS_HIP(ctx, hipMemcpyAsync(d_feats.p, fd, sizeof(fd), hipMemcpyHostToDevice, st));
-    MIS_HIP(ctx, hipMemcpyAsync(d_pairs.p, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(knn2_hamming_kernel, dim3((q->n + 255) / 256, 1), dim3(256), 0, st, (const FeatDev*)d_feats.p, (const PairDesc*)d_pairs.p,
-                       (int*)d_idx.p, (int*)d_dist.p);
+    int bad = 0;
+    if (binary) {
+        FeatDev fd[2] = {{(const uint8_t*)q->descriptors, q->keypoints, q->n, q->img_w, q->img_h},
+                         {(const uint8_t*)t->descriptors, t->keypoints, t->n, t->img_w, t->img_h}};
+        PairDesc pd;
+        pd.i = 0; pd.j = 1; pd.knn_off12 = 0; pd.knn_off21 = q->n; pd.m_off = 0; pd.cap = q->n + t->n;
+        MIS_HIP(ctx, hipMemcpyAsync(D + o_feats, fd, sizeof(fd), hipMemcpyHostToDevice, st));
+        MIS_HIP(ctx, hipMemcpyAsync(D + o_pairs, &pd, sizeof(pd), hipMemcpyHostToDevice, st));
+        MIS_HIP(ctx, hipStreamSynchronize(st));  // fd / pd live on this stack frame
+        hipLaunchKernelGGL(knn2_hamming_kernel, dim3((q->n + 255) / 256, 1), dim3(256), 0, st, (const FeatDev*)(D + o_feats), (const PairDesc*)(D + o_pairs),
+                           (int*)(D + o_idx), (float*)(D + o_dist));
+    } else {
+        MIS_HIP(ctx, hipMemsetAsync(D + o_bad, 0, 4, st));
+        hipLaunchKernelGGL(l2_prep_kernel, dim3((q->n + 3) / 4), dim3(256), 0, st, (const float*)q->descriptors, q->n, q->desc_cols, (_Float16*)(D + o_qh),
+                           (float*)(D + o_qn), (int*)(D + o_bad));
+        if (t->n > 0)
+            hipLaunchKernelGGL(l2_prep_kernel, dim3((t->n + 3) / 4), dim3(256), 0, st, (const float*)t->descriptors, t->n, t->desc_cols, (_Float16*)(D + o_th),
+                               (float*)(D + o_tn), (int*)(D + o_bad));
+        L2Set Q{(const _Float16*)(D + o_qh), (const float*)(D + o_qn), q->n}, T{(const _Float16*)(D + o_th), (const float*)(D + o_tn), std::max(t->n, 0)};
+        hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((q->n + 63) / 64), dim3(256), 0, st, Q, T, (int*)(D + o_idx), (float*)(D + o_dist));
+        MIS_HIP(ctx, hipMemcpyAsync(&bad, D + o_bad, 4, hipMemcpyDeviceToHost, st));
+    }
     MIS_HIP(ctx, hipGetLastError());
-    std::vector<int> hd(2 * (size_t)q->n);
-    MIS_HIP(ctx, hipMemcpyAsync(idx2, d_idx.p, sizeof(int) * 2 * q->n, hipMemcpyDeviceToHost, st));
-    MIS_HIP(ctx, hipMemcpyAsync(hd.data(), d_dist.p, sizeof(int) * 2 * q->n, hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipMemcpyAsync(idx2, D + o_idx, sizeof(int) * 2 * nq, hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipMemcpyAsync(dist2, D + o_dist, sizeof(float) * 2 * nq, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipStreamSynchronize(st));
-    for (size_t i = 0; i < hd.size(); i++) dist2[i] = (float)hd[i];
+    MIS_CHECK(ctx, !bad, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style): exactness of the fp16 MFMA path");
     return MIS_OK;
 }
 

@@ -135,3 +135,57 @@ def test_match_empty_and_tiny_feature_sets(ctx, oracle_mod):
     ref = oracle_mod.match_all_pairs([_feat_dict(k, d, (200, 100)) for k, d in sets])
     for g, o in zip(pm, ref):
         _compare_matches_info(g, o)
+
+
+def _sift_like(rng, n):
+    """SIFT-style descriptors: integer valued 0..255 stored as f32 (SURVEY config 5 surrogate)."""
+    d = rng.gamma(0.6, 30.0, (n, 128))
+    return np.clip(np.rint(d), 0, 255).astype(np.float32)
+
+
+def test_knn2_l2_mfma_bit_exact(ctx, oracle_mod):
+    import ctypes as C
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    rng = np.random.default_rng(51)
+    for nq, nt in ((700, 1300), (65, 33), (31, 2), (4096, 4096)):
+        q, t = _sift_like(rng, nq), _sift_like(rng, nt)
+        if nt > 40:
+            t[7] = q[3]; t[33] = q[3]      # exact duplicates in different lanes / tiles: tie -> smaller index
+        fq = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nq, KP_DTYPE), q)
+        ft = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nt, KP_DTYPE), t)
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.float32)
+        ctx.check(ctx.lib.mis_knn2(ctx.h, C.byref(fq.raw), C.byref(ft.raw), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+        oi, od = oracle_mod.knn2_l2(q, t)
+        assert np.array_equal(idx, oi)
+        assert np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+    # non-integer descriptors are refused (the fp16 MFMA path would not be exact)
+    bad = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(8, KP_DTYPE), rng.uniform(0, 1, (8, 128)).astype(np.float32))
+    with pytest.raises(isa.MisError):
+        ctx.check(ctx.lib.mis_knn2(ctx.h, C.byref(bad.raw), C.byref(bad.raw), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+
+
+def test_match_all_pairs_float_descriptors(ctx, oracle_mod):
+    """BestOf2NearestMatcher over SIFT-style float descriptors (match_conf 0.65 as with xfeatures2d)."""
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    rng = np.random.default_rng(52)
+    H = np.array([[0.98, 0.02, 40.0], [-0.01, 1.01, -9.0], [1e-5, 0.0, 1.0]])
+    n = 500
+    base = _sift_like(rng, n)
+    k1 = np.zeros(n, KP_DTYPE); k1["x"] = rng.uniform(0, 640, n); k1["y"] = rng.uniform(0, 480, n)
+    p = np.c_[k1["x"] - 320, k1["y"] - 240, np.ones(n)] @ H.T
+    k2 = np.zeros(n, KP_DTYPE); k2["x"] = p[:, 0] / p[:, 2] + 320; k2["y"] = p[:, 1] / p[:, 2] + 240
+    d2 = np.clip(base + rng.integers(-2, 3, base.shape), 0, 255).astype(np.float32)
+    d2[:80] = _sift_like(rng, 80)       # outliers
+    k3, d3 = np.zeros(300, KP_DTYPE), _sift_like(rng, 300)
+    k3["x"] = rng.uniform(0, 640, 300); k3["y"] = rng.uniform(0, 480, 300)
+    sets = [(k1, base), (k2, d2), (k3, d3)]
+    feats = [isa.ImageFeatures.upload(ctx, (640, 480), k, d, i) for i, (k, d) in enumerate(sets)]
+    pm = isa.BestOf2NearestMatcher(ctx, 0.65)(feats)
+    ref = oracle_mod.match_all_pairs([_feat_dict(k, d, (640, 480)) for k, d in sets], oracle_mod.match_default_params(match_conf=0.65))
+    for g, o in zip(pm, ref):
+        _compare_matches_info(g, o)
+    # 420 exact inliers of 420 matches: inliers / (8 + 0.3 m) > 3 -> the "too similar images" rule zeroes it
+    assert pm[1].num_inliers >= 400 and pm[1].confidence == 0.0 and pm[2].num_inliers < 20
