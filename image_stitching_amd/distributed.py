@@ -171,7 +171,7 @@ class HipEngine:
 class StitchJob:
     """The hot-path sequence of main() (image_stitching.cpp:567-1228) for one panorama, sharded."""
 
-    def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None):
+    def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
         self.cfg = config or st.StitchConfig()
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
@@ -181,6 +181,7 @@ class StitchJob:
         self.my_frames = frame_block(self.n, rank, world_size)
         self.frame_size = frame_size
         self.scale = st.Stitcher.warped_image_scale(cameras)
+        self.force_collectives = force_collectives   # run the pack / gather / reduce code even at world size 1 (tests)
         counts = {len(frame_block(self.n, r, world_size)) for r in range(world_size)}
         if len(counts) != 1:
             raise ValueError("the frame count must divide evenly over the ranks")
@@ -190,7 +191,7 @@ class StitchJob:
         return self.engine.detect([frames[i] for i in self.my_frames])
 
     def stage_gather(self, local_feats):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return local_feats
         kps, desc, counts = self.engine.pack_features(local_feats)
         kps_all = self.comm.all_gather(kps).flatten(0, 1)
@@ -221,7 +222,7 @@ class StitchJob:
         return btype, bands
 
     def stage_reduce(self):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         for lap, wgt in self.engine.accumulators():
             wide = lap.to(torch.int32)                 # no 16-bit integer type in RCCL: widen, sum, wrap
