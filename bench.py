@@ -4,7 +4,9 @@
 A "step" is one full pass of the hot path over one panorama job: ORB detect+describe of every frame,
 all-pairs 2-NN + RANSAC matching, connected-component pruning, spherical warp and multi-band blend
 (compose_megapix = -1: true 4K warp + blend), with the frames already resident in HBM and the
-ground-truth cameras standing in for the EXIF path.  N = 1 runs BASELINE config 3 (16 x 4K sweep).
+ground-truth cameras standing in for the EXIF path.  N = 1 runs BASELINE config 3 (16 x 4K sweep);
+N > 1 runs BASELINE config 4 (64 x 4K, the same 64-frame job for every N > 1: strong scaling) and adds
+`same_workload_on_1_gpu`, the unsharded run of that job on rank 0, as the base of the speed-up.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -34,6 +36,7 @@ def parse():
     ap.add_argument("--workload", default=None, help="config2 | config3 | config4 (default: config3, config4 when --gpus > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
+    ap.add_argument("--no-single-base", action="store_true", help="N > 1: skip the unsharded run of the same workload on rank 0")
     ap.add_argument("--roofline-launches", type=int, default=40)
     return ap.parse_args()
 
@@ -96,6 +99,24 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n * args.steps / dt
 
+    # N > 1: rank 0 also runs the SAME job alone (no sharding) so that the strong-scaling base of this workload
+    # is on the same line; the other ranks wait at the barrier below.  Outside the timed region.
+    single = None
+    if world > 1 and not args.no_single_base:
+        if rank == 0:
+            all_frames = {i: frames[i] if i in frames else synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in range(n)}
+            solo = misdist.StitchJob(ctx, (W, H), cams)
+            solo.run(all_frames)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                solo.run(all_frames)
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t1) / 2
+            single = {"value": round(n / t1, 3), "ms_per_step": round(t1 * 1e3, 3), "n_gpus": 1, "workload": workload}
+            del all_frames, solo
+        barrier()
+
     breakdown = None
     if args.breakdown and rank == 0:
         breakdown = job.breakdown(frames)
@@ -111,7 +132,7 @@ def main():
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong" if world > 1 and workload == "config3" else "weak", "vs_baseline": None, "dtype": "u8",
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%s: %d x %dx%d frames, ORB 4000 + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"
                                    % (workload, n, W, H),
@@ -119,6 +140,9 @@ def main():
                        "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if single:
+            res["same_workload_on_1_gpu"] = single
+            res["speedup_vs_1_gpu_same_workload"] = round(value / single["value"], 3)
         if breakdown:
             res["breakdown_ms"] = {k: round(v, 3) for k, v in breakdown.items()}
         print(json.dumps(res), flush=True)

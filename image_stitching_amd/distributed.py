@@ -8,12 +8,17 @@ spreads the same sequence over N ranks:
   match + RANSAC            pairs dealt round-robin           all-gather of {keypoints, descriptors, counts}
   component pruning         replicated (n <= 64)              all-reduce (sum) of the n x n confidence matrix
   warp + blend accumulate   frames (same blocks)              none
-  blend finalise            rank 0                            reduce (sum) of the Laplacian / weight pyramids
+  blend finalise            rank 0                            region gather of the Laplacian / weight pyramids
 
-16SC3 Laplacian sums are two's-complement wrap-around additions, so they are order independent: the
-pyramids are widened to int32 for the collective (RCCL has no 16-bit integer type) and narrowed with
-wrap afterwards -- bit-exact for any reduction order.  The f32 weight sums are order dependent in the
-last bit, which stays inside the 1-LSB pixel tolerance of the north star.
+Blend exchange.  A rank's frames are a contiguous block of the sweep, so its pyramid contributions are
+confined to one rectangle of the panorama (frame ROIs + the blender's 3 * 2^bands margin, aligned to
+2^bands so the rectangle maps exactly onto every pyramid level).  Instead of an all-reduce of the whole
+pyramid (which would also need int16 -> int32 widening: RCCL has no 16-bit integer type) each rank packs
+only its rectangle of every level into one byte buffer, ONE gather brings the buffers to rank 0 over the
+point-to-point xGMI links in parallel, and rank 0 adds them in rank order.  16SC3 Laplacian sums are
+two's-complement wrap-around additions and therefore exact in any order; the f32 weight sums are added
+in a fixed order (deterministic), differing from the single-GPU feed order in the last bit where >= 3
+frames overlap -- inside the 1-LSB pixel tolerance of the north star.
 
 The orchestration is engine-agnostic: `HipEngine` (the product) drives libmistitch through the C ABI;
 the CPU tests inject an engine of their own to exercise the sharding / collective logic under gloo.
@@ -55,11 +60,14 @@ class Comm:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def reduce_sum_to_root(self, t):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+    def gather_to_root(self, t):
+        """Equal-sized 1-D tensors -> list of world tensors on rank 0 (None elsewhere)."""
+        if self.world == 1:
+            return [t]
+        import torch.distributed as dist
+        bufs = [torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(t, bufs, dst=0, group=self.group)
+        return bufs
 
 
 class _DevArray:
@@ -147,15 +155,14 @@ class HipEngine:
         self.blender.feed(img_s, mask, tl)
 
     def accumulators(self):
-        """[(lap int16 tensor, weight f32 tensor)] views of the blender's panorama pyramids."""
+        """[(lap int16 [h, w*3], weight f32 [h, w])] tensor views of the blender's panorama pyramids."""
         out = []
         dev = self.ctx.device
         nb = self.ctx.lib.mis_blender_num_bands(self.blender.h)
         for l in range(nb + 1):
             w, h, lp, wp = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
             self.ctx.check(self.ctx.lib.mis_blender_level_info(self.blender.h, l, C.byref(w), C.byref(h), C.byref(lp), C.byref(wp)))
-            n = w.value * h.value
-            out.append((dev_tensor(lp.value, (n * 3,), "<i2", dev), dev_tensor(wp.value, (n,), "<f4", dev)))
+            out.append((dev_tensor(lp.value, (h.value, w.value * 3), "<i2", dev), dev_tensor(wp.value, (h.value, w.value), "<f4", dev)))
         return out
 
     def finalize(self):
@@ -216,20 +223,94 @@ class StitchJob:
         corners = [(rois[i][0], rois[i][1]) for i in indices]
         sizes = [(rois[i][2], rois[i][3]) for i in indices]
         btype, bands = eng.begin_compose(self.scale, corners, sizes)
+        self._compose_indices, self._compose_rois = indices, rois
         for i in self.my_frames:
             if i in rois:
                 eng.warp_feed(frames[i], self.cams[i], rois[i])
         return btype, bands
 
+    # -- blend exchange: region gather ---------------------------------------------------------
+    def rank_region(self, r, indices, rois, bands, w0, h0):
+        """Level-0 rectangle (x0, y0, x1, y1) of the panorama that rank r's frames can touch, or None."""
+        mine = [i for i in frame_block(self.n, r, self.world) if i in rois]
+        if not mine:
+            return None
+        px = min(rois[i][0] for i in indices)
+        py = min(rois[i][1] for i in indices)
+        gap, a = 3 << bands, (1 << bands) - 1
+        x0 = max(0, min(rois[i][0] for i in mine) - px - gap) & ~a
+        y0 = max(0, min(rois[i][1] for i in mine) - py - gap) & ~a
+        x1 = min(w0, (max(rois[i][0] + rois[i][2] for i in mine) - px + gap + a) & ~a)
+        y1 = min(h0, (max(rois[i][1] + rois[i][3] for i in mine) - py + gap + a) & ~a)
+        return x0, y0, x1, y1
+
+    @staticmethod
+    def _level_rects(region, levels):
+        """Per level (x0, y0, x1, y1) of a level-0 rectangle, clipped to the level size."""
+        x0, y0, x1, y1 = region
+        out = []
+        for l, (lap, wgt) in enumerate(levels):
+            h, w = wgt.shape
+            out.append((min(x0 >> l, w), min(y0 >> l, h), min(-((-x1) >> l), w), min(-((-y1) >> l), h)))
+        return out
+
+    @staticmethod
+    def _packed_size(rects):
+        return sum(((x1 - x0) * (y1 - y0) * 10 + 31) // 16 * 16 for x0, y0, x1, y1 in rects)   # 6 B lap + 4 B weight, 16 B aligned parts
+
+    @staticmethod
+    def _pack(levels, rects, nbytes):
+        dev = levels[0][0].device
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        o = 0
+        for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects):
+            m = (x1 - x0) * (y1 - y0)
+            if m:
+                buf[o:o + m * 6] = lap[y0:y1, 3 * x0:3 * x1].contiguous().view(torch.uint8).reshape(-1)
+                ow = o + (m * 6 + 15) // 16 * 16
+                buf[ow:ow + m * 4] = wgt[y0:y1, x0:x1].contiguous().view(torch.uint8).reshape(-1)
+            o += (m * 10 + 31) // 16 * 16
+        return buf
+
+    @staticmethod
+    def _add_packed(levels, rects, buf):
+        o = 0
+        for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects):
+            m = (x1 - x0) * (y1 - y0)
+            if m:
+                lap[y0:y1, 3 * x0:3 * x1] += buf[o:o + m * 6].view(torch.int16).view(y1 - y0, 3 * (x1 - x0))     # wraps
+                ow = o + (m * 6 + 15) // 16 * 16
+                wgt[y0:y1, x0:x1] += buf[ow:ow + m * 4].view(torch.float32).view(y1 - y0, x1 - x0)
+            o += (m * 10 + 31) // 16 * 16
+
     def stage_reduce(self):
         if self.world == 1 and not self.force_collectives:
             return
-        for lap, wgt in self.engine.accumulators():
-            wide = lap.to(torch.int32)                 # no 16-bit integer type in RCCL: widen, sum, wrap
-            self.comm.reduce_sum_to_root(wide)
-            self.comm.reduce_sum_to_root(wgt)
-            if self.rank == 0:
-                lap.copy_(wide.to(torch.int16))
+        levels = self.engine.accumulators()
+        bands = len(levels) - 1
+        h0, w0 = levels[0][1].shape
+        indices, rois = self._compose_indices, self._compose_rois
+        regions = [self.rank_region(r, indices, rois, bands, w0, h0) for r in range(self.world)]
+        rects = [self._level_rects(g, levels) if g else None for g in regions]
+        nbytes = max([self._packed_size(rc) for rc in rects[1:] if rc] + [16])
+        if self.force_collectives and self.world == 1:
+            # test mode: move this rank's own rectangle out, zero it, and add it back through the packed path
+            buf = self._pack(levels, rects[0], self._packed_size(rects[0]))
+            for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects[0]):
+                lap[y0:y1, 3 * x0:3 * x1] = 0
+                wgt[y0:y1, x0:x1] = 0
+            self._add_packed(levels, rects[0], buf)
+            return
+        mine = rects[self.rank]
+        if self.rank != 0 and mine:
+            buf = self._pack(levels, mine, nbytes)
+        else:
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=levels[0][0].device)
+        bufs = self.comm.gather_to_root(buf)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                if rects[r]:
+                    self._add_packed(levels, rects[r], bufs[r])
 
     def stage_finalize(self):
         if self.rank == 0:

@@ -106,9 +106,8 @@ class OracleEngine:
             w, h = C.c_int(), C.c_int()
             lp = L.mo_blender_level_lap(self.blender.h_, l, C.byref(w), C.byref(h))
             wp = L.mo_blender_level_weight(self.blender.h_, l, C.byref(w), C.byref(h))
-            n = w.value * h.value
-            lap = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_int16)), shape=(n * 3,))
-            wgt = np.ctypeslib.as_array(C.cast(wp, C.POINTER(C.c_float)), shape=(n,))
+            lap = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_int16)), shape=(h.value, w.value * 3))
+            wgt = np.ctypeslib.as_array(C.cast(wp, C.POINTER(C.c_float)), shape=(h.value, w.value))
             out.append((torch.from_numpy(lap), torch.from_numpy(wgt)))
         return out
 

@@ -1,7 +1,7 @@
 """world_size-2 gloo runs of the sharded panorama job (image_stitching_amd.distributed.StitchJob) on CPU.
 
-The orchestration (frame blocks, feature all-gather, round-robin pairs, confidence all-reduce, pyramid
-reduce with int32 widening, root finalise) is engine-agnostic; here the oracle-backed engine from
+The orchestration (frame blocks, feature all-gather, round-robin pairs, confidence all-reduce, packed
+region gather of the blend pyramids, root finalise) is engine-agnostic; here the oracle-backed engine from
 tests/oracle_engine.py stands in for the HIP engine so the N > 1 path runs without a GPU."""
 import os
 import socket
@@ -86,12 +86,25 @@ def test_two_rank_job_matches_single_rank(tmp_path):
     assert (d > 0).mean() < 0.02
 
 
-def test_reduce_widening_is_wraparound_exact():
-    """int16 accumulators summed through int32 and wrapped back equal sequential int16 wrap-around sums."""
-    rng = np.random.default_rng(3)
-    parts = [rng.integers(-32768, 32767, 1000).astype(np.int16) for _ in range(8)]
-    seq = np.zeros(1000, np.int16)
-    for p in parts:
-        seq = (seq.astype(np.int32) + p).astype(np.int16)          # C-style wrap
-    wide = sum(torch.from_numpy(p).to(torch.int32) for p in parts)
-    assert np.array_equal(wide.to(torch.int16).numpy(), seq)
+def test_region_pack_roundtrip_and_int16_wrap():
+    """Packed rectangle exchange: pack -> add lands on the same pixels at every level; int16 adds wrap."""
+    from image_stitching_amd.distributed import StitchJob
+    g = torch.Generator().manual_seed(5)
+    levels = []
+    w, h = 64, 32
+    for l in range(3):
+        levels.append((torch.randint(-32768, 32767, (h, w * 3), generator=g, dtype=torch.int16), torch.rand((h, w), generator=g)))
+        w, h = w // 2, h // 2
+    region = (8, 4, 40, 28)
+    rects = StitchJob._level_rects(region, levels)
+    assert rects == [(8, 4, 40, 28), (4, 2, 20, 14), (2, 1, 10, 7)]
+    buf = StitchJob._pack(levels, rects, StitchJob._packed_size(rects) + 64)
+    dst = [(torch.full_like(a, 30000), torch.ones_like(b)) for a, b in levels]
+    StitchJob._add_packed(dst, rects, buf)
+    for (a, b), (da, db), (x0, y0, x1, y1) in zip(levels, dst, rects):
+        exp = (a.to(torch.int32) + 30000).to(torch.int16)                  # two's-complement wrap
+        assert torch.equal(da[y0:y1, 3 * x0:3 * x1], exp[y0:y1, 3 * x0:3 * x1])
+        assert torch.equal(db[y0:y1, x0:x1], b[y0:y1, x0:x1] + 1)
+        outside = torch.ones_like(db, dtype=torch.bool)
+        outside[y0:y1, x0:x1] = False
+        assert bool((db[outside] == 1).all()) and bool((da[outside.repeat_interleave(3, 1)] == 30000).all())

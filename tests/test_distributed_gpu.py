@@ -1,5 +1,5 @@
 """GPU: the HipEngine side of the sharded job (feature packing for the all-gather, raw-pointer tensor
-views of the blender pyramids, int32-widened reduce) exercised at world size 1 with the collective code
+views of the blender pyramids, packed region exchange) exercised at world size 1 with the collective code
 paths forced on; the result must equal the plain single-GPU path bit for bit."""
 import numpy as np
 import pytest
