@@ -480,6 +480,16 @@ __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, con
 }
 
 // ---------------------------------------------------------------- scan_tail_kernel -------------
+#ifdef MIS_TAIL_PROF
+__device__ unsigned long long g_tail_prof[8];   // jacobi ticks, rotations, normal_eq ticks, LM iterations, dlt ticks, tail ticks, tails, max tail ticks
+#define PROF_T0(v) unsigned long long v = wall_clock64()
+#define PROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_tail_prof[i], wall_clock64() - (v)); } while (0)
+#define PROF_INC(i, n) do { if (threadIdx.x == 0) atomicAdd(&g_tail_prof[i], (unsigned long long)(n)); } while (0)
+#else
+#define PROF_T0(v)
+#define PROF_ADD(i, v)
+#define PROF_INC(i, n)
+#endif
 struct TailShared {
     double A[81], V[81], W[9];
     double best[9], nrm[8];
@@ -501,6 +511,7 @@ __device__ __forceinline__ void wave_sync() {
 __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
     double* A = S.A; double* V = S.V; double* W = S.W;
     const int t = threadIdx.x;
+    PROF_T0(pj);
     if (t < 64) {
         const double eps = DBL_EPSILON;
         int i, k, l, m;
@@ -538,6 +549,7 @@ __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
             }
             const double p = A[n * k + l];
             if (fabs(p) <= eps) break;  // uniform: every lane reads the same LDS words
+            PROF_INC(1, 1);
             const double y = (W[l] - W[k]) * 0.5;
             double tt = fabs(y) + cv_hypot(p, y);
             double sn = cv_hypot(p, tt);
@@ -589,6 +601,7 @@ __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
         }
     }
     __syncthreads();
+    PROF_ADD(0, pj);
 }
 
 // LM callback of the homography refinement (fundam.cpp HomographyRefineCallback)
@@ -675,6 +688,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
         if (t < 36) { a0 = j0[ai]; b0 = j0[aj]; a1 = j1[ai]; b1 = j1[aj]; }
         else if (t >= 64 && t < 72) { a0 = j0[t - 64]; b0 = 7; a1 = j1[t - 64]; b1 = 8; }
         double acc = 0, mx = 0;
+        PROF_T0(pn);
         for (int base = 0; base < np; base += TB) {
             const int p = base + t, cnt = min(TB, np - base);
             if (p < np) {
@@ -706,6 +720,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
         else if (with_J && t >= 64 && t < 72) v[t - 64] = acc;
         else if (t == 128) { sc[with_J ? 0 : 1] = acc; if (with_J) sc[2] = mx; }
         __syncthreads();
+        PROF_ADD(2, pn);
     };
     if (t < 8) x[t] = S.best[t];
     __syncthreads();
@@ -795,6 +810,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
         __syncthreads();
         if (sc[3] != 0.) normal_eq(x, true);
         iter++;
+        PROF_INC(3, 1);
         double dmax = 0;
         for (int i = 0; i < 8; i++) { double a = fabs(d[i]); if (a > dmax) dmax = a; }
         bool proceed = iter < 10 && dmax >= (double)FLT_EPSILON && sc[2] >= (double)FLT_EPSILON;
@@ -891,10 +907,17 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         __syncthreads();
     }
     const int np = s_base;
+    PROF_T0(pt);
     if (np > 0) {
         dlt_coop(S, s1, d1, np, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
+        PROF_ADD(4, pt);
         lm_refine_coop(S, s1, d1, np, rec);
     }
+    PROF_ADD(5, pt);
+    PROF_INC(6, 1);
+#ifdef MIS_TAIL_PROF
+    if (t == 0) atomicMax(&g_tail_prof[7], wall_clock64() - pt);
+#endif
     if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; }
 }
 
@@ -947,6 +970,15 @@ int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long point
     b->count = count; b->points = points; b->max_iters = max_iters;
     return MIS_OK;
 }
+
+#ifdef MIS_TAIL_PROF
+extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 void homo_batch_release(HomoBatch* b) {
     if (b->mem) hipFree(b->mem);

@@ -192,107 +192,221 @@ __device__ __forceinline__ void tile_trig(const WarpArgs& a, int tx0, int ty0, f
     __syncthreads();
 }
 
-// Fused compose-scale warp: 8UC3 source -> 16SC3 image + 8U mask.
+// Fused compose-scale warp: 8UC3 source -> 16SC3 image + 8U mask (K10, the roofline kernel).
 //
-// sin/cos of the column angle u = (tlx + x) / scale and of the row angle pi - v are separable, so a
-// tiny pre-kernel tabulates them (dw + dh entries) and the main kernel has no trigonometry at all.
-// One wave per workgroup (no workgroup barriers): the wave owns a 128 x 4 output tile, a lane owns
-// 2 adjacent columns x 4 rows (12-byte stores).  The wave evaluates the map of all its pixels (kept
-// in registers), all-reduces the bounding box of the interior taps with shuffles, stages exactly that
-// box of the source in LDS with coalesced dword loads, and gathers the 12 taps per pixel from LDS.
-// Pixels whose taps need BORDER_REFLECT (outside the frame) and tiles whose box does not fit take the
-// global-memory gather in a cold fix-up pass.
-constexpr int FT_W = 128, FT_H = 4;
-constexpr int STAGE_BYTES = 16 * 512;  // 16 rows x 512 bytes
+// The kernel is VALU bound (PMC: profiles/), so the design minimises vector instructions per pixel:
+//  * sin/cos of the column angle u = (tlx + x) / scale and of the row angle pi - v are separable: a tiny
+//    pre-kernel tabulates {sin u, cos u} per column and {sin v, m1 cos v, m4 cos v, m7 cos v} per row
+//    (the row products are the same f32 products the per-pixel formula forms): no trigonometry here.
+//  * One wave per workgroup (no workgroup barriers) owns a 32 x 16 output tile -- nearly square, because
+//    off the optical axis a tile's source footprint is a slanted strip (dy/du = tan v sin u / cos^2 u:
+//    ~29 source rows across 128 columns at a 4K frame's corner) and the staged box must stay small.
+//    A lane owns 2 adjacent columns x 4 rows; the two columns are the halves of packed-f32 registers.
+//  * x / z and y / z share one reciprocal refinement: the divide is the exact FMA sequence of an IEEE f32
+//    division (rcp, Newton step, quotient, two residual corrections) without its scaling / fix-up
+//    instructions, valid while z is in [2^-30, 2^30] and |x|, |y| < 2^15; a wave-uniform guard sends
+//    everything else down the generic path (IEEE division, x86 cvRound overflow, saturate_cast<short>).
+//  * The wave all-reduces the bounding box of its taps (DPP), stages exactly that box of the source in
+//    LDS with direct global->LDS loads (16-byte pieces, several box rows per instruction, no staging
+//    registers), and gathers the 12 taps per pixel from LDS.  Tiles whose taps need BORDER_REFLECT fold
+//    the box once; boxes that do not fit take a global-memory gather (cold).
+constexpr int FT_W = 32, FT_H = 16;
+constexpr int STAGE_BYTES = 5120;  // 32 single-wave workgroups per CU fit the 160 KB of LDS
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__host__ __device__ __forceinline__ int trig_cols(int dw) { return (dw + 3) & ~1; }  // >= dw + 2, even: 16-byte aligned row table
+static size_t trig_table_floats(int dw, int dh) { return 2 * (size_t)trig_cols(dw) + 4 * (size_t)dh; }
 
 __global__ __launch_bounds__(256) void warp_trig_kernel(WarpArgs a, float* tab) {
-    // tab: su[dw] cu[dw] sv[dh] cv[dh]
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x, ncol = trig_cols(a.dw);
+    if (i < ncol) {
         float u = (float)(a.tlx + i) / a.scale;
-        mis_sincosf(u, &tab[i], &tab[a.dw + i]);
-    } else if (i < a.dw + a.dh) {
-        int r = i - a.dw;
-        float v = (float)(a.tly + r) / a.scale;
-        mis_sincosf(MIS_PI_F - v, &tab[2 * a.dw + r], &tab[2 * a.dw + a.dh + r]);
+        mis_sincosf(u, &tab[2 * i], &tab[2 * i + 1]);
+    } else if (i < ncol + a.dh) {
+        const int r = i - ncol;
+        float v = (float)(a.tly + r) / a.scale, s, c;
+        mis_sincosf(MIS_PI_F - v, &s, &c);
+        float* t = tab + 2 * ncol + 4 * r;
+        t[0] = s; t[1] = a.m[1] * c; t[2] = a.m[4] * c; t[3] = a.m[7] * c;
     }
 }
 
 // cvRound(v) in [0, len): round-half-even maps [-0.5, len - 0.5) into range, and the upper end point
 // len - 0.5 too when len - 1 is even (ties go to the even neighbour)
-__device__ __forceinline__ bool round_in_range(float v, float hi, bool hi_even) { return v >= -0.5f && (v < hi || (hi_even && v == hi)); }
+__device__ __forceinline__ bool round_in_range(float v, float hi, bool hi_even) { return (v >= -0.5f) & ((v < hi) | (hi_even & (v == hi))); }
 
-// bilinear gather of 8 pixels from the staged box.  REFLECT = false: every tap is interior, the four
-// taps of a pixel are at fixed offsets from the top-left one.  REFLECT = true: taps are folded once
-// (BORDER_REFLECT, coordinates known to lie in [-len, 2 len)) and addressed individually.
+// wave-wide min / max -> uniform result: xor-1, xor-2, half-mirror and mirror inside the 16-lane rows as
+// single DPP instructions (s_nop 1: two wait states between a VALU write and its DPP read), then 4 readlanes
+#define MIS_DPP_STEP(OP, CTRL) asm volatile("s_nop 1\n\tv_" OP "_i32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v))
+__device__ __forceinline__ int wave_min_i32(int v) {
+    MIS_DPP_STEP("min", "quad_perm:[1,0,3,2]"); MIS_DPP_STEP("min", "quad_perm:[2,3,0,1]");
+    MIS_DPP_STEP("min", "row_half_mirror"); MIS_DPP_STEP("min", "row_mirror");
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    MIS_DPP_STEP("max", "quad_perm:[1,0,3,2]"); MIS_DPP_STEP("max", "quad_perm:[2,3,0,1]");
+    MIS_DPP_STEP("max", "row_half_mirror"); MIS_DPP_STEP("max", "row_mirror");
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+#undef MIS_DPP_STEP
+
+// numerators / denominator of SphericalProjector::mapBackward for a lane's two columns of one row
+__device__ __forceinline__ void map_terms(const float* m, v2f su, v2f cu, float4 rt, v2f* xx, v2f* yy, v2f* zz) {
+    const v2f x_ = su * rt.x, z_ = cu * rt.x;   // sinv * sinu, sinv * cosu;  y_ = cosv is folded into rt.y/z/w
+    *xx = (x_ * m[0] + rt.y) + z_ * m[2];
+    *yy = (x_ * m[3] + rt.z) + z_ * m[5];
+    *zz = (x_ * m[6] + rt.w) + z_ * m[8];
+}
+
+// nx / d and ny / d for both columns: the FMA chain of an IEEE-correct f32 division (see the header comment)
+__device__ __forceinline__ void div2_shared(v2f nx, v2f ny, v2f d, v2f* qx, v2f* qy) {
+    const v2f r0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const v2f nd = -d, one = {1.f, 1.f};
+    const v2f e = __builtin_elementwise_fma(nd, r0, one);
+    const v2f r = __builtin_elementwise_fma(e, r0, r0);
+    v2f q = nx * r;
+    v2f t = __builtin_elementwise_fma(nd, q, nx);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(nd, q, nx);
+    *qx = __builtin_elementwise_fma(t, r, q);
+    q = ny * r;
+    t = __builtin_elementwise_fma(nd, q, ny);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(nd, q, ny);
+    *qy = __builtin_elementwise_fma(t, r, q);
+}
+
+// 24-bit multiply-add in one instruction (the compiler prefers mul + add3 chains: 6 instead of 4 per channel)
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// bilinear sample of one pixel from the staged box (the Q15 weights of remap factor exactly as
+// 32 * a_i * b_j, so (sum(w_ij p_ij) + 2^14) >> 15 == (sum(a_i b_j p_ij) + 512) >> 10)
 template <bool REFLECT>
-__device__ __forceinline__ void sample8(const uint8_t* stage, int lbase, int pitch, int sw, int sh, const int* sxq, const int* syq, int (*p)[3]) {
+__device__ __forceinline__ void sample1(const uint8_t* stage, int lbase, int pitch, int sw, int sh, int xq, int yq, int* p) {
+    const int fx = xq & 31, fy = yq & 31, sx = xq >> 5, sy = yq >> 5;
+    const int wa = 32 - fx, wb = 32 - fy;
+    const uint8_t *t00, *t01, *t10, *t11;
+    if (!REFLECT) {
+        t00 = stage + (lbase + __mul24(sy, pitch) + sx * 3); t01 = t00 + 3; t10 = t00 + pitch; t11 = t10 + 3;
+    } else {
+        const int x0 = mis_reflect1(sx, sw) * 3, x1 = mis_reflect1(sx + 1, sw) * 3;
+        const int y0 = lbase + __mul24(mis_reflect1(sy, sh), pitch), y1 = lbase + __mul24(mis_reflect1(sy + 1, sh), pitch);
+        t00 = stage + (y0 + x0); t01 = stage + (y0 + x1); t10 = stage + (y1 + x0); t11 = stage + (y1 + x1);
+    }
+    const int w00 = wa * wb, w01 = fx * wb, w10 = wa * fy, w11 = fx * fy;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int fx = sxq[q] & 31, fy = syq[q] & 31;
-        const int sx = sxq[q] >> 5, sy = syq[q] >> 5;
-        const int wa = 32 - fx, wb = 32 - fy;
-        const uint8_t *t00, *t01, *t10, *t11;
-        if (!REFLECT) {
-            t00 = stage + (lbase + sy * pitch + sx * 3); t01 = t00 + 3; t10 = t00 + pitch; t11 = t10 + 3;
-        } else {
-            const int x0 = mis_reflect1(sx, sw) * 3, x1 = mis_reflect1(sx + 1, sw) * 3;
-            const int y0 = lbase + mis_reflect1(sy, sh) * pitch, y1 = lbase + mis_reflect1(sy + 1, sh) * pitch;
-            t00 = stage + (y0 + x0); t01 = stage + (y0 + x1); t10 = stage + (y1 + x0); t11 = stage + (y1 + x1);
-        }
-        // sum(w_ij * p_ij) with w_ij = 32 * a_i * b_j factors exactly: two horizontal lerps, one vertical
+    for (int c = 0; c < 3; c++) p[c] = (int)(mad24(t11[c], w11, mad24(t10[c], w10, mad24(t01[c], w01, mad24(t00[c], w00, 512u)))) >> 10);
+}
+
+__device__ __forceinline__ void sample1_global(const WarpArgs& a, int xq, int yq, int* p) {
+    const int fx = xq & 31, fy = yq & 31, sx = xq >> 5, sy = yq >> 5;
+    const int x0 = mis_reflect(sx, a.sw), x1 = mis_reflect(sx + 1, a.sw), y0 = mis_reflect(sy, a.sh), y1 = mis_reflect(sy + 1, a.sh);
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const uint8_t* r0 = a.src + (size_t)y0 * a.sstride;
+    const uint8_t* r1 = a.src + (size_t)y1 * a.sstride;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int h0 = t00[c] * wa + t01[c] * fx, h1 = t10[c] * wa + t11[c] * fx;
-            p[q][c] = (h0 * wb + h1 * fy + 512) >> 10;
+    for (int c = 0; c < 3; c++)
+        p[c] = (r0[x0 * 3 + c] * w00 + r0[x1 * 3 + c] * w01 + r1[x0 * 3 + c] * w10 + r1[x1 * 3 + c] * w11 + (1 << 14)) >> 15;
+}
+
+// global -> LDS copy of `nrows` box rows of `pitch` bytes (PIECE bytes per lane, 64 / (pitch / PIECE) rows per
+// instruction); the LDS image is row-major with that pitch.  Wave-uniform arguments except `lane`.
+template <int PIECE>
+__device__ __forceinline__ void stage_box(const uint8_t* src, size_t sstride, uint8_t* stage, int pitch, int nrows, int lane) {
+    const int lpr = pitch / PIECE;                 // lanes per row (<= 64)
+    const int k = 64 / lpr;                        // rows per instruction
+    const int lr = (lane * (65536 / lpr + 1)) >> 16, lc = lane - lr * lpr;   // lane / lpr, lane % lpr (exact for lane < 64)
+    const uint8_t* g = src + (size_t)lr * sstride + (size_t)lc * PIECE;
+    const int live = lr < k ? nrows - lr : 0;      // this lane copies rows r0 + lr while r0 < live
+    for (int r0 = 0; r0 < nrows; r0 += k) {
+        if (r0 < live) {
+            const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(g + (size_t)r0 * sstride);
+            __attribute__((address_space(3))) void* lp = (__attribute__((address_space(3))) void*)(stage + r0 * pitch);
+            if constexpr (PIECE == 16) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(gp, lp, 4, 0, 0);
         }
     }
 }
 
-__global__ __launch_bounds__(64, 4) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab) {
+#ifdef MIS_WARP_STATS
+__device__ unsigned g_warp_stats[8];   // tiles: interior, folded, global gather, generic-map
+#define WSTAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_warp_stats[i], 1u); } while (0)
+#else
+#define WSTAT(i)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
     const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H;
-    const int lane = threadIdx.x;
-    const int gxr = tx0 + 2 * lane;
+    const int lane = threadIdx.x, lx = lane & 15, ly = lane >> 4;
+    const int gxr = tx0 + 2 * lx, gy0 = ty0 + 4 * ly;
     const bool col_ok = gxr < a.dw, two = gxr + 1 < a.dw;
-    const int gx = col_ok ? gxr : a.dw - 1;  // out-of-roi lanes shadow the last column (never stored)
+    const int gx = col_ok ? gxr : ((a.dw - 1) & ~1);  // out-of-roi lanes shadow the last column pair (never stored)
     const float xhi = (float)a.sw - 0.5f, yhi = (float)a.sh - 0.5f;  // exact: sizes < 2^15
     const bool xe = ((a.sw - 1) & 1) == 0, ye = ((a.sh - 1) & 1) == 0;
-    int sxq[8], syq[8];
-    unsigned msk = 0;  // bit q: nearest source pixel of pixel q lies inside the frame
-    {
-        const int gx1 = two ? gx + 1 : gx;
-        const float su0 = tab[gx], cu0 = tab[a.dw + gx], su1 = tab[gx1], cu1 = tab[a.dw + gx1];
+    // v < hi || (even && v == hi)  <=>  v < hi2 with hi2 the next float above hi when the end point is included
+    const float xhi2 = xe ? __uint_as_float(__float_as_uint(xhi) + 1u) : xhi, yhi2 = ye ? __uint_as_float(__float_as_uint(yhi) + 1u) : yhi;
+    const float4 cs = *reinterpret_cast<const float4*>(tab + 2 * gx);  // {sin, cos} of this lane's two columns
+    const v2f su = {cs.x, cs.z}, cu = {cs.y, cs.w};
+    const float4* rowtab = reinterpret_cast<const float4*>(tab + 2 * trig_cols(a.dw));
+    int xq[8], yq[8];   // q = 2 * row + column: 5 fraction bits below the (short-range) integer coordinate
+    unsigned msk = 0;   // bit q: the nearest source pixel of pixel q lies inside the frame
+    bool bad = !(fabsf(a.m[6]) + fabsf(a.m[7]) + fabsf(a.m[8]) <= 1048576.f);   // |z| <= that sum: no upper check per pixel
 #pragma unroll
-        for (int i = 0; i < FT_H; i++) {
-            const int gy = min(ty0 + i, a.dh - 1);  // wave-uniform: scalar loads; rows past the roi shadow the last one
-            const float s_v = tab[2 * a.dw + gy], c_v = tab[2 * a.dw + a.dh + gy];
+    for (int i = 0; i < 4; i++) {
+        const int gy = min(gy0 + i, a.dh - 1);  // rows past the roi shadow the last one
+        v2f xx, yy, zz, qx, qy;
+        map_terms(a.m, su, cu, rowtab[gy], &xx, &yy, &zz);
+        div2_shared(xx, yy, zz, &qx, &qy);
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int q = 2 * i + k;
-                float x, y;
-                map_backward(a.m, k ? su1 : su0, k ? cu1 : cu0, s_v, c_v, &x, &y);
-                // saturate_cast<short> of the integer part, the 5 fraction bits are kept below it
-                const int xq = mis_round_sat_f(x * 32.f), yq = mis_round_sat_f(y * 32.f);
-                sxq[q] = (mis_sat_short(xq >> 5) << 5) | (xq & 31);
-                syq[q] = (mis_sat_short(yq >> 5) << 5) | (yq & 31);
-                msk |= (round_in_range(x, xhi, xe) && round_in_range(y, yhi, ye)) ? (1u << q) : 0u;
-            }
+        for (int k = 0; k < 2; k++) {
+            const bool sel = zz[k] >= 9.31322574615478515625e-10f;   // z >= 2^-30: in front of the camera and safely divisible
+            bad |= (zz[k] > 0) & !sel;
+            const float x = sel ? qx[k] : -1.f, y = sel ? qy[k] : -1.f;
+            xq[2 * i + k] = mis_round_f(x * 32.f);   // v_cvt saturates: out-of-range values show up in the box below
+            yq[2 * i + k] = mis_round_f(y * 32.f);
+            msk |= (unsigned)((x >= -0.5f) & (x < xhi2) & (y >= -0.5f) & (y < yhi2)) << (2 * i + k);
         }
     }
-    // bounding box of the top-left taps; all taps interior <=> 0 <= min and max + 1 <= len - 1
-    int xmin = sxq[0] >> 5, xmax = xmin, ymin = syq[0] >> 5, ymax = ymin;
+    // bounding box of the top-left taps (floor division by 32 is monotonic: reduce the packed values)
+    int xmin, xmax, ymin, ymax;
+    auto reduce_box = [&]() {
+        xmin = xq[0]; xmax = xq[0]; ymin = yq[0]; ymax = yq[0];
 #pragma unroll
-    for (int q = 1; q < 8; q++) {
-        xmin = min(xmin, sxq[q] >> 5); xmax = max(xmax, sxq[q] >> 5);
-        ymin = min(ymin, syq[q] >> 5); ymax = max(ymax, syq[q] >> 5);
-    }
+        for (int q = 1; q < 8; q++) {
+            xmin = min(xmin, xq[q]); xmax = max(xmax, xq[q]);
+            ymin = min(ymin, yq[q]); ymax = max(ymax, yq[q]);
+        }
+        xmin = wave_min_i32(xmin); xmax = wave_max_i32(xmax);
+        ymin = wave_min_i32(ymin); ymax = wave_max_i32(ymax);
+    };
+    reduce_box();
+    if (__any(bad) || xmin <= -(1 << 20) || ymin <= -(1 << 20) || xmax >= (1 << 20) || ymax >= (1 << 20)) {
+        // generic path (cold): IEEE division, x86 cvRound overflow semantics, saturate_cast<short> of the integer part
+        WSTAT(3);
+        msk = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
-        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        for (int i = 0; i < 4; i++) {
+            const int gy = min(gy0 + i, a.dh - 1);
+            v2f xx, yy, zz;
+            map_terms(a.m, su, cu, rowtab[gy], &xx, &yy, &zz);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool front = zz[k] > 0;
+                const float x = front ? xx[k] / zz[k] : -1.f, y = front ? yy[k] / zz[k] : -1.f;
+                const int xr = mis_round_sat_f(x * 32.f), yr = mis_round_sat_f(y * 32.f);
+                xq[2 * i + k] = (mis_sat_short(xr >> 5) << 5) | (xr & 31);
+                yq[2 * i + k] = (mis_sat_short(yr >> 5) << 5) | (yr & 31);
+                msk |= (unsigned)(round_in_range(x, xhi, xe) & round_in_range(y, yhi, ye)) << (2 * i + k);
+            }
+        }
+        reduce_box();
     }
-    // wave-uniform classification
+    xmin >>= 5; xmax >>= 5; ymin >>= 5; ymax >>= 5;
+    // wave-uniform classification; all taps interior <=> 0 <= min and max + 1 <= len - 1
     const bool interior = xmin >= 0 && ymin >= 0 && xmax + 1 <= a.sw - 1 && ymax + 1 <= a.sh - 1;
     const bool foldable = xmin >= -a.sw && xmax + 1 < 2 * a.sw && ymin >= -a.sh && ymax + 1 < 2 * a.sh;
     int bx0 = xmin, bx1 = xmax + 1, by0 = ymin, by1 = ymax + 1;  // box of source columns / rows to stage
@@ -308,80 +422,55 @@ __global__ __launch_bounds__(64, 4) void warp_fused_kernel(WarpArgs a, const flo
         fold(xmin, xmax + 1, a.sw, &bx0, &bx1);
         fold(ymin, ymax + 1, a.sh, &by0, &by1);
     }
-    // With a 4-byte-multiple stride every row has the same alignment shift, so LDS offsets are 32-bit
-    // and affine in the source coordinates.
-    const int shift = (bx0 * 3) & 3;
-    const int pitch = ((bx1 - bx0 + 1) * 3 + shift + 3) & ~3;
+    // Rows are copied in whole 16-byte (or, for frames whose base / stride is not 16-byte aligned, 4-byte)
+    // pieces starting at an aligned address: every row has the same alignment shift, so LDS offsets are
+    // 32-bit and affine in the source coordinates.  The last piece of the last row must lie inside the frame.
+    const bool wide = (((size_t)a.src | a.sstride) & 15) == 0;
+    const int amask = wide ? 15 : 3;
+    const int shift = (bx0 * 3) & amask;
+    const int pitch = ((bx1 - bx0 + 1) * 3 + shift + amask) & ~amask;
     const int nrows = by1 - by0 + 1;
-    constexpr int MAXR = 16;  // rows of the staged box; a row is at most 128 dwords (two per lane)
-    const bool staged = (interior || foldable) && (a.sstride & 3) == 0 && nrows <= MAXR && pitch <= 512;
+    const size_t total_bytes = (size_t)(a.sh - 1) * a.sstride + (size_t)a.sw * 3;  // last valid byte + 1
+    const size_t gbase = (size_t)by0 * a.sstride + (size_t)(bx0 * 3 - shift);
+    const bool staged = (interior || foldable) && (((size_t)a.src | a.sstride) & 3) == 0 && nrows * pitch <= STAGE_BYTES &&
+                        pitch <= (wide ? 1024 : 256) && gbase + (size_t)(nrows - 1) * a.sstride + pitch <= total_bytes;
     if (staged) {
-        // all loads of the box are issued before the first LDS write: one memory latency per tile
-        const int dwords_per_row = pitch >> 2;
-        const size_t total_bytes = (size_t)(a.sh - 1) * a.sstride + (size_t)a.sw * 3;  // last valid byte + 1
-        const size_t gbase = (size_t)by0 * a.sstride + (size_t)(bx0 * 3 - shift) + 4 * (size_t)lane;
-        const bool c0 = lane < dwords_per_row, c1 = lane + 64 < dwords_per_row;
-        unsigned v0[MAXR], v1[MAXR];
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            const size_t g0 = gbase + (size_t)r * a.sstride;
-            v0[r] = 0; v1[r] = 0;
-            if (r < nrows) {
-                if (c0) {
-                    if (g0 + 4 <= total_bytes) v0[r] = *reinterpret_cast<const unsigned*>(a.src + g0);
-                    else for (int k = 0; k < 4; k++) if (g0 + k < total_bytes) v0[r] |= (unsigned)a.src[g0 + k] << (8 * k);
-                }
-                if (c1) {
-                    if (g0 + 256 + 4 <= total_bytes) v1[r] = *reinterpret_cast<const unsigned*>(a.src + g0 + 256);
-                    else for (int k = 0; k < 4; k++) if (g0 + 256 + k < total_bytes) v1[r] |= (unsigned)a.src[g0 + 256 + k] << (8 * k);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            if (r < nrows) {
-                if (c0) *reinterpret_cast<unsigned*>(stage + r * pitch + 4 * lane) = v0[r];
-                if (c1) *reinterpret_cast<unsigned*>(stage + r * pitch + 4 * lane + 256) = v1[r];
-            }
-        }
+        if (wide) stage_box<16>(a.src + gbase, a.sstride, stage, pitch, nrows, lane);
+        else stage_box<4>(a.src + gbase, a.sstride, stage, pitch, nrows, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();  // single-wave workgroup: an LDS fence
+    WSTAT(staged ? (interior ? 0 : 1) : 2);
     if (!col_ok) return;
     const int lbase = shift - by0 * pitch - bx0 * 3;  // LDS byte offset of source pixel (0, 0)
-    int p[8][3];
-    if (staged && interior) sample8<false>(stage, lbase, pitch, a.sw, a.sh, sxq, syq, p);
-    else if (staged) sample8<true>(stage, lbase, pitch, a.sw, a.sh, sxq, syq, p);
-    else {
-        // box too large for LDS or coordinates far outside the frame: gather from global memory
+    uint8_t* drow = (uint8_t*)a.dst + (size_t)gy0 * a.dstride + (size_t)gx * 6;
+    uint8_t* mrow = a.mask + (size_t)gy0 * a.mstride + gx;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int fx = sxq[q] & 31, fy = syq[q] & 31, sx = sxq[q] >> 5, sy = syq[q] >> 5;
-            const int x0 = mis_reflect(sx, a.sw), x1 = mis_reflect(sx + 1, a.sw), y0 = mis_reflect(sy, a.sh), y1 = mis_reflect(sy + 1, a.sh);
-            const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
-            const uint8_t* r0 = a.src + (size_t)y0 * a.sstride;
-            const uint8_t* r1 = a.src + (size_t)y1 * a.sstride;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                p[q][c] = (r0[x0 * 3 + c] * w00 + r0[x1 * 3 + c] * w01 + r1[x0 * 3 + c] * w10 + r1[x1 * 3 + c] * w11 + (1 << 14)) >> 15;
+    for (int i = 0; i < 4; i++, drow += a.dstride, mrow += a.mstride) {
+        if (gy0 + i >= a.dh) break;
+        int p0[3], p1[3];
+        if (staged && interior) {
+            sample1<false>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i], yq[2 * i], p0);
+            sample1<false>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i + 1], yq[2 * i + 1], p1);
+        } else if (staged) {
+            sample1<true>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i], yq[2 * i], p0);
+            sample1<true>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i + 1], yq[2 * i + 1], p1);
+        } else {
+            // box too large for LDS or coordinates far outside the frame: gather from global memory
+            sample1_global(a, xq[2 * i], yq[2 * i], p0);
+            sample1_global(a, xq[2 * i + 1], yq[2 * i + 1], p1);
         }
-    }
-#pragma unroll
-    for (int i = 0; i < FT_H; i++) {
-        const int gy = ty0 + i;
-        if (gy >= a.dh) break;
-        uint8_t* drow = (uint8_t*)a.dst + (size_t)gy * a.dstride + (size_t)gx * 6;
-        uint8_t* mrow = a.mask + (size_t)gy * a.mstride + gx;
         const unsigned m0 = (msk >> (2 * i) & 1) ? 255u : 0u, m1 = (msk >> (2 * i + 1) & 1) ? 255u : 0u;
         if (two) {
             uint3 w;
-            w.x = (unsigned)p[2 * i][0] | ((unsigned)p[2 * i][1] << 16);
-            w.y = (unsigned)p[2 * i][2] | ((unsigned)p[2 * i + 1][0] << 16);
-            w.z = (unsigned)p[2 * i + 1][1] | ((unsigned)p[2 * i + 1][2] << 16);
+            w.x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+            w.y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
+            w.z = (unsigned)p1[1] | ((unsigned)p1[2] << 16);
             *reinterpret_cast<uint3*>(drow) = w;
             *reinterpret_cast<unsigned short*>(mrow) = (unsigned short)(m0 | (m1 << 8));
         } else {
             int16_t* d = reinterpret_cast<int16_t*>(drow);
-            d[0] = (int16_t)p[2 * i][0]; d[1] = (int16_t)p[2 * i][1]; d[2] = (int16_t)p[2 * i][2];
+            d[0] = (int16_t)p0[0]; d[1] = (int16_t)p0[1]; d[2] = (int16_t)p0[2];
             mrow[0] = (uint8_t)m0;
         }
     }
@@ -438,6 +527,15 @@ int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], c
 
 }  // namespace
 
+#ifdef MIS_WARP_STATS
+extern "C" int mis_debug_warp_stats(unsigned* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_warp_stats), sizeof(unsigned) * 8);
+    if (reset) { unsigned z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_warp_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 extern "C" int mis_warp_roi(float scale, int w, int h, const float K[9], const float R[9], MisRect* roi) {
     if (!K || !R || !roi || w < 1 || h < 1 || !(scale > 0.f)) return MIS_E_INVALID;
     Projector p;
@@ -493,14 +591,14 @@ extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, fl
     a.src = (const uint8_t*)din.data; a.sstride = din.stride;
     a.dst = dout.data; a.dstride = dout.stride; a.mask = (uint8_t*)dm.data; a.mstride = dm.stride;
     // separable trig tables live in the context's grow-only scratch
-    const size_t tab_bytes = sizeof(float) * 2 * ((size_t)a.dw + a.dh);
+    const size_t tab_bytes = sizeof(float) * trig_table_floats(a.dw, a.dh);
     if (ctx->stage_bytes < tab_bytes) {
         if (ctx->stage) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
         MIS_HIP(ctx, hipMalloc(&ctx->stage, tab_bytes * 2 + 4096));
         ctx->stage_bytes = tab_bytes * 2 + 4096;
     }
     float* tab = (float*)ctx->stage;
-    hipLaunchKernelGGL(warp_trig_kernel, dim3((a.dw + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
+    hipLaunchKernelGGL(warp_trig_kernel, dim3((trig_cols(a.dw) + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
     dim3 grid((a.dw + FT_W - 1) / FT_W, (a.dh + FT_H - 1) / FT_H), block(64);
     hipLaunchKernelGGL(warp_fused_kernel, grid, block, 0, ctx->stream, a, (const float*)tab);
     MIS_HIP(ctx, hipGetLastError());

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_stitching_amd as isa, synth
 ctx = isa.Context(0)
 cam = synth.workload("config3")[8]
