@@ -15,6 +15,7 @@ struct MisWorkspace {
 
 struct MisContext {
     int device = 0;
+    int num_cu = 256;   // compute units of the device (persistent kernels size their grids from it)
     MisWorkspace* match_ws = nullptr;
     // recycled device blocks (size, pointer): feature sets are allocated and released every frame, and a
     // hipFree would synchronise the whole device each time

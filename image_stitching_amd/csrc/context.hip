@@ -43,6 +43,10 @@ extern "C" int mis_context_create(int device, void* stream, MisContext** out) {
     if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
     MisContext* ctx = new MisContext();
     ctx->device = device;
+    {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->num_cu = cu;
+    }
     // NULL is the device's default (null) stream -- the same stream torch uses unless told otherwise,
     // so library kernels stay ordered with the caller's copies and allocator reuse.
     ctx->stream = (hipStream_t)stream;

@@ -9,6 +9,7 @@
 // into LDS (128 + 16 evaluations per 2048 pixels).
 #include "common.h"
 #include "dev_math.h"
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -338,38 +339,61 @@ __device__ unsigned g_warp_stats[8];   // tiles: interior, folded, global gather
 #else
 #define WSTAT(i)
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
-    const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H;
-    const int lane = threadIdx.x, lx = lane & 15, ly = lane >> 4;
+// Everything a tile needs between its map phase and its sample phase (one lane's share in registers).
+struct TileState {
+    int xq[8], yq[8];   // q = 2 * row + column: 5 fraction bits below the (short-range) integer coordinate
+    unsigned msk;       // bit q: the nearest source pixel of pixel q lies inside the frame
+    int gx, gy0;        // this lane's first column / row
+    bool col_ok, two;
+    // wave-uniform
+    bool interior, staged, wide;
+    int pitch, nrows, lbase;
+    size_t gbase;
+};
+
+// Phase 1 of a tile: backward map of the lane's 2 x 4 pixels, box reduction, classification.
+// The separable trig terms of a lane's 2 columns x 4 rows (prefetched one pipeline stage ahead of the map)
+struct TileTrig {
+    float4 cs;      // {sin u0, cos u0, sin u1, cos u1}
+    float4 rt[4];   // per row {sin v, m1 cos v, m4 cos v, m7 cos v}
+};
+__device__ __forceinline__ void tile_trig(const WarpArgs& a, const float* __restrict__ tab, int tile, int ntx, int lane, TileTrig& g) {
+    const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
+    const int gxr = tx0 + 2 * (lane & 15), gy0 = ty0 + 4 * (lane >> 4);
+    const int gx = gxr < a.dw ? gxr : ((a.dw - 1) & ~1);
+    g.cs = *reinterpret_cast<const float4*>(tab + 2 * gx);
+    const float4* rowtab = reinterpret_cast<const float4*>(tab + 2 * trig_cols(a.dw));
+#pragma unroll
+    for (int i = 0; i < 4; i++) g.rt[i] = rowtab[min(gy0 + i, a.dh - 1)];  // rows past the roi shadow the last one
+}
+
+__device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, int tile, int ntx, int lane, TileState& t) {
+    const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
+    const int lx = lane & 15, ly = lane >> 4;
     const int gxr = tx0 + 2 * lx, gy0 = ty0 + 4 * ly;
-    const bool col_ok = gxr < a.dw, two = gxr + 1 < a.dw;
-    const int gx = col_ok ? gxr : ((a.dw - 1) & ~1);  // out-of-roi lanes shadow the last column pair (never stored)
+    t.col_ok = gxr < a.dw; t.two = gxr + 1 < a.dw;
+    const int gx = t.col_ok ? gxr : ((a.dw - 1) & ~1);  // out-of-roi lanes shadow the last column pair (never stored)
+    t.gx = gx; t.gy0 = gy0;
     const float xhi = (float)a.sw - 0.5f, yhi = (float)a.sh - 0.5f;  // exact: sizes < 2^15
     const bool xe = ((a.sw - 1) & 1) == 0, ye = ((a.sh - 1) & 1) == 0;
     // v < hi || (even && v == hi)  <=>  v < hi2 with hi2 the next float above hi when the end point is included
     const float xhi2 = xe ? __uint_as_float(__float_as_uint(xhi) + 1u) : xhi, yhi2 = ye ? __uint_as_float(__float_as_uint(yhi) + 1u) : yhi;
-    const float4 cs = *reinterpret_cast<const float4*>(tab + 2 * gx);  // {sin, cos} of this lane's two columns
-    const v2f su = {cs.x, cs.z}, cu = {cs.y, cs.w};
-    const float4* rowtab = reinterpret_cast<const float4*>(tab + 2 * trig_cols(a.dw));
-    int xq[8], yq[8];   // q = 2 * row + column: 5 fraction bits below the (short-range) integer coordinate
-    unsigned msk = 0;   // bit q: the nearest source pixel of pixel q lies inside the frame
-    bool bad = !(fabsf(a.m[6]) + fabsf(a.m[7]) + fabsf(a.m[8]) <= 1048576.f);   // |z| <= that sum: no upper check per pixel
+    const v2f su = {g.cs.x, g.cs.z}, cu = {g.cs.y, g.cs.w};
+    int* xq = t.xq; int* yq = t.yq;
+    unsigned msk = 0xffu;
+    // ---- fast map: assumes z >= 2^-30 everywhere in the tile (checked below, wave-uniform) ----
+    float zlo = 3.0e38f;
+    const v2f k32 = {32.f, 32.f}, magic = {12582912.f, 12582912.f};   // 1.5 * 2^23: float add rounds to nearest-even integer
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int gy = min(gy0 + i, a.dh - 1);  // rows past the roi shadow the last one
         v2f xx, yy, zz, qx, qy;
-        map_terms(a.m, su, cu, rowtab[gy], &xx, &yy, &zz);
+        map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
         div2_shared(xx, yy, zz, &qx, &qy);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const bool sel = zz[k] >= 9.31322574615478515625e-10f;   // z >= 2^-30: in front of the camera and safely divisible
-            bad |= (zz[k] > 0) & !sel;
-            const float x = sel ? qx[k] : -1.f, y = sel ? qy[k] : -1.f;
-            xq[2 * i + k] = mis_round_f(x * 32.f);   // v_cvt saturates: out-of-range values show up in the box below
-            yq[2 * i + k] = mis_round_f(y * 32.f);
-            msk |= (unsigned)((x >= -0.5f) & (x < xhi2) & (y >= -0.5f) & (y < yhi2)) << (2 * i + k);
-        }
+        zlo = fminf(fminf(zlo, zz.x), zz.y);
+        // cvRound(32 x) for |32 x| < 2^22; anything larger lands outside +-2^22 as well and is caught by the box check
+        const v2f tx = qx * k32 + magic, ty = qy * k32 + magic;
+        xq[2 * i] = (int)__float_as_uint(tx.x) - 0x4B400000; xq[2 * i + 1] = (int)__float_as_uint(tx.y) - 0x4B400000;
+        yq[2 * i] = (int)__float_as_uint(ty.x) - 0x4B400000; yq[2 * i + 1] = (int)__float_as_uint(ty.y) - 0x4B400000;
     }
     // bounding box of the top-left taps (floor division by 32 is monotonic: reduce the packed values)
     int xmin, xmax, ymin, ymax;
@@ -384,15 +408,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         ymin = wave_min_i32(ymin); ymax = wave_max_i32(ymax);
     };
     reduce_box();
-    if (__any(bad) || xmin <= -(1 << 20) || ymin <= -(1 << 20) || xmax >= (1 << 20) || ymax >= (1 << 20)) {
-        // generic path (cold): IEEE division, x86 cvRound overflow semantics, saturate_cast<short> of the integer part
+    // |z| <= |m6| + |m7| + |m8| bounds z from above (uniform); z from below per lane; coordinates through the box
+    const bool good = (fabsf(a.m[6]) + fabsf(a.m[7]) + fabsf(a.m[8]) <= 1048576.f) && !__any(!(zlo >= 9.31322574615478515625e-10f)) &&
+                      xmin > -(1 << 20) && ymin > -(1 << 20) && xmax < (1 << 20) && ymax < (1 << 20);
+    const bool all_inside = good && xmin >= 0 && ymin >= 0 && (xmax >> 5) + 1 <= a.sw - 1 && (ymax >> 5) + 1 <= a.sh - 1;
+    if (!good) {
+        // generic map (cold): IEEE division, x86 cvRound overflow semantics, saturate_cast<short> of the integer part
         WSTAT(3);
         msk = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int gy = min(gy0 + i, a.dh - 1);
             v2f xx, yy, zz;
-            map_terms(a.m, su, cu, rowtab[gy], &xx, &yy, &zz);
+            map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const bool front = zz[k] > 0;
@@ -404,7 +431,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
         }
         reduce_box();
+    } else if (!all_inside) {
+        // some taps leave the frame: the mask (nearest source pixel inside?) needs the unquantised coordinates again
+        msk = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v2f xx, yy, zz, qx, qy;
+            map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
+            div2_shared(xx, yy, zz, &qx, &qy);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                msk |= (unsigned)((qx[k] >= -0.5f) & (qx[k] < xhi2) & (qy[k] >= -0.5f) & (qy[k] < yhi2)) << (2 * i + k);
+        }
     }
+    t.msk = msk;
     xmin >>= 5; xmax >>= 5; ymin >>= 5; ymax >>= 5;
     // wave-uniform classification; all taps interior <=> 0 <= min and max + 1 <= len - 1
     const bool interior = xmin >= 0 && ymin >= 0 && xmax + 1 <= a.sw - 1 && ymax + 1 <= a.sh - 1;
@@ -432,36 +472,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int nrows = by1 - by0 + 1;
     const size_t total_bytes = (size_t)(a.sh - 1) * a.sstride + (size_t)a.sw * 3;  // last valid byte + 1
     const size_t gbase = (size_t)by0 * a.sstride + (size_t)(bx0 * 3 - shift);
-    const bool staged = (interior || foldable) && (((size_t)a.src | a.sstride) & 3) == 0 && nrows * pitch <= STAGE_BYTES &&
-                        pitch <= (wide ? 1024 : 256) && gbase + (size_t)(nrows - 1) * a.sstride + pitch <= total_bytes;
-    if (staged) {
-        if (wide) stage_box<16>(a.src + gbase, a.sstride, stage, pitch, nrows, lane);
-        else stage_box<4>(a.src + gbase, a.sstride, stage, pitch, nrows, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();  // single-wave workgroup: an LDS fence
-    WSTAT(staged ? (interior ? 0 : 1) : 2);
-    if (!col_ok) return;
-    const int lbase = shift - by0 * pitch - bx0 * 3;  // LDS byte offset of source pixel (0, 0)
-    uint8_t* drow = (uint8_t*)a.dst + (size_t)gy0 * a.dstride + (size_t)gx * 6;
-    uint8_t* mrow = a.mask + (size_t)gy0 * a.mstride + gx;
+    t.interior = interior; t.wide = wide; t.pitch = pitch; t.nrows = nrows; t.gbase = gbase;
+    t.staged = (interior || foldable) && (((size_t)a.src | a.sstride) & 3) == 0 && nrows * pitch <= STAGE_BYTES &&
+               pitch <= (wide ? 1024 : 256) && gbase + (size_t)(nrows - 1) * a.sstride + pitch <= total_bytes;
+    t.lbase = shift - by0 * pitch - bx0 * 3;  // LDS byte offset of source pixel (0, 0)
+    WSTAT(t.staged ? (interior ? 0 : 1) : 2);
+}
+
+// Phase 2: issue the global -> LDS copies of the tile's source box (asynchronous; completion = vmcnt)
+__device__ __forceinline__ void tile_stage(const WarpArgs& a, const TileState& t, uint8_t* stage, int lane) {
+    if (!t.staged) return;
+    if (t.wide) stage_box<16>(a.src + t.gbase, a.sstride, stage, t.pitch, t.nrows, lane);
+    else stage_box<4>(a.src + t.gbase, a.sstride, stage, t.pitch, t.nrows, lane);
+}
+
+// Phase 3: bilinear gather from the staged box and the 16SC3 / mask stores
+__device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileState& t, const uint8_t* stage) {
+    if (!t.col_ok) return;
+    uint8_t* drow = (uint8_t*)a.dst + (size_t)t.gy0 * a.dstride + (size_t)t.gx * 6;
+    uint8_t* mrow = a.mask + (size_t)t.gy0 * a.mstride + t.gx;
 #pragma unroll
     for (int i = 0; i < 4; i++, drow += a.dstride, mrow += a.mstride) {
-        if (gy0 + i >= a.dh) break;
+        if (t.gy0 + i >= a.dh) break;
         int p0[3], p1[3];
-        if (staged && interior) {
-            sample1<false>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i], yq[2 * i], p0);
-            sample1<false>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i + 1], yq[2 * i + 1], p1);
-        } else if (staged) {
-            sample1<true>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i], yq[2 * i], p0);
-            sample1<true>(stage, lbase, pitch, a.sw, a.sh, xq[2 * i + 1], yq[2 * i + 1], p1);
+        if (t.staged && t.interior) {
+            sample1<false>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i], t.yq[2 * i], p0);
+            sample1<false>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i + 1], t.yq[2 * i + 1], p1);
+        } else if (t.staged) {
+            sample1<true>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i], t.yq[2 * i], p0);
+            sample1<true>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i + 1], t.yq[2 * i + 1], p1);
         } else {
             // box too large for LDS or coordinates far outside the frame: gather from global memory
-            sample1_global(a, xq[2 * i], yq[2 * i], p0);
-            sample1_global(a, xq[2 * i + 1], yq[2 * i + 1], p1);
+            sample1_global(a, t.xq[2 * i], t.yq[2 * i], p0);
+            sample1_global(a, t.xq[2 * i + 1], t.yq[2 * i + 1], p1);
         }
-        const unsigned m0 = (msk >> (2 * i) & 1) ? 255u : 0u, m1 = (msk >> (2 * i + 1) & 1) ? 255u : 0u;
-        if (two) {
+        const unsigned m0 = (t.msk >> (2 * i) & 1) ? 255u : 0u, m1 = (t.msk >> (2 * i + 1) & 1) ? 255u : 0u;
+        if (t.two) {
             uint3 w;
             w.x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
             w.y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
@@ -474,6 +520,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             mrow[0] = (uint8_t)m0;
         }
     }
+}
+
+#ifdef WV_STAMPS
+__device__ unsigned long long g_warp_stamps[16384 * 8];
+#endif
+// One tile per wave, TILE_WAVES independent waves per workgroup (no barriers; fewer, larger workgroups to dispatch).
+#ifndef WV_TILE_WAVES
+#define WV_TILE_WAVES 2
+#endif
+constexpr int TILE_WAVES = WV_TILE_WAVES;
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
+    const int ntx = (a.dw + FT_W - 1) / FT_W, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t* stage = stage_all[wave];
+    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2, so XCD j
+    // takes the j-th contiguous eighth of the raster-ordered tiles: neighbouring tiles, which share source rows and
+    // the 16-byte pieces at their box edges, hit the same L2 (PMC: L2 -> fabric fetch 64 MB -> 26 MB per 4K frame,
+    // = the frame itself; ~1 % slower than plain raster order, whose re-fetches are served by the Infinity Cache).
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int wg = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3);
+    const int tile = wg * TILE_WAVES + wave;
+    if (tile >= ntiles) return;
+    TileState cur;
+    TileTrig trig;
+#ifdef WV_STAMPS   // diagnostics build (tools/warp_stamps.py): per-wave phase time stamps, shader clock and wall clock
+    const unsigned long long r0 = wall_clock64(), s0 = __builtin_readcyclecounter();
+    tile_trig(a, tab, tile, ntx, lane, trig);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long s1 = __builtin_readcyclecounter();
+    tile_map(a, trig, tile, ntx, lane, cur);
+    const unsigned long long s2 = __builtin_readcyclecounter();
+    tile_stage(a, cur, stage, lane);
+    const unsigned long long s3 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const unsigned long long s4 = __builtin_readcyclecounter();
+    tile_sample_store(a, cur, stage);
+    const unsigned long long s5 = __builtin_readcyclecounter();
+    if (lane == 0 && tile < 16384) {
+        unsigned long long* o = g_warp_stamps + 8 * tile;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = r0; o[7] = wall_clock64();
+    }
+#else
+    tile_trig(a, tab, tile, ntx, lane, trig);
+    tile_map(a, trig, tile, ntx, lane, cur);
+    tile_stage(a, cur, stage, lane);                       // asynchronous global -> LDS copies ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    tile_sample_store(a, cur, stage);
+#endif
 }
 
 // General warp (seam-scale path and plain masks): u8 with CN channels, one column per lane.
@@ -534,6 +630,16 @@ extern "C" int mis_debug_warp_stats(unsigned* out, int reset) {
     if (reset) { unsigned z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_warp_stats), z, sizeof(z)); }
     return 0;
 }
+    return 0;
+}
+#endif
+
+#ifdef WV_STAMPS
+extern "C" int mis_debug_warp_stamps(unsigned long long* out, int n) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_warp_stamps), sizeof(unsigned long long) * 8 * n);
+    return 0;
+}
 #endif
 
 extern "C" int mis_warp_roi(float scale, int w, int h, const float K[9], const float R[9], MisRect* roi) {
@@ -574,8 +680,8 @@ extern "C" int mis_warp_spherical(MisContext* ctx, const MisImage* src, float sc
     return MIS_OK;
 }
 
-extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
-                                        MisImage* dst, MisImage* dmask, MisPoint* tl) {
+static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
+                           MisImage* dst, MisImage* dmask, MisPoint* tl, int repeats, float* avg_us) {
     if (!ctx) return MIS_E_INVALID;
     WarpArgs a;
     int brx, bry, rc;
@@ -599,12 +705,39 @@ extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, fl
     }
     float* tab = (float*)ctx->stage;
     hipLaunchKernelGGL(warp_trig_kernel, dim3((trig_cols(a.dw) + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
-    dim3 grid((a.dw + FT_W - 1) / FT_W, (a.dh + FT_H - 1) / FT_H), block(64);
-    hipLaunchKernelGGL(warp_fused_kernel, grid, block, 0, ctx->stream, a, (const float*)tab);
+    const int ntiles = ((a.dw + FT_W - 1) / FT_W) * ((a.dh + FT_H - 1) / FT_H);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (avg_us) {
+        MIS_HIP(ctx, hipEventCreate(&e0));
+        MIS_HIP(ctx, hipEventCreate(&e1));
+        MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    for (int rep = 0; rep < repeats; rep++)
+        hipLaunchKernelGGL(warp_fused_kernel, dim3((ntiles + TILE_WAVES - 1) / TILE_WAVES), dim3(64 * TILE_WAVES), 0, ctx->stream, a, (const float*)tab, ntiles);
+    if (avg_us) {
+        float ms = 0.f;
+        MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        MIS_HIP(ctx, hipEventSynchronize(e1));
+        MIS_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = ms * 1000.f / (float)repeats;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
     MIS_HIP(ctx, hipGetLastError());
     if ((rc = mis_dev_image_commit(ctx, dst, &dout)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_commit(ctx, dmask, &dm)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_release(ctx, &din)) != MIS_OK) return rc;
     if (tl) { tl->x = a.tlx; tl->y = a.tly; }
     return MIS_OK;
+}
+
+extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
+                                        MisImage* dst, MisImage* dmask, MisPoint* tl) {
+    return warp_fused_impl(ctx, src, scale, K, R, dst, dmask, tl, 1, nullptr);
+}
+
+extern "C" int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
+                                              MisImage* dst, MisImage* dmask, MisPoint* tl, int repeats, float* avg_us) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, repeats >= 1 && avg_us, MIS_E_INVALID, "repeats must be >= 1 and avg_us non-null");
+    return warp_fused_impl(ctx, src, scale, K, R, dst, dmask, tl, repeats, avg_us);
 }

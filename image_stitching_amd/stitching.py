@@ -167,6 +167,16 @@ class SphericalWarper:
                                                              C.byref(mimg), C.byref(tl)))
         return (tl.x, tl.y)
 
+    def warp_fused_timed(self, src_bgr, K, R, roi, dst, msk, repeats):
+        """Average duration (us) of the fused warp kernel over `repeats` back-to-back launches (HIP events)."""
+        simg, dimg, mimg = as_image(src_bgr), as_image(dst), as_image(msk)
+        ka, kp = _mat9(K)
+        ra, rp = _mat9(R)
+        tl, us = capi.MisPoint(), C.c_float()
+        self.ctx.check(self.ctx.lib.mis_warp_spherical_fused_timed(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(dimg),
+                                                                   C.byref(mimg), C.byref(tl), int(repeats), C.byref(us)))
+        return float(us.value)
+
     def warp_fused(self, src_bgr, K, R, roi=None):
         """Compose-scale step of main(): warp(img, LINEAR, REFLECT) + warp(mask, NEAREST, CONSTANT) +
         convertTo(CV_16S) (image_stitching.cpp:1154-1164) -> (tl, img_warped_s, mask_warped)."""

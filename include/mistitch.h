@@ -163,6 +163,10 @@ int mis_warp_spherical(MisContext* ctx, const MisImage* src, float scale, const 
  * (NEAREST, CONSTANT of an all-255 mask) in one pass -- replaces :1154 + :1157-1159 + :1164. */
 int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
                              MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl);
+/* measurement aid: the same warp with the main kernel launched `repeats` times back to back on the context's
+ * stream between two HIP events; *avg_us = average kernel duration (bench.py's roofline leg: no host gaps). */
+int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
+                                   MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl, int repeats, float* avg_us);
 
 /* ---------------------------------------------------------------- blend --------------------- */
 /* reference-side blender sizing, image_stitching.cpp:1176-1190: returns the blend type to use in

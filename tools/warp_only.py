@@ -16,4 +16,6 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(n): w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
 e1.record(); torch.cuda.synchronize()
-print("roi", roi, "avg us", e0.elapsed_time(e1) / n * 1e3)
+print("roi", roi, "avg us (host-paced launches)", e0.elapsed_time(e1) / n * 1e3)
+for _ in range(3):
+    print("back-to-back kernel avg us", w.warp_fused_timed(frame, cam["K"], cam["R"], roi, dst, msk, 200))
