@@ -99,6 +99,9 @@ PROTOTYPES = {
     "mis_warp_roi": (_i, [_f, _i, _i, _vp, _vp, _P(MisRect)]),
     "mis_warp_spherical": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _i, _i, _P(MisImage), _P(MisPoint)]),
     "mis_warp_spherical_fused": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint)]),
+    "mis_resize_linear_exact": (_i, [_vp, _P(MisImage), _i, _i, C.c_double, C.c_double, _P(MisImage)]),
+    "mis_rotate": (_i, [_vp, _P(MisImage), _i, _P(MisImage)]),
+    "mis_seam_mask_apply": (_i, [_vp, _P(MisImage), _P(MisImage)]),
     "mis_warp_spherical_fused_timed": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint), _i, _P(C.c_float)]),
     "mis_blend_config": (_i, [_i, _f, _i, _i, _P(_i), _P(_i), _P(_f)]),
     "mis_result_roi": (_i, [_P(MisPoint), _P(MisSize), _i, _P(MisRect)]),

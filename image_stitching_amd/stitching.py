@@ -189,6 +189,42 @@ class SphericalWarper:
 
 
 # ------------------------------------------------------------------------------------------------
+# image operators either side of the path (image_stitching.cpp:571-580, :619, :1144, :1169-1171)
+ROTATE_90_CLOCKWISE, ROTATE_180, ROTATE_90_COUNTERCLOCKWISE = 0, 1, 2
+
+
+def resize(ctx, src, dsize=None, fx=0.0, fy=0.0):
+    """cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR_EXACT) on the device (8UC1 / 8UC3)."""
+    simg = as_image(src)
+    if dsize:
+        dw, dh = int(dsize[0]), int(dsize[1])
+    else:
+        dw, dh = int(np.rint(simg.width * fx)), int(np.rint(simg.height * fy))   # cvRound: half to even
+    dst = _empty_image(ctx, dh, dw, simg.channels, torch.uint8)
+    dimg = as_image(dst)
+    ctx.check(ctx.lib.mis_resize_linear_exact(ctx.h, C.byref(simg), dw if dsize else 0, dh if dsize else 0, float(fx), float(fy), C.byref(dimg)))
+    return dst
+
+
+def rotate(ctx, src, code):
+    """cv::rotate(src, dst, code) on the device (8UC1 / 8UC3)."""
+    simg = as_image(src)
+    dw, dh = (simg.width, simg.height) if code == ROTATE_180 else (simg.height, simg.width)
+    dst = _empty_image(ctx, dh, dw, simg.channels, torch.uint8)
+    dimg = as_image(dst)
+    ctx.check(ctx.lib.mis_rotate(ctx.h, C.byref(simg), int(code), C.byref(dimg)))
+    return dst
+
+
+def seam_mask_apply(ctx, seam_mask_warped, mask_warped):
+    """mask_warped &= resize(dilate(seam_mask_warped), mask_warped.size(), INTER_LINEAR_EXACT), in place
+    (image_stitching.cpp:1169-1171)."""
+    simg, mimg = as_image(seam_mask_warped), as_image(mask_warped)
+    ctx.check(ctx.lib.mis_seam_mask_apply(ctx.h, C.byref(simg), C.byref(mimg)))
+    return mask_warped
+
+
+# ------------------------------------------------------------------------------------------------
 # blend: cv::detail::Blender / MultiBandBlender / FeatherBlender (image_stitching.cpp:1173-1225)
 def result_roi(corners, sizes):
     lib = capi.load()

@@ -168,6 +168,18 @@ int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float sca
 int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
                                    MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl, int repeats, float* avg_us);
 
+/* ---------------------------------------------------------------- image operators ----------- */
+/* cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR_EXACT) -- replaces image_stitching.cpp:580 (work scale), :619 (seam
+ * scale), :1144 (compose scale).  8UC1 / 8UC3.  dst_w, dst_h > 0: that size (scale = dsize / ssize); otherwise
+ * dsize = (cvRound(w * fx), cvRound(h * fy)) and the coordinate scale is exactly 1/fx, 1/fy, as in resize(). */
+int mis_resize_linear_exact(MisContext* ctx, const MisImage* src, int dst_w, int dst_h, double fx, double fy, MisImage* dst);
+/* cv::rotate(src, dst, code) -- replaces image_stitching.cpp:571 (ROTATE_90_CLOCKWISE = 0), :576 (ROTATE_180 = 1);
+ * 2 = ROTATE_90_COUNTERCLOCKWISE.  8UC1 / 8UC3. */
+int mis_rotate(MisContext* ctx, const MisImage* src, int rotate_code, MisImage* dst);
+/* dilate(masks_warped[i], 3x3) -> resize(to mask_warped.size(), INTER_LINEAR_EXACT) -> mask_warped &= ... in one
+ * pass -- replaces image_stitching.cpp:1169-1171.  Both 8UC1; mask_warped is updated in place. */
+int mis_seam_mask_apply(MisContext* ctx, const MisImage* seam_mask_warped, MisImage* mask_warped);
+
 /* ---------------------------------------------------------------- blend --------------------- */
 /* reference-side blender sizing, image_stitching.cpp:1176-1190: returns the blend type to use in
  * *type_out and fills num_bands (MULTI_BAND) or sharpness (FEATHER) */

@@ -594,3 +594,49 @@ def camera_rehand(R, is_portrait=False):
     o = np.zeros(9)
     lib().mo_camera_rehand_d(_p(R), int(is_portrait), _p(o))
     return o.reshape(3, 3)
+
+
+# ---- image operators (mo_imgops.c) -------------------------------------------------------------
+def resize_exact(src, dsize=None, fx=0.0, fy=0.0):
+    """cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR_EXACT), u8 with 1 or 3 channels."""
+    L = lib()
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = C.c_int(), C.c_int()
+    L.mo_resize_dsize(sw, sh, int(dsize[0]) if dsize else 0, int(dsize[1]) if dsize else 0, C.c_double(fx), C.c_double(fy), C.byref(dw), C.byref(dh))
+    dst = np.zeros((dh.value, dw.value) if cn == 1 else (dh.value, dw.value, cn), np.uint8)
+    L.mo_resize_linear_exact_u8_ex(src.ctypes.data_as(C.c_void_p), sw, sh, C.c_size_t(sw * cn), cn, dst.ctypes.data_as(C.c_void_p), dw.value, dh.value,
+                                   C.c_size_t(dw.value * cn), C.c_double(fx), C.c_double(fy), 0 if dsize else 1)
+    return dst
+
+
+def rotate(src, code):
+    L = lib()
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = (sw, sh) if code == 1 else (sh, sw)
+    dst = np.zeros((dh, dw) if cn == 1 else (dh, dw, cn), np.uint8)
+    L.mo_rotate_u8(src.ctypes.data_as(C.c_void_p), sw, sh, C.c_size_t(sw * cn), cn, int(code), dst.ctypes.data_as(C.c_void_p), C.c_size_t(dw * cn))
+    return dst
+
+
+def dilate3x3(src):
+    L = lib()
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.zeros_like(src)
+    L.mo_dilate3x3_u8(src.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), dst.ctypes.data_as(C.c_void_p), C.c_size_t(w))
+    return dst
+
+
+def seam_mask_apply(seam, mask):
+    """returns resize(dilate(seam), mask.shape, INTER_LINEAR_EXACT) & mask"""
+    L = lib()
+    seam = np.ascontiguousarray(seam, np.uint8)
+    out = np.ascontiguousarray(mask, np.uint8).copy()
+    sh, sw = seam.shape
+    mh, mw = out.shape
+    L.mo_seam_mask_apply(seam.ctypes.data_as(C.c_void_p), sw, sh, C.c_size_t(sw), out.ctypes.data_as(C.c_void_p), mw, mh, C.c_size_t(mw))
+    return out

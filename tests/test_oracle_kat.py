@@ -259,3 +259,47 @@ def test_blend_config_reference_sizing(oracle_mod):
     t, nb, sh = o.blend_config(o.BLEND_FEATHER, 5.0, 1000, 1000)
     assert t == o.BLEND_FEATHER and abs(sh - 1 / 50.0) < 1e-7
     assert o.blend_config(o.BLEND_MULTI_BAND, 5.0, 10, 10)[0] == o.BLEND_NO
+
+
+# ---- image operators (mo_imgops.c): closed-form known answers ---------------------------------
+def test_resize_exact_known_answers(oracle_mod):
+    o = oracle_mod
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)
+    # identity scale reproduces the image; a constant image stays constant for any scale
+    assert np.array_equal(o.resize_exact(img, fx=1.0, fy=1.0), img)
+    c = np.full((9, 14), 173, np.uint8)
+    assert np.all(o.resize_exact(c, fx=0.37, fy=0.61) == 173)
+    assert np.all(o.resize_exact(c, dsize=(31, 17)) == 173)
+    # exact 2x decimation: destination i samples 2i + 0.5 -> mean of two neighbours (weights 128/128), rounded half up
+    a = np.arange(16, dtype=np.uint8).reshape(1, 16) * 10
+    a = np.repeat(a, 2, 0)
+    r = o.resize_exact(a, fx=0.5, fy=0.5)
+    assert r.shape == (1, 8) and list(r[0]) == [5, 25, 45, 65, 85, 105, 125, 145]
+    # dsize by factor rounds half to even (cvRound): 5 * 0.5 = 2.5 -> 2, 7 * 0.5 = 3.5 -> 4
+    assert o.resize_exact(np.zeros((5, 7), np.uint8), fx=0.5, fy=0.5).shape == (2, 4)
+
+
+def test_rotate_dilate_and_seam_mask_known_answers(oracle_mod):
+    o = oracle_mod
+    a = np.arange(6, dtype=np.uint8).reshape(2, 3)
+    assert o.rotate(a, 0).tolist() == [[3, 0], [4, 1], [5, 2]]          # 90 clockwise
+    assert o.rotate(a, 1).tolist() == [[5, 4, 3], [2, 1, 0]]            # 180
+    assert o.rotate(a, 2).tolist() == [[2, 5], [1, 4], [0, 3]]          # 90 counter-clockwise
+    rgb = np.arange(24, dtype=np.uint8).reshape(2, 4, 3)
+    assert np.array_equal(o.rotate(o.rotate(rgb, 0), 2), rgb) and np.array_equal(o.rotate(o.rotate(rgb, 1), 1), rgb)
+    m = np.zeros((5, 5), np.uint8)
+    m[2, 2] = 255
+    d = o.dilate3x3(m)
+    assert d[1:4, 1:4].min() == 255 and d.sum() == 9 * 255
+    m[0, 0] = 200                                                       # the border contributes nothing
+    assert o.dilate3x3(m)[0:2, 0:2].min() == 200
+    # seam mask: all-255 seam leaves the mask untouched, all-zero seam clears it
+    mask = np.full((40, 60), 255, np.uint8)
+    mask[:, :7] = 0
+    assert np.array_equal(o.seam_mask_apply(np.full((10, 15), 255, np.uint8), mask), mask)
+    assert o.seam_mask_apply(np.zeros((10, 15), np.uint8), mask).max() == 0
+    # a one-pixel hole in the seam mask is closed by the dilation
+    seam = np.full((10, 15), 255, np.uint8)
+    seam[5, 7] = 0
+    assert np.array_equal(o.seam_mask_apply(seam, mask), mask)
