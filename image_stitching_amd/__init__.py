@@ -11,12 +11,12 @@ from . import _capi
 from ._capi import (BLEND_FEATHER, BLEND_MULTI_BAND, BLEND_NO, BORDER_CONSTANT, BORDER_REFLECT, INTER_LINEAR,
                     INTER_NEAREST)
 from .stitching import (BestOf2NearestMatcher, Blender, Context, FeatherBlender, ImageFeatures, MatchesInfo,
-                        MisError, MultiBandBlender, OrbFeatureFinder, SphericalWarper, StitchConfig, Stitcher,
+                        MisError, MultiBandBlender, OrbFeatureFinder, SiftFeatureFinder, SphericalWarper, StitchConfig, Stitcher,
                         blend_config, computeImageFeatures, find_homography, leaveBiggestComponent, resize, result_roi,
                         rotate, seam_mask_apply, warp_roi)
 
 __all__ = [
-    "Context", "MisError", "SphericalWarper", "Blender", "MultiBandBlender", "FeatherBlender", "OrbFeatureFinder",
+    "Context", "MisError", "SphericalWarper", "Blender", "MultiBandBlender", "FeatherBlender", "OrbFeatureFinder", "SiftFeatureFinder",
     "computeImageFeatures", "ImageFeatures", "BestOf2NearestMatcher", "MatchesInfo", "leaveBiggestComponent",
     "find_homography", "warp_roi", "result_roi", "blend_config", "StitchConfig", "Stitcher", "resize", "rotate",
     "seam_mask_apply",

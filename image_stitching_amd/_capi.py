@@ -48,6 +48,11 @@ class MisOrbParams(C.Structure):
                 ("score_type", C.c_int), ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
 
 
+class MisSiftParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("n_octave_layers", C.c_int), ("contrast_threshold", C.c_double),
+                ("edge_threshold", C.c_double), ("sigma", C.c_double)]
+
+
 class MisFeatures(C.Structure):
     _fields_ = [("img_idx", C.c_int), ("img_w", C.c_int), ("img_h", C.c_int), ("n", C.c_int),
                 ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("desc_cols", C.c_int),
@@ -89,6 +94,11 @@ PROTOTYPES = {
     "mis_features_upload": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _P(MisFeatures)]),
     "mis_features_free": (_i, [_vp, _P(MisFeatures)]),
     "mis_orb_debug_level": (_i, [_vp, _i, _i, _vp, _P(_i), _P(_i)]),
+    "mis_sift_default_params": (None, [_P(MisSiftParams)]),
+    "mis_sift_create": (_i, [_vp, _P(MisSiftParams), _i, _i, _P(_vp)]),
+    "mis_sift_destroy": (_i, [_vp]),
+    "mis_sift_detect": (_i, [_vp, _P(MisImage), _P(MisFeatures)]),
+    "mis_sift_debug_level": (_i, [_vp, _P(MisImage), _i, _i, _i, _vp, _P(_i), _P(_i)]),
     "mis_match_default_params": (None, [_P(MisMatchParams)]),
     "mis_match_all_pairs": (_i, [_vp, _P(MisFeatures), _i, _P(MisMatchParams), _P(MisMatchesInfo)]),
     "mis_match_pairs_sharded": (_i, [_vp, _P(MisFeatures), _i, _P(MisMatchParams), _i, _i, _P(MisMatchesInfo)]),

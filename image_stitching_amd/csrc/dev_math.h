@@ -164,6 +164,28 @@ MIS_HD float mis_fast_atan2(float y, float x) {
     return a;
 }
 
+// Cephes expf with the final scaling by exact power-of-two products (the SIFT weights; same code as the oracle's mo_expf)
+MIS_HD float mis_expf(float xx) {
+    float x = xx, z;
+    if (x > 88.72283905206835f) return INFINITY;
+    if (x < -103.278929903431851103f) return 0.f;
+    z = floorf(1.44269504088896341f * x + 0.5f);
+    x -= z * 0.693359375f;
+    x -= z * -2.12194440e-4f;
+    const int n = (int)z;
+    z = x * x;
+    z = (((((1.9875691500E-4f * x + 1.3981999507E-3f) * x + 8.3334519073E-3f) * x + 4.1665795894E-2f) * x + 1.6666665459E-1f) * x + 5.0000001201E-1f) * z + x + 1.0f;
+    union { uint32_t u; float f; } a, b;
+    if (n < -126) {
+        a.u = (uint32_t)1 << 23;  // 2^-126
+        b.u = (uint32_t)(n + 126 + 127) << 23;
+        return (z * b.f) * a.f;
+    }
+    a.u = (uint32_t)(n + 127) << 23;
+    return z * a.f;
+}
+MIS_HD int mis_floor_f(float v) { int i = (int)v; return i - ((float)i > v); }
+
 // natural log in f64 from + * / and exponent extraction (RANSAC iteration-count update)
 MIS_HD double mis_log_d(double x) {
     union { double d; uint64_t u; } v;

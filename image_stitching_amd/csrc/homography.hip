@@ -27,7 +27,7 @@ namespace {
 
 constexpr int HYP_TPB = 128;      // hypotheses (threads) per workgroup of hyp_kernel
 constexpr int SLOT_DOUBLES = 126; // 36 (strict upper triangle) + 9 (diagonal / eigenvalues) + 81 (eigenvectors)
-constexpr int PHASE0 = 128;       // hypotheses evaluated before the first replay
+constexpr int PHASE0 = 128;       // hypotheses evaluated before the first replay (a single phase over all 2000 was measured: 26 ms instead of 15 ms per step)
 constexpr int RNG_TABLE = 1 << 17;
 constexpr int TB = 256;           // threads of draw / scan_tail workgroups
 

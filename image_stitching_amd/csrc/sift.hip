@@ -1,0 +1,568 @@
+// sift.hip -- cv::SIFT::create()->detectAndCompute on the GPU (config 5 of BASELINE.json).
+// Reference call sites: image_stitching/image_stitching.cpp:559 (`SIFT::create()` when features_type == "sift"),
+// :613 (`computeImageFeatures`).  OpenCV source restated: features2d sift.dispatch.cpp / sift.simd.hpp (4.5+, float
+// scale space), imgproc GaussianBlur / resize -- see oracle/mo_sift.h for the restatement choices.
+//
+// Stages (all float arithmetic is IEEE + - * / sqrt in the CPU path's order, no FMA contraction):
+//   gray (Q14) -> 2x bilinear upsample -> Gaussian pyramid (separable blur, nearest 2:1 decimation between
+//   octaves) -> DoG -> 26-neighbour extrema (candidates appended through a counter) -> per candidate: 3-D quadratic
+//   refinement, contrast / edge tests, 36-bin orientation histogram (sequential sums: order matters in float) ->
+//   keypoints -> canonical order of KeyPointsFilter::removeDuplicatedSorted + duplicate removal (a total order, so
+//   the append order of the atomics never shows) -> 4x4x8 descriptor per keypoint.
+// The sort / duplicate removal of the (tens of thousands of) keypoints runs on the host inside this library between
+// the two device phases; everything that touches pixels runs on the device.
+#include "common.h"
+#include "dev_math.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int SIFT_IMG_BORDER = 5, SIFT_MAX_INTERP_STEPS = 5, SIFT_ORI_HIST_BINS = 36;
+constexpr float SIFT_INIT_SIGMA = 0.5f, SIFT_ORI_SIG_FCTR = 1.5f, SIFT_ORI_RADIUS = 3 * 1.5f, SIFT_ORI_PEAK_RATIO = 0.8f;
+constexpr float SIFT_DESCR_SCL_FCTR = 3.f, SIFT_DESCR_MAG_THR = 0.2f, SIFT_INT_DESCR_FCTR = 512.f;
+constexpr int MAX_OCT = 16, MAX_LAYERS = 8, MAX_TAPS = 64;
+
+struct Taps {
+    int n;
+    float k[MAX_TAPS];
+};
+
+// GaussianBlur: ksize from sigma for float images; getGaussianKernel in double, normalised, stored as float
+Taps gaussian_taps(double sigma) {
+    Taps t;
+    int n = mis_round_d(sigma * 8 + 1) | 1;
+    if (n > MAX_TAPS - 1) n = MAX_TAPS - 1;
+    double v[MAX_TAPS], sum = 0, scale2x = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        v[i] = exp(scale2x * x * x);
+        sum += v[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) t.k[i] = (float)(v[i] * sum);
+    t.n = n;
+    return t;
+}
+
+struct Pyr {   // device-visible description of the scale space of the current image
+    int noct, nl;
+    int w[MAX_OCT], h[MAX_OCT];
+    float* gauss[MAX_OCT * (MAX_LAYERS + 3)];
+    float* dog[MAX_OCT * (MAX_LAYERS + 2)];
+};
+
+__global__ __launch_bounds__(256) void sift_gray_kernel(const uint8_t* __restrict__ bgr, size_t stride, int w, int h, uint8_t* __restrict__ gray) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
+    gray[(size_t)y * w + x] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+}
+
+// resize(float, 2x, INTER_LINEAR): source coordinate (d + 0.5) * 0.5 - 0.5, taps clamped, horizontal then vertical
+__global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t* __restrict__ g, int w, int h, float* __restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, dw = 2 * w;
+    if (x >= dw) return;
+    float fy = (float)((y + 0.5) * 0.5 - 0.5);
+    int sy = mis_floor_f(fy);
+    fy -= sy;
+    if (sy < 0) { sy = 0; fy = 0; }
+    if (sy >= h - 1) { sy = h - 1; fy = 0; }
+    const int sy1 = sy + 1 < h ? sy + 1 : sy;
+    float fx = (float)((x + 0.5) * 0.5 - 0.5);
+    int sx = mis_floor_f(fx);
+    fx -= sx;
+    if (sx < 0) { sx = 0; fx = 0; }
+    if (sx >= w - 1) { sx = w - 1; fx = 0; }
+    const int sx1 = sx + 1 < w ? sx + 1 : sx;
+    const uint8_t *r0 = g + (size_t)sy * w, *r1 = g + (size_t)sy1 * w;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float h0 = (float)r0[sx] * a0 + (float)r0[sx1] * a1;
+    const float h1 = (float)r1[sx] * a0 + (float)r1[sx1] * a1;
+    dst[(size_t)y * dw + x] = h0 * b0 + h1 * b1;
+}
+
+// separable Gaussian, BORDER_REFLECT_101, taps accumulated in ascending order
+template <bool COLS>
+__global__ __launch_bounds__(256) void sift_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Taps t) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int r = t.n / 2;
+    float acc = 0;
+    if (!COLS) {
+        const float* row = src + (size_t)y * w;
+        if (x >= r && x + r < w) for (int k = 0; k < t.n; k++) acc += t.k[k] * row[x + k - r];
+        else for (int k = 0; k < t.n; k++) acc += t.k[k] * row[mis_reflect101(x + k - r, w)];
+    } else {
+        if (y >= r && y + r < h) for (int k = 0; k < t.n; k++) acc += t.k[k] * src[(size_t)(y + k - r) * w + x];
+        else for (int k = 0; k < t.n; k++) acc += t.k[k] * src[(size_t)mis_reflect101(y + k - r, h) * w + x];
+    }
+    dst[(size_t)y * w + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sift_sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = b[i] - a[i];
+}
+
+__global__ __launch_bounds__(256) void sift_decimate_kernel(const float* __restrict__ src, int sw, int sh, float* __restrict__ dst, int w, int h) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int sy = y * 2 < sh ? y * 2 : sh - 1, sx = x * 2 < sw ? x * 2 : sw - 1;
+    dst[(size_t)y * w + x] = src[(size_t)sy * sw + sx];
+}
+
+#define AT(img, r, c) ((img)[(size_t)(r) * w + (c)])
+
+// findScaleSpaceExtrema, the scan: layer = blockIdx.z + 1
+__global__ __launch_bounds__(256) void sift_extrema_kernel(Pyr P, int o, int threshold, int4* __restrict__ cand, unsigned* __restrict__ n_cand, unsigned cap) {
+    const int w = P.w[o], h = P.h[o], nl = P.nl;
+    const int c = blockIdx.x * 256 + threadIdx.x + SIFT_IMG_BORDER, r = blockIdx.y + SIFT_IMG_BORDER, layer = blockIdx.z + 1;
+    if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
+    const float* img = P.dog[o * (nl + 2) + layer];
+    const float* prev = P.dog[o * (nl + 2) + layer - 1];
+    const float* next = P.dog[o * (nl + 2) + layer + 1];
+    const float val = AT(img, r, c);
+    if (!(fabsf(val) > (float)threshold)) return;
+    bool ext = true;
+    if (val > 0) {
+        for (int dr = -1; dr <= 1; dr++)
+            for (int dc = -1; dc <= 1; dc++)
+                ext = ext && val >= AT(img, r + dr, c + dc) && val >= AT(prev, r + dr, c + dc) && val >= AT(next, r + dr, c + dc);
+    } else {
+        for (int dr = -1; dr <= 1; dr++)
+            for (int dc = -1; dc <= 1; dc++)
+                ext = ext && val <= AT(img, r + dr, c + dc) && val <= AT(prev, r + dr, c + dc) && val <= AT(next, r + dr, c + dc);
+    }
+    if (!ext) return;
+    const unsigned slot = atomicAdd(n_cand, 1u);
+    if (slot < cap) cand[slot] = make_int4(o, layer, r, c);
+}
+
+// Matx33f::solve(DECOMP_LU): closed form through the determinant
+__device__ __forceinline__ bool solve3(const float* a, const float* b, float* x) {
+    float d = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    if (d == 0) return false;
+    d = 1 / d;
+    x[0] = d * (b[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (b[1] * a[8] - a[5] * b[2]) + a[2] * (b[1] * a[7] - a[4] * b[2]));
+    x[1] = d * (a[0] * (b[1] * a[8] - a[5] * b[2]) - b[0] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * b[2] - b[1] * a[6]));
+    x[2] = d * (a[0] * (a[4] * b[2] - b[1] * a[7]) - a[1] * (a[3] * b[2] - b[1] * a[6]) + b[0] * (a[3] * a[7] - a[4] * a[6]));
+    return true;
+}
+
+struct SiftConsts {
+    float contrast_threshold, edge_threshold, sigma;
+};
+
+// adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one thread per candidate
+__global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, const int4* __restrict__ cand, const unsigned* __restrict__ n_cand, unsigned cand_cap,
+                                                        MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
+    const unsigned q = blockIdx.x * 64 + threadIdx.x;
+    const unsigned nc = min(*n_cand, cand_cap);
+    if (q >= nc) return;
+    const int4 cd = cand[q];
+    const int octv = cd.x, nl = P.nl, w = P.w[octv], h = P.h[octv];
+    int layer = cd.y, r = cd.z, c = cd.w;
+    const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0, contr = 0;
+    int i = 0;
+    for (; i < SIFT_MAX_INTERP_STEPS; i++) {
+        const float* img = P.dog[octv * (nl + 2) + layer];
+        const float* prev = P.dog[octv * (nl + 2) + layer - 1];
+        const float* next = P.dog[octv * (nl + 2) + layer + 1];
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
+        const float v2 = AT(img, r, c) * 2;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
+        const float dss = (AT(next, r, c) + AT(prev, r, c) - v2) * second_deriv_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
+        const float dxs = (AT(next, r, c + 1) - AT(next, r, c - 1) - AT(prev, r, c + 1) + AT(prev, r, c - 1)) * cross_deriv_scale;
+        const float dys = (AT(next, r + 1, c) - AT(next, r - 1, c) - AT(prev, r + 1, c) + AT(prev, r - 1, c)) * cross_deriv_scale;
+        const float H[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
+        float X[3] = {0, 0, 0};
+        solve3(H, dD, X);
+        xi = -X[2]; xr = -X[1]; xc = -X[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return;
+        c += mis_round_f(xc); r += mis_round_f(xr); layer += mis_round_f(xi);
+        if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= w - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
+    }
+    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    {
+        const float* img = P.dog[octv * (nl + 2) + layer];
+        const float* prev = P.dog[octv * (nl + 2) + layer - 1];
+        const float* next = P.dog[octv * (nl + 2) + layer + 1];
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale, (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
+        const float t = (dD[0] * xc + dD[1] * xr) + dD[2] * xi;
+        contr = AT(img, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * nl < K.contrast_threshold) return;
+        const float v2 = AT(img, r, c) * 2.f;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy, et = K.edge_threshold;
+        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) return;
+    }
+    MisKeyPoint kpt;
+    kpt.x = (c + xc) * (1 << octv);
+    kpt.y = (r + xr) * (1 << octv);
+    kpt.octave = octv + (layer << 8) + (mis_round_f((xi + 0.5f) * 255) << 16);
+    kpt.size = K.sigma * mis_expf(((layer + xi) / nl) * 0.69314718055994530942f) * (1 << octv) * 2;
+    kpt.response = fabsf(contr);
+    kpt.angle = 0;
+    // ---- calcOrientationHist on the Gaussian image of the refined layer ----
+    const float scl_octv = kpt.size * 0.5f / (1 << octv);
+    const int radius = mis_round_f(SIFT_ORI_RADIUS * scl_octv), n = SIFT_ORI_HIST_BINS;
+    const float sigma_o = SIFT_ORI_SIG_FCTR * scl_octv, expf_scale = -1.f / (2.f * sigma_o * sigma_o);
+    const float* gimg = P.gauss[octv * (nl + 3) + layer];
+    float temphist[SIFT_ORI_HIST_BINS + 4];
+    float* th = temphist + 2;
+    for (int j = 0; j < n + 4; j++) temphist[j] = 0.f;
+    for (int di = -radius; di <= radius; di++) {
+        const int y = r + di;
+        if (y <= 0 || y >= h - 1) continue;
+        for (int dj = -radius; dj <= radius; dj++) {
+            const int x = c + dj;
+            if (x <= 0 || x >= w - 1) continue;
+            const float dx = AT(gimg, y, x + 1) - AT(gimg, y, x - 1), dy = AT(gimg, y - 1, x) - AT(gimg, y + 1, x);
+            const float wgt = mis_expf((di * di + dj * dj) * expf_scale);
+            const float ori = mis_fast_atan2(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+            int bin = mis_round_f((n / 360.f) * ori);
+            if (bin >= n) bin -= n;
+            if (bin < 0) bin += n;
+            th[bin] += wgt * mag;
+        }
+    }
+    th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
+    float hist[SIFT_ORI_HIST_BINS];
+    for (int j = 0; j < n; j++) hist[j] = (th[j - 2] + th[j + 2]) * (1.f / 16.f) + (th[j - 1] + th[j + 1]) * (4.f / 16.f) + th[j] * (6.f / 16.f);
+    float omax = hist[0];
+    for (int j = 1; j < n; j++) omax = omax > hist[j] ? omax : hist[j];
+    const float mag_thr = omax * SIFT_ORI_PEAK_RATIO;
+    for (int j = 0; j < n; j++) {
+        const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+        if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
+            float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
+            bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
+            kpt.angle = 360.f - (float)((360.f / n) * bin);
+            if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
+            const unsigned slot = atomicAdd(n_kps, 1u);
+            if (slot < kp_cap) kps[slot] = kpt;
+        }
+    }
+}
+
+// calcSIFTDescriptor: one thread per keypoint, the (d+2)(d+2)(n+2) histogram in LDS (sequential float sums)
+constexpr int DESC_TPB = 32, HISTLEN = 6 * 6 * 10;
+__global__ __launch_bounds__(DESC_TPB) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, int nk, float* __restrict__ desc) {
+    __shared__ float hist_all[HISTLEN * DESC_TPB];
+    const int q = blockIdx.x * DESC_TPB + threadIdx.x;
+    if (q >= nk) return;
+    float* hist = hist_all + threadIdx.x;   // element e at hist[e * DESC_TPB]: conflict-free across the threads
+#define HS(e) hist[(e) * DESC_TPB]
+    const int d = 4, n = 8, nl = P.nl, firstOctave = -1;
+    const MisKeyPoint k = kps[q];
+    int octave = k.octave & 255;
+    const int layer = (k.octave >> 8) & 255;
+    octave = octave < 128 ? octave : (-128 | octave);
+    const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+    const float size = k.size * scale, ptx = k.x * scale, pty = k.y * scale;
+    const int oi = octave - firstOctave;
+    float ori = 360.f - k.angle;
+    if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
+    const float scl = size * 0.5f;
+    const float* img = P.gauss[oi * (nl + 3) + layer];
+    const int w = P.w[oi], h = P.h[oi];
+    const int px = mis_round_f(ptx), py = mis_round_f(pty);
+    float cos_t = mis_cosf(ori * (float)(3.14159265358979323846 / 180)), sin_t = mis_sinf(ori * (float)(3.14159265358979323846 / 180));
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = SIFT_DESCR_SCL_FCTR * scl;
+    int radius = mis_round_f(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    const int rmax = (int)sqrt((double)w * w + (double)h * h);
+    if (radius > rmax) radius = rmax;
+    cos_t /= hist_width; sin_t /= hist_width;
+    for (int e = 0; e < HISTLEN; e++) HS(e) = 0.f;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
+            const float dx = AT(img, r, c + 1) - AT(img, r, c - 1), dy = AT(img, r - 1, c) - AT(img, r + 1, c);
+            const float wgt = mis_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (mis_fast_atan2(dy, dx) - ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const int r0 = mis_floor_f(rbin), c0 = mis_floor_f(cbin);
+            int o0 = mis_floor_f(obin);
+            rbin -= r0; cbin -= c0; obin -= o0;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            HS(idx) += v_rco000; HS(idx + 1) += v_rco001;
+            HS(idx + (n + 2)) += v_rco010; HS(idx + (n + 3)) += v_rco011;
+            HS(idx + (d + 2) * (n + 2)) += v_rco100; HS(idx + (d + 2) * (n + 2) + 1) += v_rco101;
+            HS(idx + (d + 3) * (n + 2)) += v_rco110; HS(idx + (d + 3) * (n + 2) + 1) += v_rco111;
+        }
+    float* dst = desc + 128 * (size_t)q;
+    float nrm2 = 0;
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            HS(idx) += HS(idx + n);
+            HS(idx + 1) += HS(idx + n + 1);
+            for (int kk = 0; kk < n; kk++) { const float v = HS(idx + kk); dst[(i * d + j) * n + kk] = v; nrm2 += v * v; }
+        }
+    const int len = d * d * n;
+    const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
+    nrm2 = 0;
+    for (int kk = 0; kk < len; kk++) {
+        const float val = dst[kk] < thr ? dst[kk] : thr;
+        dst[kk] = val;
+        nrm2 += val * val;
+    }
+    const float root = sqrtf(nrm2);
+    nrm2 = SIFT_INT_DESCR_FCTR / (root > FLT_EPSILON ? root : FLT_EPSILON);
+    for (int kk = 0; kk < len; kk++) {
+        const int v = mis_round_f(dst[kk] * nrm2);   // saturate_cast<uchar>
+        dst[kk] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+#undef HS
+}
+
+bool kp_less(const MisKeyPoint& a, const MisKeyPoint& b) {   // KeyPoint_LessThan of KeyPointsFilter::removeDuplicatedSorted
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    return false;
+}
+
+}  // namespace
+
+struct MisSift {
+    MisContext* ctx;
+    MisSiftParams p;
+    int max_w, max_h;
+    Pyr pyr;            // for the current image size
+    int cur_w = 0, cur_h = 0;
+    uint8_t* mem = nullptr;   // one allocation: pyramids, scratch, lists
+    size_t bytes = 0;
+    uint8_t* gray = nullptr;
+    float *tmp = nullptr, *grayf = nullptr;
+    int4* cand = nullptr;
+    MisKeyPoint* raw = nullptr;
+    unsigned* counters = nullptr;   // [0] candidates, [1] raw keypoints
+    unsigned cand_cap = 0, kp_cap = 0;
+    double sig[MAX_LAYERS + 4];
+};
+
+static int sift_plan(MisSift* s, int w, int h) {
+    // carve the one allocation for this image size (allocation sized for max_w x max_h)
+    const int nl = s->p.n_octave_layers, firstOctave = -1;
+    Pyr& P = s->pyr;
+    const int bw = 2 * w, bh = 2 * h;
+    int noct = mis_round_d(log((double)std::min(bw, bh)) / log(2.) - 2) - firstOctave;
+    noct = std::max(1, std::min(noct, MAX_OCT));
+    P.nl = nl;
+    size_t off = 0;
+    auto carve = [&](size_t b) { size_t o = off; off += mis_align_up(b, 256); return s->mem ? s->mem + o : (uint8_t*)nullptr; };
+    int cw = bw, ch = bh, built = 0;
+    for (int o = 0; o < noct; o++) {
+        P.w[o] = cw; P.h[o] = ch;
+        for (int i = 0; i < nl + 3; i++) P.gauss[o * (nl + 3) + i] = (float*)carve(sizeof(float) * (size_t)cw * ch);
+        for (int i = 0; i < nl + 2; i++) P.dog[o * (nl + 2) + i] = (float*)carve(sizeof(float) * (size_t)cw * ch);
+        built = o + 1;
+        cw /= 2; ch /= 2;
+        if (cw < 1 || ch < 1) break;
+    }
+    P.noct = built;
+    s->gray = carve((size_t)w * h);
+    s->grayf = (float*)carve(sizeof(float) * (size_t)bw * bh);
+    s->tmp = (float*)carve(sizeof(float) * (size_t)bw * bh);
+    s->cand_cap = (unsigned)std::max<size_t>(65536, (size_t)bw * bh / 8);
+    s->kp_cap = (unsigned)std::max<size_t>(65536, (size_t)bw * bh / 16);
+    s->cand = (int4*)carve(sizeof(int4) * s->cand_cap);
+    s->raw = (MisKeyPoint*)carve(sizeof(MisKeyPoint) * s->kp_cap);
+    s->counters = (unsigned*)carve(256);
+    s->bytes = off;
+    s->cur_w = w; s->cur_h = h;
+    return MIS_OK;
+}
+
+extern "C" void mis_sift_default_params(MisSiftParams* p) {
+    if (!p) return;
+    p->nfeatures = 0; p->n_octave_layers = 3; p->contrast_threshold = 0.04; p->edge_threshold = 10; p->sigma = 1.6;
+}
+
+extern "C" int mis_sift_create(MisContext* ctx, const MisSiftParams* params, int max_width, int max_height, MisSift** out) {
+    if (!ctx || !out) return MIS_E_INVALID;
+    *out = nullptr;
+    MisSiftParams p;
+    mis_sift_default_params(&p);
+    if (params) p = *params;
+    MIS_CHECK(ctx, p.nfeatures == 0, MIS_E_UNSUPPORTED, "SIFT: only nfeatures = 0 (the reference's SIFT::create()) is supported");
+    MIS_CHECK(ctx, p.n_octave_layers >= 1 && p.n_octave_layers <= MAX_LAYERS && p.sigma > 0.5, MIS_E_INVALID, "SIFT: bad parameters");
+    MIS_CHECK(ctx, max_width >= 16 && max_height >= 16 && max_width <= 16384 && max_height <= 16384, MIS_E_INVALID, "SIFT: image size out of range");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MisSift* s = new MisSift();
+    s->ctx = ctx; s->p = p; s->max_w = max_width; s->max_h = max_height;
+    sift_plan(s, max_width, max_height);            // sizes only (mem == nullptr)
+    const size_t need = s->bytes;
+    if (hipMalloc((void**)&s->mem, need) != hipSuccess) { delete s; return mis_set_error(ctx, MIS_E_HIP, "SIFT: cannot allocate %zu bytes of scale space", need); }
+    sift_plan(s, max_width, max_height);
+    // buildGaussianPyramid: incremental sigmas
+    const int nl = p.n_octave_layers;
+    s->sig[0] = p.sigma;
+    const double k = pow(2., 1. / nl);
+    for (int i = 1; i < nl + 3; i++) {
+        const double sig_prev = pow(k, (double)(i - 1)) * p.sigma, sig_total = sig_prev * k;
+        s->sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+    }
+    *out = s;
+    return MIS_OK;
+}
+
+extern "C" int mis_sift_destroy(MisSift* s) {
+    if (!s) return MIS_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->mem) hipFree(s->mem);
+    delete s;
+    return MIS_OK;
+}
+
+static void blur(MisSift* s, const float* src, float* dst, int w, int h, double sigma) {
+    const Taps t = gaussian_taps(sigma);
+    dim3 grid((w + 255) / 256, h), block(256);
+    hipLaunchKernelGGL(sift_blur_kernel<false>, grid, block, 0, s->ctx->stream, src, s->tmp, w, h, t);
+    hipLaunchKernelGGL(sift_blur_kernel<true>, grid, block, 0, s->ctx->stream, (const float*)s->tmp, dst, w, h, t);
+}
+
+// scale space of one image (everything up to and including the DoG pyramid)
+static int sift_build(MisSift* s, const MisImage* bgr, const DevImage& din) {
+    MisContext* ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const int w = bgr->width, h = bgr->height, nl = s->p.n_octave_layers;
+    if (w != s->cur_w || h != s->cur_h) sift_plan(s, w, h);
+    const Pyr& P = s->pyr;
+    hipLaunchKernelGGL(sift_gray_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, (const uint8_t*)din.data, din.stride, w, h, s->gray);
+    hipLaunchKernelGGL(sift_upsample_kernel, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, st, (const uint8_t*)s->gray, w, h, s->grayf);
+    const float sd = sqrtf(fmaxf((float)(s->p.sigma * s->p.sigma) - SIFT_INIT_SIGMA * SIFT_INIT_SIGMA * 4, 0.01f));
+    blur(s, s->grayf, P.gauss[0], P.w[0], P.h[0], (double)sd);
+    for (int o = 0; o < P.noct; o++) {
+        const int ow = P.w[o], oh = P.h[o];
+        for (int i = 0; i < nl + 3; i++) {
+            if (o == 0 && i == 0) continue;
+            float* dst = P.gauss[o * (nl + 3) + i];
+            if (i == 0)
+                hipLaunchKernelGGL(sift_decimate_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, st, (const float*)P.gauss[(o - 1) * (nl + 3) + nl], P.w[o - 1],
+                                   P.h[o - 1], dst, ow, oh);
+            else
+                blur(s, P.gauss[o * (nl + 3) + i - 1], dst, ow, oh, s->sig[i]);
+        }
+        const size_t n = (size_t)ow * oh;
+        for (int i = 0; i < nl + 2; i++)
+            hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)P.gauss[o * (nl + 3) + i],
+                               (const float*)P.gauss[o * (nl + 3) + i + 1], P.dog[o * (nl + 2) + i], n);
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+extern "C" int mis_sift_detect(MisSift* s, const MisImage* bgr, MisFeatures* out) {
+    if (!s) return MIS_E_INVALID;
+    MisContext* ctx = s->ctx;
+    MIS_CHECK(ctx, bgr && out && bgr->data, MIS_E_INVALID, "null argument");
+    MIS_CHECK(ctx, bgr->dtype == MIS_U8 && bgr->channels == 3, MIS_E_UNSUPPORTED, "SIFT input must be 8UC3 (BGR)");
+    MIS_CHECK(ctx, bgr->width >= 16 && bgr->height >= 16 && bgr->width <= s->max_w && bgr->height <= s->max_h, MIS_E_INVALID,
+              "image %dx%d outside the detector's range (16x16 .. %dx%d)", bgr->width, bgr->height, s->max_w, s->max_h);
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevImage din;
+    int rc;
+    if ((rc = mis_dev_image_in(ctx, bgr, &din)) != MIS_OK) return rc;
+    if ((rc = sift_build(s, bgr, din)) != MIS_OK) return rc;
+    const Pyr& P = s->pyr;
+    const int nl = s->p.n_octave_layers, firstOctave = -1;
+    MIS_HIP(ctx, hipMemsetAsync(s->counters, 0, 256, st));
+    const int threshold = (int)floor(0.5 * s->p.contrast_threshold / nl * 255);
+    for (int o = 0; o < P.noct; o++) {
+        const int iw = P.w[o] - 2 * SIFT_IMG_BORDER, ih = P.h[o] - 2 * SIFT_IMG_BORDER;
+        if (iw <= 0 || ih <= 0) continue;
+        hipLaunchKernelGGL(sift_extrema_kernel, dim3((iw + 255) / 256, ih, nl), dim3(256), 0, st, P, o, threshold, s->cand, s->counters, s->cand_cap);
+    }
+    unsigned counts[2] = {0, 0};
+    MIS_HIP(ctx, hipMemcpyAsync(counts, s->counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipStreamSynchronize(st));
+    MIS_CHECK(ctx, counts[0] <= s->cand_cap, MIS_E_INVALID, "SIFT: %u extrema candidates exceed the capacity %u", counts[0], s->cand_cap);
+    const SiftConsts K{(float)s->p.contrast_threshold, (float)s->p.edge_threshold, (float)s->p.sigma};
+    if (counts[0])
+        hipLaunchKernelGGL(sift_refine_kernel, dim3((counts[0] + 63) / 64), dim3(64), 0, st, P, K, (const int4*)s->cand, (const unsigned*)s->counters, s->cand_cap, s->raw,
+                           s->counters + 1, s->kp_cap);
+    MIS_HIP(ctx, hipMemcpyAsync(&counts[1], s->counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipStreamSynchronize(st));
+    MIS_CHECK(ctx, counts[1] <= s->kp_cap, MIS_E_INVALID, "SIFT: %u keypoints exceed the capacity %u", counts[1], s->kp_cap);
+    // KeyPointsFilter::removeDuplicatedSorted (a total order) + the firstOctave < 0 rescaling -- host, between the phases
+    std::vector<MisKeyPoint> kp(counts[1]);
+    if (counts[1]) {
+        MIS_HIP(ctx, hipMemcpyAsync(kp.data(), s->raw, sizeof(MisKeyPoint) * counts[1], hipMemcpyDeviceToHost, st));
+        MIS_HIP(ctx, hipStreamSynchronize(st));
+    }
+    std::sort(kp.begin(), kp.end(), kp_less);
+    size_t m = 0;
+    for (size_t i = 0; i < kp.size(); i++) {
+        if (m > 0 && kp[m - 1].x == kp[i].x && kp[m - 1].y == kp[i].y && kp[m - 1].size == kp[i].size && kp[m - 1].angle == kp[i].angle) continue;
+        kp[m++] = kp[i];
+    }
+    kp.resize(m);
+    for (MisKeyPoint& k : kp) {
+        const float scale = 1.f / (float)(1 << -firstOctave);
+        k.octave = (k.octave & ~255) | ((k.octave + firstOctave) & 255);
+        k.x *= scale; k.y *= scale; k.size *= scale;
+    }
+    // output block: keypoints + descriptors
+    const int nk = (int)kp.size();
+    memset(out, 0, sizeof(*out));
+    out->img_w = bgr->width; out->img_h = bgr->height; out->n = nk; out->desc_cols = 128; out->desc_dtype = MIS_F32;
+    const size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)std::max(nk, 1), 256), db = sizeof(float) * 128 * (size_t)std::max(nk, 1);
+    uint8_t* blk = nullptr;
+    MIS_HIP(ctx, hipMalloc((void**)&blk, kb + db));
+    out->owner_ = blk; out->keypoints = (MisKeyPoint*)blk; out->descriptors = blk + kb;
+    if (nk) {
+        MIS_HIP(ctx, hipMemcpyAsync(out->keypoints, kp.data(), sizeof(MisKeyPoint) * (size_t)nk, hipMemcpyHostToDevice, st));
+        MIS_HIP(ctx, hipStreamSynchronize(st));   // kp is a local vector
+        hipLaunchKernelGGL(sift_descriptor_kernel, dim3((nk + DESC_TPB - 1) / DESC_TPB), dim3(DESC_TPB), 0, st, P, (const MisKeyPoint*)out->keypoints, nk,
+                           (float*)out->descriptors);
+        MIS_HIP(ctx, hipGetLastError());
+    }
+    return mis_dev_image_release(ctx, &din);
+}
+
+extern "C" int mis_sift_debug_level(MisSift* s, const MisImage* bgr, int octave, int layer, int dog, float* host_out, int* width, int* height) {
+    if (!s) return MIS_E_INVALID;
+    MisContext* ctx = s->ctx;
+    MIS_CHECK(ctx, bgr && bgr->data && width && height, MIS_E_INVALID, "null argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    DevImage din;
+    int rc;
+    if ((rc = mis_dev_image_in(ctx, bgr, &din)) != MIS_OK) return rc;
+    if ((rc = sift_build(s, bgr, din)) != MIS_OK) return rc;
+    const Pyr& P = s->pyr;
+    const int nl = s->p.n_octave_layers;
+    MIS_CHECK(ctx, octave >= 0 && octave < P.noct && layer >= 0 && layer < (dog ? nl + 2 : nl + 3), MIS_E_INVALID, "bad octave / layer");
+    *width = P.w[octave]; *height = P.h[octave];
+    if (host_out) {
+        const float* src = dog ? P.dog[octave * (nl + 2) + layer] : P.gauss[octave * (nl + 3) + layer];
+        MIS_HIP(ctx, hipMemcpyAsync(host_out, src, sizeof(float) * (size_t)P.w[octave] * P.h[octave], hipMemcpyDeviceToHost, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return mis_dev_image_release(ctx, &din);
+}

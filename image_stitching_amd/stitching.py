@@ -450,6 +450,55 @@ class OrbFeatureFinder:
             pass
 
 
+class SiftFeatureFinder:
+    """SIFT::create() (image_stitching.cpp:559, features_type == "sift"): same detect() interface as the ORB finder;
+    descriptors are n x 128 f32 with integer values 0..255 (the L2 matcher's MFMA path, K8, consumes them)."""
+
+    def __init__(self, ctx, max_size, params=None):
+        self.ctx = ctx
+        p = capi.MisSiftParams()
+        ctx.lib.mis_sift_default_params(C.byref(p))
+        for k, v in (params or {}).items():
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mis_sift_create(ctx.h, C.byref(p), int(max_size[0]), int(max_size[1]), C.byref(h)))
+        self.h = h
+
+    def detect(self, img):
+        raw = capi.MisFeatures()
+        i = as_image(img)
+        self.ctx.check(self.ctx.lib.mis_sift_detect(self.h, C.byref(i), C.byref(raw)))
+        return ImageFeatures(self.ctx, raw)
+
+    def detect_batch(self, imgs):
+        out = []
+        for k, im in enumerate(imgs):
+            f = self.detect(im)
+            f.img_idx = k
+            out.append(f)
+        return out
+
+    def debug_level(self, img, octave, layer, dog=False):
+        i = as_image(img)
+        w, h = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.mis_sift_debug_level(self.h, C.byref(i), octave, layer, int(dog), None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.float32)
+        self.ctx.check(self.ctx.lib.mis_sift_debug_level(self.h, C.byref(i), octave, layer, int(dog), out.ctypes.data_as(C.c_void_p), C.byref(w), C.byref(h)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.mis_sift_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def computeImageFeatures(finder, img, img_idx=0):
     """cv::detail::computeImageFeatures(finder, img, features) + features.img_idx = i (:613-614)."""
     f = finder.detect(img)

@@ -168,6 +168,23 @@ int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float sca
 int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
                                    MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl, int repeats, float* avg_us);
 
+/* ---------------------------------------------------------------- SIFT ---------------------- */
+/* SIFT::create() -- replaces image_stitching/image_stitching.cpp:559 (features_type == "sift").  Defaults of the
+ * reference: nfeatures 0 (only value supported), nOctaveLayers 3, contrastThreshold 0.04, edgeThreshold 10, sigma 1.6. */
+typedef struct {
+    int nfeatures, n_octave_layers;
+    double contrast_threshold, edge_threshold, sigma;
+} MisSiftParams;
+typedef struct MisSift MisSift;
+void mis_sift_default_params(MisSiftParams* p);
+int mis_sift_create(MisContext* ctx, const MisSiftParams* params /* NULL = defaults */, int max_width, int max_height, MisSift** out);
+int mis_sift_destroy(MisSift* sift);
+/* computeImageFeatures(finder, img, features) -- replaces image_stitching.cpp:613 for the SIFT finder: keypoints in the
+ * order of KeyPointsFilter::removeDuplicatedSorted, descriptors n x 128 f32 with integer values 0..255 (feeds K8). */
+int mis_sift_detect(MisSift* sift, const MisImage* bgr, MisFeatures* out);
+/* test aid: one image of the Gaussian (dog = 0) or DoG (dog = 1) pyramid of `bgr`, copied to host_out (may be NULL) */
+int mis_sift_debug_level(MisSift* sift, const MisImage* bgr, int octave, int layer, int dog, float* host_out, int* width, int* height);
+
 /* ---------------------------------------------------------------- image operators ----------- */
 /* cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR_EXACT) -- replaces image_stitching.cpp:580 (work scale), :619 (seam
  * scale), :1144 (compose scale).  8UC1 / 8UC3.  dst_w, dst_h > 0: that size (scale = dsize / ssize); otherwise

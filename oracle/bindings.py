@@ -640,3 +640,73 @@ def seam_mask_apply(seam, mask):
     mh, mw = out.shape
     L.mo_seam_mask_apply(seam.ctypes.data_as(C.c_void_p), sw, sh, C.c_size_t(sw), out.ctypes.data_as(C.c_void_p), mw, mh, C.c_size_t(mw))
     return out
+
+
+# ---- SIFT (mo_sift.c) ----------------------------------------------------------------------------
+class SiftParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("n_octave_layers", C.c_int), ("contrast_threshold", C.c_double), ("edge_threshold", C.c_double),
+                ("sigma", C.c_double)]
+
+
+class Sift:
+    """cv::SIFT::create() + detectAndCompute on one BGR image (defaults of the reference, image_stitching.cpp:559)."""
+
+    def __init__(self, width, height, params=None):
+        L = lib()
+        L.mo_sift_create.restype = C.c_void_p
+        L.mo_sift_keypoints.restype = C.c_void_p
+        L.mo_sift_descriptors.restype = C.c_void_p
+        L.mo_sift_gauss.restype = C.c_void_p
+        L.mo_sift_dog.restype = C.c_void_p
+        p = SiftParams()
+        L.mo_sift_default_params(C.byref(p))
+        if params:
+            for k, v in params.items():
+                setattr(p, k, v)
+        self.params = p
+        self.w, self.h = width, height
+        self.h_ = C.c_void_p(L.mo_sift_create(C.byref(p), width, height))
+
+    def __del__(self):
+        try:
+            lib().mo_sift_destroy(self.h_)
+        except Exception:
+            pass
+
+    def run(self, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        assert bgr.shape == (self.h, self.w, 3)
+        n = lib().mo_sift_run(self.h_, bgr.ctypes.data_as(C.c_void_p), C.c_size_t(self.w * 3))
+        if n < 0:
+            raise RuntimeError("mo_sift_run failed")
+        kps = _from_ptr(lib().mo_sift_keypoints(self.h_), (n,), KP_DTYPE) if n else np.zeros(0, KP_DTYPE)
+        desc = _from_ptr(lib().mo_sift_descriptors(self.h_), (n, 128), np.float32) if n else np.zeros((0, 128), np.float32)
+        return kps, desc
+
+    def num_octaves(self):
+        return lib().mo_sift_num_octaves(self.h_)
+
+    def num_raw_keypoints(self):
+        return lib().mo_sift_num_raw_keypoints(self.h_)
+
+    def gauss(self, o, i):
+        w, h = C.c_int(), C.c_int()
+        p = lib().mo_sift_gauss(self.h_, o, i, C.byref(w), C.byref(h))
+        return _from_ptr(p, (h.value, w.value), np.float32)
+
+    def dog(self, o, i):
+        w, h = C.c_int(), C.c_int()
+        p = lib().mo_sift_dog(self.h_, o, i, C.byref(w), C.byref(h))
+        return _from_ptr(p, (h.value, w.value), np.float32)
+
+
+def expf(x):
+    L = lib()
+    L.mo_expf.restype = C.c_float
+    return L.mo_expf(C.c_float(x))
+
+
+def gaussian_taps_f32(sigma):
+    buf = (C.c_float * 64)()
+    n = lib().mo_gaussian_taps_f32(C.c_double(sigma), buf)
+    return np.array(buf[:n], np.float32)

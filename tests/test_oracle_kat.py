@@ -303,3 +303,34 @@ def test_rotate_dilate_and_seam_mask_known_answers(oracle_mod):
     seam = np.full((10, 15), 255, np.uint8)
     seam[5, 7] = 0
     assert np.array_equal(o.seam_mask_apply(seam, mask), mask)
+
+
+# ---- SIFT (mo_sift.c): closed-form expectations of the published algorithm --------------------
+def test_sift_blob_scale_and_position(oracle_mod):
+    o = oracle_mod
+    h, w, s0 = 128, 160, 6.0
+    yy, xx = np.mgrid[0:h, 0:w]
+    g = 200 * np.exp(-((xx - 80) ** 2 + (yy - 64) ** 2) / (2 * s0 ** 2))
+    img = np.repeat(g[..., None], 3, 2).astype(np.uint8)
+    s = o.Sift(w, h)
+    k, d = s.run(img)
+    assert s.num_octaves() == 7 and len(k) >= 1
+    # the blob's DoG extremum: centre within half a pixel, characteristic scale sigma ~ s0 (size = 2 sigma, within 20 %)
+    assert np.all(np.abs(k["x"] - 80) < 0.75) and np.all(np.abs(k["y"] - 64) < 0.75)
+    assert np.all(np.abs(k["size"] / 2 - s0) < 0.2 * s0)
+    assert np.array_equal(d, np.rint(d)) and d.max() <= 255 and d.min() >= 0
+    assert np.all(np.abs(np.linalg.norm(d, axis=1) - 512) < 24)
+    # a flat image has no extrema
+    assert len(o.Sift(64, 48).run(np.full((48, 64, 3), 31, np.uint8))[0]) == 0
+
+
+def test_sift_helpers(oracle_mod):
+    import math
+    o = oracle_mod
+    assert 0.0 <= o.expf(-103.0) < 1e-44                                  # denormal range: coarse
+    for x in [-80.0, -20.5, -1.0, -1e-3, 0.0, 0.3, 1.0, 10.0, 88.0]:
+        assert abs(o.expf(x) - math.exp(x)) <= 2e-7 * math.exp(x)
+    assert o.expf(-200.0) == 0.0
+    t = o.gaussian_taps_f32(1.6)
+    assert len(t) == 15 and abs(float(t.sum()) - 1.0) < 1e-6 and np.array_equal(t, t[::-1]) and t.argmax() == 7
+    assert len(o.gaussian_taps_f32(1.2489996)) == 11
