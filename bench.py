@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, help="config2 | config3 | config4 (default: config3, config4 when --gpus > 1)")
+    ap.add_argument("--features", default=None, help="orb | sift (default: orb; sift for config5, BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
     ap.add_argument("--no-single-base", action="store_true", help="N > 1: skip the unsharded run of the same workload on rank 0")
@@ -68,7 +69,9 @@ def main():
     n = len(cams)
     W, H = cams[0]["width"], cams[0]["height"]
     ctx = isa.Context(local_rank)
-    job = misdist.StitchJob(ctx, (W, H), cams, rank=rank, world_size=world, group=pg)
+    features = args.features or ("sift" if workload == "config5" else "orb")
+    cfg = isa.StitchConfig(features_type=features)
+    job = misdist.StitchJob(ctx, (W, H), cams, rank=rank, world_size=world, group=pg, config=cfg)
     # synthetic frames of this rank's shard, rendered straight into HBM
     frames = {i: synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in job.my_frames}
     torch.cuda.synchronize()
@@ -105,7 +108,7 @@ def main():
     if world > 1 and not args.no_single_base:
         if rank == 0:
             all_frames = {i: frames[i] if i in frames else synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in range(n)}
-            solo = misdist.StitchJob(ctx, (W, H), cams)
+            solo = misdist.StitchJob(ctx, (W, H), cams, config=cfg)
             solo.run(all_frames)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -127,15 +130,15 @@ def main():
     cpu = None
     if rank == 0:
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and features == "orb":
             cpu = cpu_baseline(cams, workload)
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s: %d x %dx%d frames, ORB 4000 + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"
-                                   % (workload, n, W, H),
+            "config": {"workload": "%s: %d x %dx%d frames, %s + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"
+                                   % (workload, n, W, H, "SIFT (128-D f32, L2 on fp16 MFMA)" if features == "sift" else "ORB 4000"),
                        "frames": n, "frame_size": [W, H], "pairs": n * (n - 1) // 2, "pano_size": list(out["pano_size"]),
                        "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -88,9 +88,9 @@ class HipEngine:
         self.ctx = ctx
         self.cfg = config or st.StitchConfig()
         self.frame_size = frame_size
-        self.finder = st.OrbFeatureFinder(ctx, frame_size)
+        # finder per features_type (image_stitching.cpp:543-563): ORB, or SIFT (float descriptors -> the L2 matcher)
+        self.finder = st.SiftFeatureFinder(ctx, frame_size) if self.cfg.features_type == "sift" else st.OrbFeatureFinder(ctx, frame_size)
         self.matcher = st.BestOf2NearestMatcher(ctx, self.cfg.match_conf)
-        self.cap = None
         self.blender = None
         self._keep = []
 
@@ -98,34 +98,40 @@ class HipEngine:
     def detect(self, frames):
         return self.finder.detect_batch(frames)
 
-    def pack_features(self, feats):
-        """-> (kps u8 [m, cap*24], desc u8 [m, cap*32], counts i32 [m]) device tensors for the all-gather."""
-        cap = self.finder.params.nfeatures + 128 * self.finder.params.nlevels
+    def feature_counts(self, feats):
+        return torch.tensor([len(f) for f in feats], dtype=torch.int32, device=self.ctx.device)
+
+    def pack_features(self, feats, cap):
+        """-> (kps u8 [m, cap*24], desc u8 [m, cap*row_bytes]) device tensors for the all-gather; `cap` = the largest
+        keypoint count of any frame of the job (agreed by the ranks beforehand: SIFT has no fixed budget)."""
         m = len(feats)
         dev = self.ctx.device
+        rb = self._row_bytes(feats)
         kps = torch.zeros((m, cap * 24), dtype=torch.uint8, device=dev)
-        desc = torch.zeros((m, cap * 32), dtype=torch.uint8, device=dev)
-        counts = torch.tensor([len(f) for f in feats], dtype=torch.int32, device=dev)
+        desc = torch.zeros((m, cap * rb), dtype=torch.uint8, device=dev)
         for i, f in enumerate(feats):
             n = len(f)
             if n:
                 kps[i, : n * 24] = dev_tensor(f.raw.keypoints, (n * 24,), "|u1", dev)
-                desc[i, : n * 32] = dev_tensor(f.raw.descriptors, (n * 32,), "|u1", dev)
-        self.cap = cap
-        return kps, desc, counts
+                desc[i, : n * rb] = dev_tensor(f.raw.descriptors, (n * rb,), "|u1", dev)
+        return kps, desc
+
+    def _row_bytes(self, feats=None):
+        return 512 if self.cfg.features_type == "sift" else 32
 
     def unpack_features(self, kps_all, desc_all, counts_all):
         """Gathered tensors [n, ...] -> ImageFeatures views (no copies; tensors kept alive)."""
         self._keep = [kps_all, desc_all, counts_all]
         counts = counts_all.cpu().tolist()
         w, h = self.frame_size
+        sift = self.cfg.features_type == "sift"
         out = []
         for i, n in enumerate(counts):
             raw = capi.MisFeatures()
             raw.img_idx, raw.img_w, raw.img_h, raw.n = i, w, h, int(n)
             raw.keypoints = kps_all[i].data_ptr()
             raw.descriptors = desc_all[i].data_ptr()
-            raw.desc_cols, raw.desc_dtype, raw.owner_ = 32, capi.U8, None
+            raw.desc_cols, raw.desc_dtype, raw.owner_ = (128, capi.F32, None) if sift else (32, capi.U8, None)
             out.append(st.ImageFeatures(self.ctx, raw))
         return out
 
@@ -200,10 +206,11 @@ class StitchJob:
     def stage_gather(self, local_feats):
         if self.world == 1 and not self.force_collectives:
             return local_feats
-        kps, desc, counts = self.engine.pack_features(local_feats)
+        counts_all = self.comm.all_gather(self.engine.feature_counts(local_feats)).flatten(0, 1)
+        cap = max(int(counts_all.max()), 1)
+        kps, desc = self.engine.pack_features(local_feats, cap)
         kps_all = self.comm.all_gather(kps).flatten(0, 1)
         desc_all = self.comm.all_gather(desc).flatten(0, 1)
-        counts_all = self.comm.all_gather(counts).flatten(0, 1)
         return self.engine.unpack_features(kps_all, desc_all, counts_all)
 
     def stage_match(self, feats):

@@ -36,16 +36,18 @@ class OracleEngine:
             out.append(dict(img_w=w, img_h=h, kps=k, xy=np.stack([k["x"], k["y"]], 1), desc=d))
         return out
 
-    def pack_features(self, feats):
+    def feature_counts(self, feats):
+        return torch.tensor([len(f["kps"]) for f in feats], dtype=torch.int32)
+
+    def pack_features(self, feats, cap):
         m = len(feats)
-        kps = torch.zeros((m, self.CAP * 24), dtype=torch.uint8)
-        desc = torch.zeros((m, self.CAP * 32), dtype=torch.uint8)
-        counts = torch.tensor([len(f["kps"]) for f in feats], dtype=torch.int32)
+        kps = torch.zeros((m, cap * 24), dtype=torch.uint8)
+        desc = torch.zeros((m, cap * 32), dtype=torch.uint8)
         for i, f in enumerate(feats):
             n = len(f["kps"])
             kps[i, : n * 24] = torch.from_numpy(np.frombuffer(f["kps"].tobytes(), np.uint8).copy())
             desc[i, : n * 32] = torch.from_numpy(f["desc"].reshape(-1).copy())
-        return kps, desc, counts
+        return kps, desc
 
     def unpack_features(self, kps_all, desc_all, counts_all):
         w, h = self.frame_size

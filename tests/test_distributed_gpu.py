@@ -44,3 +44,24 @@ def test_accumulator_views_alias_blender_memory(ctx):
         w.fill_(1.0)
     out, mask = eng.finalize()
     assert int(mask.min()) == 255 and int(out.min()) == 6 and int(out.max()) == 6   # (short)(7 / (1 + 1e-5)) = 6
+
+
+def test_sift_job_forced_collectives_match_plain_job(ctx):
+    """features_type = "sift": float descriptors through the variable-capacity gather and the L2 (MFMA) matcher."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd.distributed import StitchJob
+    w, h = 480, 270
+    cams = [synth.make_camera(w, h, 60.0, 11.0 * i - 16.0, 0.4 * ((i % 3) - 1)) for i in range(4)]
+    frames = {i: torch.from_numpy(synth.render_frame(c)).cuda() for i, c in enumerate(cams)}
+    cfg = isa.StitchConfig(features_type="sift")
+    plain = StitchJob(ctx, (w, h), cams, config=cfg).run(frames)
+    forced = StitchJob(ctx, (w, h), cams, config=cfg, force_collectives=True).run(frames)
+    assert plain["indices"] == forced["indices"] == [0, 1, 2, 3]
+    assert torch.equal(forced["confidence"], plain["confidence"])
+    k, d = plain["features"][1].download()
+    assert d.dtype == np.float32 and d.shape[1] == 128 and len(k) > 300
+    for a, b in zip(forced["features"], plain["features"]):
+        assert np.array_equal(a.download()[1], b.download()[1])
+    assert torch.equal(forced["pano"], plain["pano"]) and torch.equal(forced["mask"], plain["mask"])
