@@ -619,6 +619,13 @@ struct MisOrb {
     size_t pad_bytes = 0, map_bytes = 0;
     int cand_total = 0, fin_total = 0, tab_total = 0, surv_total = 0, out_cap = 0;
     std::vector<int> tab_host;
+    // Batches spread their frames over helper finders, each with its own workspace and its own non-blocking stream:
+    // the per-frame chain has ~60 launches, most of them small and latency bound, and chains of different frames
+    // overlap on the device.  Created on the first batch of more than one frame.
+    std::vector<MisOrb*> helpers;
+    std::vector<hipEvent_t> helper_done;
+    hipEvent_t fork_event = nullptr;
+    bool is_helper = false;
 };
 
 namespace {
@@ -842,10 +849,42 @@ extern "C" int mis_orb_destroy(MisOrb* o) {
     if (!o) return MIS_OK;
     hipSetDevice(o->ctx->device);
     hipStreamSynchronize(o->ctx->stream);
+    for (MisOrb* hlp : o->helpers) {
+        MisContext* hc = hlp->ctx;
+        mis_orb_destroy(hlp);
+        hipStreamDestroy(hc->stream);
+        delete hc;
+    }
+    for (hipEvent_t e : o->helper_done) hipEventDestroy(e);
+    if (o->fork_event) hipEventDestroy(o->fork_event);
     if (o->mem) hipFree(o->mem);
     delete o;
     return MIS_OK;
 }
+
+namespace {
+constexpr int ORB_HELPERS = 3;   // + the finder itself: 4 frames in flight
+
+int ensure_helpers(MisOrb* o) {
+    if (!o->helpers.empty() || o->is_helper) return MIS_OK;
+    MisContext* ctx = o->ctx;
+    MIS_HIP(ctx, hipEventCreateWithFlags(&o->fork_event, hipEventDisableTiming));
+    for (int k = 0; k < ORB_HELPERS; k++) {
+        MisContext* hc = new MisContext();
+        hc->device = ctx->device; hc->num_cu = ctx->num_cu;
+        if (hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking) != hipSuccess) { delete hc; return mis_set_error(ctx, MIS_E_HIP, "cannot create a helper stream"); }
+        MisOrb* hlp = nullptr;
+        int rc = mis_orb_create(hc, &o->p, o->max_w, o->max_h, &hlp);
+        if (rc != MIS_OK) { mis_set_error(ctx, rc, "helper finder: %s", hc->err.c_str()); hipStreamDestroy(hc->stream); delete hc; return rc; }
+        hlp->is_helper = true;
+        hipEvent_t e;
+        MIS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        o->helpers.push_back(hlp);
+        o->helper_done.push_back(e);
+    }
+    return MIS_OK;
+}
+}  // namespace
 
 extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisFeatures* out) {
     if (!o) return MIS_E_INVALID;
@@ -858,24 +897,55 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
         MIS_CHECK(ctx, imgs[i].width == imgs[0].width && imgs[i].height == imgs[0].height, MIS_E_INVALID, "batch frames must share one size");
     }
     if ((rc = replan_if_needed(o, imgs[0].width, imgs[0].height)) != MIS_OK) return rc;
+    std::vector<MisOrb*> lanes{o};
+    if (n > 1) {
+        if ((rc = ensure_helpers(o)) != MIS_OK) return rc;
+        for (MisOrb* hlp : o->helpers) {
+            if ((rc = replan_if_needed(hlp, imgs[0].width, imgs[0].height)) != MIS_OK) return mis_set_error(ctx, rc, "helper finder: %s", hlp->ctx->err.c_str());
+            lanes.push_back(hlp);
+        }
+        // fork: the helper streams start after everything already queued on the context's stream (the frames' producers)
+        MIS_HIP(ctx, hipEventRecord(o->fork_event, ctx->stream));
+        for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
+    }
     std::vector<DevImage> dimg(n);
     for (int i = 0; i < n; i++) {
         memset(&out[i], 0, sizeof(MisFeatures));
         out[i].img_idx = i; out[i].img_w = imgs[i].width; out[i].img_h = imgs[i].height;
         if ((rc = alloc_features(ctx, o->out_cap, 32, MIS_U8, &out[i])) != MIS_OK) return rc;
         if ((rc = mis_dev_image_in(ctx, &imgs[i], &dimg[i])) != MIS_OK) return rc;
-        if ((rc = enqueue_detect(o, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK) return rc;
     }
-    // one synchronisation for the whole batch: counts + overflow flag
+    if (n > 1) {   // staged host inputs were copied on the context's stream after the fork event: fork again behind them
+        bool staged = false;
+        for (int i = 0; i < n; i++) staged |= dimg[i].owned;
+        if (staged) {
+            MIS_HIP(ctx, hipEventRecord(o->fork_event, ctx->stream));
+            for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        MisOrb* lane = lanes[i % lanes.size()];
+        if ((rc = enqueue_detect(lane, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK)
+            return lane == o ? rc : mis_set_error(ctx, rc, "helper finder: %s", lane->ctx->err.c_str());
+    }
+    // join: the context's stream continues after every helper chain
+    for (size_t k = 0; k + 1 < lanes.size(); k++) {
+        MIS_HIP(ctx, hipEventRecord(o->helper_done[k], lanes[k + 1]->ctx->stream));
+        MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, o->helper_done[k], 0));
+    }
+    // one synchronisation for the whole batch: counts + overflow flags
     std::vector<int> counts(n);
-    int flags = 0;
+    std::vector<int> lane_flags(lanes.size(), 0);
     for (int i = 0; i < n; i++)
         MIS_HIP(ctx, hipMemcpyAsync(&counts[i], feat_count(&out[i], o->out_cap), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MIS_HIP(ctx, hipMemcpyAsync(&flags, o->w.flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    for (size_t k = 0; k < lanes.size(); k++)
+        MIS_HIP(ctx, hipMemcpyAsync(&lane_flags[k], lanes[k]->w.flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int flags = 0;
+    for (size_t k = 0; k < lanes.size(); k++)
+        if (lane_flags[k]) { flags |= lane_flags[k]; hipMemsetAsync(lanes[k]->w.flags, 0, sizeof(int), ctx->stream); }
     for (int i = 0; i < n; i++) { out[i].n = counts[i]; mis_dev_image_release(ctx, &dimg[i]); }
     if (flags) {
-        hipMemsetAsync(o->w.flags, 0, sizeof(int), ctx->stream);
         return mis_set_error(ctx, MIS_E_OVERFLOW, "ORB candidate buffers overflowed (flags %d): too many tied scores", flags);
     }
     return MIS_OK;

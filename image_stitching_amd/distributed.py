@@ -332,6 +332,7 @@ class StitchJob:
         btype, bands = self.stage_compose(frames, indices)
         self.stage_reduce()
         pano, mask = self.stage_finalize()
+        self.engine.sync()      # the job's results are complete when run() returns
         return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,
                 "pano_size": self.engine.pano_size, "num_bands": bands}
 
