@@ -73,9 +73,7 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
 // SIFT descriptors are integer valued (0..255, stored as f32): they are exact in fp16, every dot
 // product of two 128-D descriptors is an integer < 2^24 and therefore exact in the f32 accumulator of
 // v_mfma_f32_32x32x16_f16, so |a-b|^2 = |a|^2 + |b|^2 - 2 a.b comes out bit-exact and the 2-NN order
-// (distance, trainIdx) equals the CPU's.  A workgroup of 4 waves owns 64 queries; each wave a 32 x 32
-// (query x train) tile per step; the top-2 is kept per accumulator register and merged across the 32
-// lanes of a row at the end.
+// (distance, trainIdx) equals the CPU's.  Kernel structure: see l2_knn2_mfma_kernel below.
 struct L2Set {
     const _Float16* h;  // n x 128 fp16
     const float* nrm;   // n squared norms (exact integers)
@@ -103,77 +101,145 @@ __device__ __forceinline__ void top2_insert(float d, int i, float& d0, int& i0, 
     else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
 }
 
-__global__ __launch_bounds__(256) void l2_knn2_mfma_kernel(L2Set Q, L2Set T, int* idx2, float* dist2) {
+typedef int int16v __attribute__((ext_vector_type(16)));
+constexpr int L2_MAX_SLICES = 16;
+
+// A workgroup of 4 waves owns 128 queries (32 per wave, A fragments in registers) and walks the train set in
+// tiles of 32 descriptors that are staged ONCE per workgroup in LDS (double buffered, rows padded to 272 bytes so
+// the 16-byte fragment reads of the 32 lanes fall into different banks).  Per tile a wave issues 8 MFMAs
+// (32 x 32 x 128) and keeps, per accumulator register, the best two trains its lane (= column class) has seen.
+// The insertion is filtered: thr[g] = the smallest second-best of the 32 lanes that share the row, refreshed every
+// 8 tiles, is an upper bound of the row's final second-best distance, and it only contains trains of earlier tiles
+// (smaller indices), so a candidate with d >= thr[g] can never enter the row's top two -- also not through the
+// (distance, index) tie rule.  Candidates below the bound take the exact insertion.
+// The query norm is the same for every candidate of a row, so the ordering is decided on e = |t|^2 - 2 q.t (an
+// exact integer, possibly negative); |q|^2 is added at the end.  Train indices are kept as tile numbers (index =
+// 32 tile + lane column), two per register.  The train set is split into `gridDim.y` slices so that small query
+// sets still fill the device; slice results go to part_* and a second kernel merges them by (distance, index).
+constexpr int L2_TB = 32, L2_PITCH = 272;
+__global__ __launch_bounds__(256, 2) void l2_knn2_mfma_kernel(L2Set Q, L2Set T, int tiles_per_slice, int* part_idx, float* part_e) {
+    __shared__ __attribute__((aligned(16))) uint8_t sb[2][L2_TB * L2_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int q0 = blockIdx.x * 64 + (wave >> 1) * 32;   // this wave's 32 queries
-    if (blockIdx.x * 64 >= Q.n) return;
+    const int q0 = blockIdx.x * 128 + wave * 32;   // this wave's 32 queries
     // A fragments: lane holds A[row r][k = 16 s + 8 hh + j] for the 8 k-steps
     half8 a[8];
     const int qa = min(q0 + r, Q.n - 1);
 #pragma unroll
     for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const half8*>(Q.h + (size_t)qa * 128 + 16 * s8 + 8 * hh);
-    // per accumulator register: running best two of the trains this lane's column class has seen
-    float d0[16], d1[16];
-    int i0[16], i1[16];
+    float16v e0, e1, thr;
+    int16v it;   // tile of the best | tile of the second best << 16 (0xffff = none)
 #pragma unroll
-    for (int g = 0; g < 16; g++) { d0[g] = 3.0e38f; d1[g] = 3.0e38f; i0[g] = 0x7fffffff; i1[g] = 0x7fffffff; }
-    float qn[16];
-#pragma unroll
-    for (int g = 0; g < 16; g++) { const int row = (g & 3) + 8 * (g >> 2) + 4 * hh; qn[g] = Q.nrm[min(q0 + row, Q.n - 1)]; }
-    // the two waves of a query half interleave the train tiles
-    for (int t0 = (wave & 1) * 32; t0 < T.n; t0 += 64) {
-        const int tc = t0 + r;                     // this lane's train column
-        const int tb = min(tc, T.n - 1);
-        float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) {
-            const half8 b = *reinterpret_cast<const half8*>(T.h + (size_t)tb * 128 + 16 * s8 + 8 * hh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s8], b, acc, 0, 0, 0);
-        }
-        if (tc < T.n) {
-            const float tn = T.nrm[tc];
-#pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const float d2 = (qn[g] + tn) - 2.f * acc[g];  // exact integers below 2^24
-                top2_insert(d2, tc, d0[g], i0[g], d1[g], i1[g]);
-            }
-        }
-    }
-    // merge across the 32 lanes (columns) that share a row, then across the two waves through LDS
-    __shared__ float sd[2][32][4];
-    __shared__ int si[2][32][4];
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            const float od0 = __shfl_xor(d0[g], o), od1 = __shfl_xor(d1[g], o);
-            const int oi0 = __shfl_xor(i0[g], o), oi1 = __shfl_xor(i1[g], o);
-            top2_insert(od0, oi0, d0[g], i0[g], d1[g], i1[g]);
-            top2_insert(od1, oi1, d0[g], i0[g], d1[g], i1[g]);
-        }
-    }
-    const int qhalf = wave >> 1;
-    if ((wave & 1) == 1 && r == 0) {
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int row = (g & 3) + 8 * (g >> 2) + 4 * hh;
-            sd[qhalf][row][0] = d0[g]; sd[qhalf][row][1] = d1[g]; si[qhalf][row][0] = i0[g]; si[qhalf][row][1] = i1[g];
-        }
+    for (int g = 0; g < 16; g++) { e0[g] = 3.0e38f; e1[g] = 3.0e38f; thr[g] = 3.0e38f; it[g] = -1; }
+    // staging role of a thread: 16-byte chunk (t & 15) of train rows (t >> 4) and (t >> 4) + 16 of the tile
+    const int srow = threadIdx.x >> 4, schunk = threadIdx.x & 15;
+    const int ntiles_all = (T.n + L2_TB - 1) / L2_TB;
+    const int tile_lo = blockIdx.y * tiles_per_slice, tile_hi = min(ntiles_all, tile_lo + tiles_per_slice);
+    uint4 st0, st1;
+    auto fetch = [&](int tile) {
+        const int ta = tile * L2_TB + srow, tb = ta + 16;
+        st0 = ta < T.n ? *reinterpret_cast<const uint4*>(T.h + (size_t)ta * 128 + 8 * schunk) : make_uint4(0, 0, 0, 0);
+        st1 = tb < T.n ? *reinterpret_cast<const uint4*>(T.h + (size_t)tb * 128 + 8 * schunk) : make_uint4(0, 0, 0, 0);
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<uint4*>(sb[buf] + srow * L2_PITCH + 16 * schunk) = st0;
+        *reinterpret_cast<uint4*>(sb[buf] + (srow + 16) * L2_PITCH + 16 * schunk) = st1;
+    };
+    if (tile_lo < tile_hi) {
+        fetch(tile_lo);
+        stash(0);
     }
     __syncthreads();
-    if ((wave & 1) == 0 && r == 0) {
+    for (int tile = tile_lo; tile < tile_hi; tile++) {
+        const int buf = (tile - tile_lo) & 1;
+        if (tile + 1 < tile_hi) fetch(tile + 1);      // in flight during the MFMAs of this tile
+        const int tc = tile * L2_TB + r;              // this lane's train column
+        const float tn = tc < T.n ? T.nrm[tc] : 3.0e38f;
+        float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uint8_t* brow = sb[buf] + r * L2_PITCH + 16 * hh;
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, q = q0 + row;
-            top2_insert(sd[qhalf][row][0], si[qhalf][row][0], d0[g], i0[g], d1[g], i1[g]);
-            top2_insert(sd[qhalf][row][1], si[qhalf][row][1], d0[g], i0[g], d1[g], i1[g]);
-            if (q < Q.n) {
-                idx2[2 * (size_t)q] = i0[g] == 0x7fffffff ? -1 : i0[g]; idx2[2 * (size_t)q + 1] = i1[g] == 0x7fffffff ? -1 : i1[g];
-                dist2[2 * (size_t)q] = sqrtf(d0[g]); dist2[2 * (size_t)q + 1] = sqrtf(d1[g]);
+        for (int s8 = 0; s8 < 8; s8++) {
+            const half8 b = *reinterpret_cast<const half8*>(brow + 32 * s8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s8], b, acc, 0, 0, 0);
+        }
+        bool hit = false;
+#pragma unroll
+        for (int g = 0; g < 16; g++) hit |= (tn - 2.f * acc[g]) < thr[g];   // exact integers below 2^24 (or ~3e38 for a padded column)
+        if (__any(hit)) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const float e = tn - 2.f * acc[g];
+                if (e < thr[g]) {
+                    // within a lane the train index only grows: ties keep the earlier entry
+                    if (e < e0[g]) { e1[g] = e0[g]; e0[g] = e; it[g] = (it[g] << 16) | tile; }
+                    else if (e < e1[g]) { e1[g] = e; it[g] = (it[g] & 0xffff) | (tile << 16); }
+                }
             }
         }
+        if (((tile - tile_lo) & 7) == 7) {
+            // refresh the bound: the smallest second-best among the 32 lanes of the row (lanes with equal hh)
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                float m = e1[g];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+                thr[g] = m;
+            }
+        }
+        if (tile + 1 < tile_hi) stash(buf ^ 1);
+        __syncthreads();
     }
+    // merge across the 32 lanes (columns) that share a row; lane r == 0 of each half writes its 16 rows
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        float a0 = e0[g], a1 = e1[g];
+        const int t0 = it[g] & 0xffff, t1 = (it[g] >> 16) & 0xffff;
+        int b0 = a0 < 1.0e38f ? t0 * L2_TB + r : 0x7fffffff, b1 = a1 < 1.0e38f ? t1 * L2_TB + r : 0x7fffffff;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float od0 = __shfl_xor(a0, o), od1 = __shfl_xor(a1, o);
+            const int oi0 = __shfl_xor(b0, o), oi1 = __shfl_xor(b1, o);
+            top2_insert(od0, oi0, a0, b0, a1, b1);
+            top2_insert(od1, oi1, a0, b0, a1, b1);
+        }
+        const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, q = q0 + row;
+        if (r == 0 && q < Q.n) {
+            const size_t o = ((size_t)blockIdx.y * Q.n + q) * 2;
+            part_idx[o] = b0; part_idx[o + 1] = b1;
+            part_e[o] = a0; part_e[o + 1] = a1;
+        }
+    }
+}
+
+// merge of the train slices of one query set: top two by (e, index), then distance = sqrt(|q|^2 + e)
+__global__ __launch_bounds__(256) void l2_merge_kernel(L2Set Q, int slices, const int* __restrict__ part_idx, const float* __restrict__ part_e, int* __restrict__ idx2,
+                                                      float* __restrict__ dist2) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q.n) return;
+    float d0 = 3.0e38f, d1 = 3.0e38f;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int s = 0; s < slices; s++) {
+        const size_t o = ((size_t)s * Q.n + q) * 2;
+        top2_insert(part_e[o], part_idx[o], d0, i0, d1, i1);
+        top2_insert(part_e[o + 1], part_idx[o + 1], d0, i0, d1, i1);
+    }
+    const float qn = Q.nrm[q];
+    idx2[2 * (size_t)q] = i0 == 0x7fffffff ? -1 : i0; idx2[2 * (size_t)q + 1] = i1 == 0x7fffffff ? -1 : i1;
+    dist2[2 * (size_t)q] = i0 == 0x7fffffff ? sqrtf(3.0e38f) : sqrtf(qn + d0);
+    dist2[2 * (size_t)q + 1] = i1 == 0x7fffffff ? sqrtf(3.0e38f) : sqrtf(qn + d1);
+}
+
+// launches the sliced distance pass + merge for one directed pair; `part` holds 2 * slices * Q.n (int + float)
+static void l2_knn2_launch(hipStream_t st, int num_cu, const L2Set& Q, const L2Set& T, void* part, int* idx2, float* dist2) {
+    const int qblocks = (Q.n + 127) / 128, ntiles = (T.n + L2_TB - 1) / L2_TB;
+    int slices = std::max(1, std::min({(4 * num_cu + qblocks - 1) / qblocks, ntiles / 16, L2_MAX_SLICES}));   // >= 16 tiles per slice
+    if (slices < 1) slices = 1;
+    const int tiles_per_slice = (ntiles + slices - 1) / slices;
+    slices = (ntiles + tiles_per_slice - 1) / tiles_per_slice;
+    int* pi = (int*)part;
+    float* pe = (float*)(pi + (size_t)2 * L2_MAX_SLICES * Q.n);
+    hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3(qblocks, slices), dim3(256), 0, st, Q, T, tiles_per_slice, pi, pe);
+    hipLaunchKernelGGL(l2_merge_kernel, dim3((Q.n + 255) / 256), dim3(256), 0, st, Q, slices, (const int*)pi, (const float*)pe, idx2, dist2);
 }
 
 // ---------------------------------------------------------------- ratio test + union ----------
@@ -414,6 +480,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         Carver lc;
         for (int i = 0; i < n; i++) { hoff[i] = lc.take((size_t)std::max(feats[i].n, 1) * 256); noff[i] = lc.take((size_t)std::max(feats[i].n, 1) * 4); }
         const size_t o_bad = lc.take(4);
+        const size_t o_part = lc.take((size_t)16 * L2_MAX_SLICES * std::max(maxq, 1));   // slice results of one directed pair (stream ordered reuse)
         MIS_HIP(ctx, ws->l2.reserve(lc.off));
         uint8_t* L = (uint8_t*)ws->l2.p;
         MIS_HIP(ctx, hipMemsetAsync(L + o_bad, 0, 4, st));
@@ -423,8 +490,8 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
                                    feats[i].desc_cols, (_Float16*)(L + hoff[i]), (float*)(L + noff[i]), (int*)(L + o_bad));
         for (const PairDesc& pd : pairs) {
             L2Set A{(const _Float16*)(L + hoff[pd.i]), (const float*)(L + noff[pd.i]), feats[pd.i].n}, B{(const _Float16*)(L + hoff[pd.j]), (const float*)(L + noff[pd.j]), feats[pd.j].n};
-            hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((A.n + 63) / 64), dim3(256), 0, st, A, B, d_idx + 2 * pd.knn_off12, d_dist + 2 * pd.knn_off12);
-            hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((B.n + 63) / 64), dim3(256), 0, st, B, A, d_idx + 2 * pd.knn_off21, d_dist + 2 * pd.knn_off21);
+            l2_knn2_launch(st, ctx->num_cu, A, B, L + o_part, d_idx + 2 * pd.knn_off12, d_dist + 2 * pd.knn_off12);
+            l2_knn2_launch(st, ctx->num_cu, B, A, L + o_part, d_idx + 2 * pd.knn_off21, d_dist + 2 * pd.knn_off21);
         }
         MIS_HIP(ctx, hipMemcpyAsync(&l2_bad, L + o_bad, 4, hipMemcpyDeviceToHost, st));
     }
@@ -532,6 +599,7 @@ extern "C" int mis_knn2(MisContext* ctx, const MisFeatures* q, const MisFeatures
     Carver dc;
     const size_t o_feats = dc.take(2 * sizeof(FeatDev)), o_pairs = dc.take(sizeof(PairDesc)), o_idx = dc.take(sizeof(int) * 2 * nq), o_dist = dc.take(sizeof(float) * 2 * nq);
     const size_t o_qh = dc.take(nq * 256), o_th = dc.take(nt * 256), o_qn = dc.take(nq * 4), o_tn = dc.take(nt * 4), o_bad = dc.take(4);
+    const size_t o_part = dc.take((size_t)16 * L2_MAX_SLICES * nq);
     MIS_HIP(ctx, ws->dev.reserve(dc.off));
     uint8_t* D = (uint8_t*)ws->dev.p;
     int bad = 0;
@@ -553,7 +621,7 @@ extern "C" int mis_knn2(MisContext* ctx, const MisFeatures* q, const MisFeatures
             hipLaunchKernelGGL(l2_prep_kernel, dim3((t->n + 3) / 4), dim3(256), 0, st, (const float*)t->descriptors, t->n, t->desc_cols, (_Float16*)(D + o_th),
                                (float*)(D + o_tn), (int*)(D + o_bad));
         L2Set Q{(const _Float16*)(D + o_qh), (const float*)(D + o_qn), q->n}, T{(const _Float16*)(D + o_th), (const float*)(D + o_tn), std::max(t->n, 0)};
-        hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3((q->n + 63) / 64), dim3(256), 0, st, Q, T, (int*)(D + o_idx), (float*)(D + o_dist));
+        l2_knn2_launch(st, ctx->num_cu, Q, T, D + o_part, (int*)(D + o_idx), (float*)(D + o_dist));
         MIS_HIP(ctx, hipMemcpyAsync(&bad, D + o_bad, 4, hipMemcpyDeviceToHost, st));
     }
     MIS_HIP(ctx, hipGetLastError());
