@@ -83,22 +83,77 @@ __global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t* __res
     dst[(size_t)y * dw + x] = h0 * b0 + h1 * b1;
 }
 
-// separable Gaussian, BORDER_REFLECT_101, taps accumulated in ascending order
-template <bool COLS>
-__global__ __launch_bounds__(256) void sift_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Taps t) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const int r = t.n / 2;
-    float acc = 0;
-    if (!COLS) {
-        const float* row = src + (size_t)y * w;
-        if (x >= r && x + r < w) for (int k = 0; k < t.n; k++) acc += t.k[k] * row[x + k - r];
-        else for (int k = 0; k < t.n; k++) acc += t.k[k] * row[mis_reflect101(x + k - r, w)];
+// separable Gaussian, BORDER_REFLECT_101, taps accumulated in ascending order (the CPU path's order).  A thread
+// produces BLK consecutive outputs along the filtered axis from BLK + N - 1 loads; with N a template parameter the
+// tap index tests fold away.  N = 0: generic tap count (t.n).  The column pass optionally writes the DoG image
+// (this layer minus the previous one) as well, saving a pass over both.
+constexpr int BLK = 8;
+template <int N>
+__global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Taps t) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * BLK, y = blockIdx.y;
+    if (x0 >= w) return;
+    const int n = N ? N : t.n, r = n / 2;
+    const float* row = src + (size_t)y * w;
+    float acc[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) acc[j] = 0.f;
+    const bool inner = x0 - r >= 0 && x0 + BLK - 1 + r < w;
+    if (N) {
+#pragma unroll
+        for (int k = 0; k < N + BLK - 1; k++) {
+            const int xs = x0 + k - r;
+            const float v = inner ? row[xs] : row[mis_reflect101(xs, w)];
+#pragma unroll
+            for (int j = 0; j < BLK; j++)
+                if (k - j >= 0 && k - j < N) acc[j] += t.k[k - j] * v;
+        }
     } else {
-        if (y >= r && y + r < h) for (int k = 0; k < t.n; k++) acc += t.k[k] * src[(size_t)(y + k - r) * w + x];
-        else for (int k = 0; k < t.n; k++) acc += t.k[k] * src[(size_t)mis_reflect101(y + k - r, h) * w + x];
+        for (int k = 0; k < n + BLK - 1; k++) {
+            const float v = row[mis_reflect101(x0 + k - r, w)];
+#pragma unroll
+            for (int j = 0; j < BLK; j++)
+                if (k - j >= 0 && k - j < n) acc[j] += t.k[k - j] * v;
+        }
     }
-    dst[(size_t)y * w + x] = acc;
+#pragma unroll
+    for (int j = 0; j < BLK; j++)
+        if (x0 + j < w) dst[(size_t)y * w + x0 + j] = acc[j];
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Taps t,
+                                                            const float* __restrict__ prev, float* __restrict__ dog) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * BLK;
+    if (x >= w) return;
+    const int n = N ? N : t.n, r = n / 2;
+    float acc[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) acc[j] = 0.f;
+    const bool inner = y0 - r >= 0 && y0 + BLK - 1 + r < h;
+    if (N) {
+#pragma unroll
+        for (int k = 0; k < N + BLK - 1; k++) {
+            const int ys = y0 + k - r;
+            const float v = src[(size_t)(inner ? ys : mis_reflect101(ys, h)) * w + x];
+#pragma unroll
+            for (int j = 0; j < BLK; j++)
+                if (k - j >= 0 && k - j < N) acc[j] += t.k[k - j] * v;
+        }
+    } else {
+        for (int k = 0; k < n + BLK - 1; k++) {
+            const float v = src[(size_t)mis_reflect101(y0 + k - r, h) * w + x];
+#pragma unroll
+            for (int j = 0; j < BLK; j++)
+                if (k - j >= 0 && k - j < n) acc[j] += t.k[k - j] * v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; j++)
+        if (y0 + j < h) {
+            const size_t o = (size_t)(y0 + j) * w + x;
+            dst[o] = acc[j];
+            if (dog) dog[o] = acc[j] - prev[o];
+        }
 }
 
 __global__ __launch_bounds__(256) void sift_sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d, size_t n) {
@@ -255,14 +310,17 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, co
     }
 }
 
-// calcSIFTDescriptor: one thread per keypoint, the (d+2)(d+2)(n+2) histogram in LDS (sequential float sums)
-constexpr int DESC_TPB = 32, HISTLEN = 6 * 6 * 10;
-__global__ __launch_bounds__(DESC_TPB) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, int nk, float* __restrict__ desc) {
-    __shared__ float hist_all[HISTLEN * DESC_TPB];
-    const int q = blockIdx.x * DESC_TPB + threadIdx.x;
-    if (q >= nk) return;
-    float* hist = hist_all + threadIdx.x;   // element e at hist[e * DESC_TPB]: conflict-free across the threads
-#define HS(e) hist[(e) * DESC_TPB]
+// calcSIFTDescriptor: one wave per keypoint.  The float sums into the (d+2)(d+2)(n+2) histogram are order
+// dependent, so the CPU's order is kept: samples are evaluated 64 at a time in raster order (one per lane: gradient,
+// exp weight, atan2, trilinear split), compacted in that order, and then lanes 0..7 -- one per trilinear corner --
+// walk the compacted samples sequentially.  The 8 corners of one sample are 8 distinct bins, and a wave's LDS
+// operations execute in program order, so every bin receives its contributions in sample order.
+constexpr int HISTLEN = 6 * 6 * 10;
+__global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, int nk, float* __restrict__ desc) {
+    __shared__ float hist[HISTLEN];
+    __shared__ int s_idx[64];
+    __shared__ float s_val[64 * 8];
+    const int q = blockIdx.x, lane = threadIdx.x;
     const int d = 4, n = 8, nl = P.nl, firstOctave = -1;
     const MisKeyPoint k = kps[q];
     int octave = k.octave & 255;
@@ -283,56 +341,82 @@ __global__ __launch_bounds__(DESC_TPB) void sift_descriptor_kernel(Pyr P, const 
     const int rmax = (int)sqrt((double)w * w + (double)h * h);
     if (radius > rmax) radius = rmax;
     cos_t /= hist_width; sin_t /= hist_width;
-    for (int e = 0; e < HISTLEN; e++) HS(e) = 0.f;
-    for (int i = -radius; i <= radius; i++)
-        for (int j = -radius; j <= radius; j++) {
+    for (int e = lane; e < HISTLEN; e += 64) hist[e] = 0.f;
+    __syncthreads();
+    const int side = 2 * radius + 1;
+    const long long total = (long long)side * side;
+    // offsets of the 8 trilinear corners from the base bin: (r, c, o) in {0,1}^3, o fastest
+    const int corner_off = ((lane >> 2) & 1) * (d + 2) * (n + 2) + ((lane >> 1) & 1) * (n + 2) + (lane & 1);
+    volatile float* vh = hist;
+    for (long long base = 0; base < total; base += 64) {
+        const long long kk = base + lane;
+        bool valid = false;
+        int idx = 0;
+        float v[8];
+        if (kk < total) {
+            const int i = (int)(kk / side) - radius, j = (int)(kk % side) - radius;
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
-            const float dx = AT(img, r, c + 1) - AT(img, r, c - 1), dy = AT(img, r - 1, c) - AT(img, r + 1, c);
-            const float wgt = mis_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            float obin = (mis_fast_atan2(dy, dx) - ori) * bins_per_rad;
-            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-            const int r0 = mis_floor_f(rbin), c0 = mis_floor_f(cbin);
-            int o0 = mis_floor_f(obin);
-            rbin -= r0; cbin -= c0; obin -= o0;
-            if (o0 < 0) o0 += n;
-            if (o0 >= n) o0 -= n;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            HS(idx) += v_rco000; HS(idx + 1) += v_rco001;
-            HS(idx + (n + 2)) += v_rco010; HS(idx + (n + 3)) += v_rco011;
-            HS(idx + (d + 2) * (n + 2)) += v_rco100; HS(idx + (d + 2) * (n + 2) + 1) += v_rco101;
-            HS(idx + (d + 3) * (n + 2)) += v_rco110; HS(idx + (d + 3) * (n + 2) + 1) += v_rco111;
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
+                valid = true;
+                const float dx = AT(img, r, c + 1) - AT(img, r, c - 1), dy = AT(img, r - 1, c) - AT(img, r + 1, c);
+                const float wgt = mis_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                float obin = (mis_fast_atan2(dy, dx) - ori) * bins_per_rad;
+                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+                const int r0 = mis_floor_f(rbin), c0 = mis_floor_f(cbin);
+                int o0 = mis_floor_f(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7]; v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
+                v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3]; v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
+                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            }
         }
-    float* dst = desc + 128 * (size_t)q;
-    float nrm2 = 0;
-    for (int i = 0; i < d; i++)
-        for (int j = 0; j < d; j++) {
-            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            HS(idx) += HS(idx + n);
-            HS(idx + 1) += HS(idx + n + 1);
-            for (int kk = 0; kk < n; kk++) { const float v = HS(idx + kk); dst[(i * d + j) * n + kk] = v; nrm2 += v * v; }
+        const unsigned long long bal = __ballot(valid);
+        const int slot = __popcll(bal & ((1ull << lane) - 1ull)), cnt = __popcll(bal);
+        if (valid) {
+            s_idx[slot] = idx;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; c8++) s_val[slot * 8 + c8] = v[c8];
         }
-    const int len = d * d * n;
-    const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
-    nrm2 = 0;
-    for (int kk = 0; kk < len; kk++) {
-        const float val = dst[kk] < thr ? dst[kk] : thr;
-        dst[kk] = val;
-        nrm2 += val * val;
+        __syncthreads();
+        if (lane < 8) {
+            for (int sI = 0; sI < cnt; sI++) {
+                const int b = s_idx[sI] + corner_off;
+                vh[b] = vh[b] + s_val[sI * 8 + lane];
+            }
+        }
+        __syncthreads();
     }
-    const float root = sqrtf(nrm2);
-    nrm2 = SIFT_INT_DESCR_FCTR / (root > FLT_EPSILON ? root : FLT_EPSILON);
-    for (int kk = 0; kk < len; kk++) {
-        const int v = mis_round_f(dst[kk] * nrm2);   // saturate_cast<uchar>
-        dst[kk] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    if (lane == 0) {
+        float* dst = desc + 128 * (size_t)q;
+        float nrm2 = 0;
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) {
+                const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+                hist[idx] += hist[idx + n];
+                hist[idx + 1] += hist[idx + n + 1];
+                for (int kk = 0; kk < n; kk++) { const float v = hist[idx + kk]; dst[(i * d + j) * n + kk] = v; nrm2 += v * v; }
+            }
+        const int len = d * d * n;
+        const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
+        nrm2 = 0;
+        for (int kk = 0; kk < len; kk++) {
+            const float val = dst[kk] < thr ? dst[kk] : thr;
+            dst[kk] = val;
+            nrm2 += val * val;
+        }
+        const float root = sqrtf(nrm2);
+        nrm2 = SIFT_INT_DESCR_FCTR / (root > FLT_EPSILON ? root : FLT_EPSILON);
+        for (int kk = 0; kk < len; kk++) {
+            const int v = mis_round_f(dst[kk] * nrm2);   // saturate_cast<uchar>
+            dst[kk] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
     }
-#undef HS
 }
 
 bool kp_less(const MisKeyPoint& a, const MisKeyPoint& b) {   // KeyPoint_LessThan of KeyPointsFilter::removeDuplicatedSorted
@@ -439,11 +523,23 @@ extern "C" int mis_sift_destroy(MisSift* s) {
     return MIS_OK;
 }
 
-static void blur(MisSift* s, const float* src, float* dst, int w, int h, double sigma) {
+// GaussianBlur(src -> dst); with prev / dog set, dog = dst - prev is written by the column pass too
+static void blur(MisSift* s, const float* src, float* dst, int w, int h, double sigma, const float* prev = nullptr, float* dog = nullptr) {
     const Taps t = gaussian_taps(sigma);
-    dim3 grid((w + 255) / 256, h), block(256);
-    hipLaunchKernelGGL(sift_blur_kernel<false>, grid, block, 0, s->ctx->stream, src, s->tmp, w, h, t);
-    hipLaunchKernelGGL(sift_blur_kernel<true>, grid, block, 0, s->ctx->stream, (const float*)s->tmp, dst, w, h, t);
+    hipStream_t st = s->ctx->stream;
+    const dim3 grows(((w + BLK - 1) / BLK + 255) / 256, h), gcols((w + 255) / 256, (h + BLK - 1) / BLK), block(256);
+#define MIS_BLUR_CASE(NN)                                                                                                                        \
+    case NN:                                                                                                                                     \
+        hipLaunchKernelGGL(sift_blur_rows_kernel<NN>, grows, block, 0, st, src, s->tmp, w, h, t);                                                \
+        hipLaunchKernelGGL(sift_blur_cols_kernel<NN>, gcols, block, 0, st, (const float*)s->tmp, dst, w, h, t, prev, dog);                       \
+        break;
+    switch (t.n) {
+        MIS_BLUR_CASE(11) MIS_BLUR_CASE(13) MIS_BLUR_CASE(17) MIS_BLUR_CASE(21) MIS_BLUR_CASE(25)   // the taps of SIFT::create()'s sigmas
+        default:
+            hipLaunchKernelGGL(sift_blur_rows_kernel<0>, grows, block, 0, st, src, s->tmp, w, h, t);
+            hipLaunchKernelGGL(sift_blur_cols_kernel<0>, gcols, block, 0, st, (const float*)s->tmp, dst, w, h, t, prev, dog);
+    }
+#undef MIS_BLUR_CASE
 }
 
 // scale space of one image (everything up to and including the DoG pyramid)
@@ -465,13 +561,9 @@ static int sift_build(MisSift* s, const MisImage* bgr, const DevImage& din) {
             if (i == 0)
                 hipLaunchKernelGGL(sift_decimate_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, st, (const float*)P.gauss[(o - 1) * (nl + 3) + nl], P.w[o - 1],
                                    P.h[o - 1], dst, ow, oh);
-            else
-                blur(s, P.gauss[o * (nl + 3) + i - 1], dst, ow, oh, s->sig[i]);
+            else   // the column pass also writes dog[i - 1] = gauss[i] - gauss[i - 1]
+                blur(s, P.gauss[o * (nl + 3) + i - 1], dst, ow, oh, s->sig[i], P.gauss[o * (nl + 3) + i - 1], P.dog[o * (nl + 2) + i - 1]);
         }
-        const size_t n = (size_t)ow * oh;
-        for (int i = 0; i < nl + 2; i++)
-            hipLaunchKernelGGL(sift_sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)P.gauss[o * (nl + 3) + i],
-                               (const float*)P.gauss[o * (nl + 3) + i + 1], P.dog[o * (nl + 2) + i], n);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -539,7 +631,7 @@ extern "C" int mis_sift_detect(MisSift* s, const MisImage* bgr, MisFeatures* out
     if (nk) {
         MIS_HIP(ctx, hipMemcpyAsync(out->keypoints, kp.data(), sizeof(MisKeyPoint) * (size_t)nk, hipMemcpyHostToDevice, st));
         MIS_HIP(ctx, hipStreamSynchronize(st));   // kp is a local vector
-        hipLaunchKernelGGL(sift_descriptor_kernel, dim3((nk + DESC_TPB - 1) / DESC_TPB), dim3(DESC_TPB), 0, st, P, (const MisKeyPoint*)out->keypoints, nk,
+        hipLaunchKernelGGL(sift_descriptor_kernel, dim3(nk), dim3(64), 0, st, P, (const MisKeyPoint*)out->keypoints, nk,
                            (float*)out->descriptors);
         MIS_HIP(ctx, hipGetLastError());
     }
