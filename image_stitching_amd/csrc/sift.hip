@@ -534,7 +534,7 @@ static void blur(MisSift* s, const float* src, float* dst, int w, int h, double 
         hipLaunchKernelGGL(sift_blur_cols_kernel<NN>, gcols, block, 0, st, (const float*)s->tmp, dst, w, h, t, prev, dog);                       \
         break;
     switch (t.n) {
-        MIS_BLUR_CASE(11) MIS_BLUR_CASE(13) MIS_BLUR_CASE(17) MIS_BLUR_CASE(21) MIS_BLUR_CASE(25)   // the taps of SIFT::create()'s sigmas
+        MIS_BLUR_CASE(11) MIS_BLUR_CASE(13) MIS_BLUR_CASE(17) MIS_BLUR_CASE(21) MIS_BLUR_CASE(27)   // the tap counts of SIFT::create()'s sigmas
         default:
             hipLaunchKernelGGL(sift_blur_rows_kernel<0>, grows, block, 0, st, src, s->tmp, w, h, t);
             hipLaunchKernelGGL(sift_blur_cols_kernel<0>, gcols, block, 0, st, (const float*)s->tmp, dst, w, h, t, prev, dog);
