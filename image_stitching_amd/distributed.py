@@ -41,23 +41,35 @@ def frame_block(n, rank, world):
 
 
 class Comm:
-    """Thin wrapper over torch.distributed (nccl = RCCL on GPUs, gloo on CPU); identity when world = 1."""
+    """Thin wrapper over torch.distributed (nccl = RCCL on GPUs, gloo on CPU); identity when world = 1.
+    With the gloo backend device tensors are staged through host memory (rehearsals of the N > 1 path on one GPU)."""
 
     def __init__(self, rank=0, world=1, group=None):
         self.rank, self.world, self.group = rank, world, group
+        self._stage = False
+        if world > 1:
+            import torch.distributed as dist
+            self._stage = dist.get_backend(group) == "gloo"
+
+    def _h(self, t):
+        return t.cpu() if (self._stage and t.is_cuda) else t
 
     def all_gather(self, t):
         if self.world == 1:
             return t.unsqueeze(0)
         import torch.distributed as dist
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
-        return out
+        src = self._h(t).contiguous()
+        out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out.view(-1), src.view(-1), group=self.group)
+        return out.to(t.device)
 
     def all_reduce_sum(self, t):
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            h = self._h(t)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            if h is not t:
+                t.copy_(h)
         return t
 
     def gather_to_root(self, t):
@@ -65,9 +77,10 @@ class Comm:
         if self.world == 1:
             return [t]
         import torch.distributed as dist
-        bufs = [torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(t, bufs, dst=0, group=self.group)
-        return bufs
+        h = self._h(t)
+        bufs = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(h, bufs, dst=0, group=self.group)
+        return [b.to(t.device) for b in bufs] if bufs is not None else None
 
 
 class _DevArray:
