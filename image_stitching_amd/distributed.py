@@ -106,6 +106,11 @@ class HipEngine:
         self.matcher = st.BestOf2NearestMatcher(ctx, self.cfg.match_conf)
         self.blender = None
         self._keep = []
+        # warp + blend run in a context of their own (second stream): StitchJob composes speculatively while the
+        # latency-bound RANSAC chains of the matcher leave most of the device idle
+        self.compose_stream = torch.cuda.Stream(device=ctx.device)
+        self.cctx = st.Context(ctx.device.index, stream=self.compose_stream.cuda_stream)
+        self.speculative_compose = True
 
     # ---- features ----
     def detect(self, frames):
@@ -161,11 +166,13 @@ class HipEngine:
     def begin_compose(self, scale, corners, sizes):
         x, y, pw, ph = st.result_roi(corners, sizes)
         btype, bands, sharp = st.blend_config(self.cfg.blend_type, self.cfg.blend_strength, (pw, ph))
-        if self.blender is None or self.blender.type != btype:
-            self.blender = {capi.BLEND_MULTI_BAND: lambda: st.MultiBandBlender(self.ctx, bands),
-                            capi.BLEND_FEATHER: lambda: st.FeatherBlender(self.ctx, sharp), capi.BLEND_NO: lambda: st.Blender(self.ctx)}[btype]()
+        key = (btype, bands, sharp)
+        if self.blender is None or getattr(self, "_blender_key", None) != key:   # band count / sharpness are creation parameters
+            self._blender_key = key
+            self.blender = {capi.BLEND_MULTI_BAND: lambda: st.MultiBandBlender(self.cctx, bands),
+                            capi.BLEND_FEATHER: lambda: st.FeatherBlender(self.cctx, sharp), capi.BLEND_NO: lambda: st.Blender(self.cctx)}[btype]()
         self.blender.prepare(corners, sizes)
-        self.warper = st.SphericalWarper(self.ctx, scale)
+        self.warper = st.SphericalWarper(self.cctx, scale)
         self.pano_size = (pw, ph)
         return btype, bands
 
@@ -180,7 +187,7 @@ class HipEngine:
         nb = self.ctx.lib.mis_blender_num_bands(self.blender.h)
         for l in range(nb + 1):
             w, h, lp, wp = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
-            self.ctx.check(self.ctx.lib.mis_blender_level_info(self.blender.h, l, C.byref(w), C.byref(h), C.byref(lp), C.byref(wp)))
+            self.cctx.check(self.cctx.lib.mis_blender_level_info(self.blender.h, l, C.byref(w), C.byref(h), C.byref(lp), C.byref(wp)))
             out.append((dev_tensor(lp.value, (h.value, w.value * 3), "<i2", dev), dev_tensor(wp.value, (h.value, w.value), "<f4", dev)))
         return out
 
@@ -338,13 +345,48 @@ class StitchJob:
         return None, None
 
     # -- whole job ---------------------------------------------------------------------------
+    def _compose_on_side_stream(self, frames, indices):
+        """stage_compose with the engine's compose stream current (allocations and launches belong to it)."""
+        eng = self.engine
+        with torch.cuda.stream(eng.compose_stream):
+            return self.stage_compose(frames, indices)
+
     def run(self, frames):
         feats = self.stage_gather(self.stage_features(frames))
-        pm, conf = self.stage_match(feats)
-        indices = self.stage_prune(conf)
-        btype, bands = self.stage_compose(frames, indices)
-        self.stage_reduce()
-        pano, mask = self.stage_finalize()
+        spec = getattr(self.engine, "speculative_compose", False)
+        if spec:
+            # Speculation: almost always every frame survives the pruning, and warp + blend do not depend on the
+            # matches otherwise (the cameras are inputs).  Compose for ALL frames on the second stream from a helper
+            # thread (the library calls release the GIL) while the matcher runs; redo it if a frame was dropped.
+            import threading
+            everyone = list(range(self.n))
+            box = {}
+
+            def work():
+                try:
+                    box["r"] = self._compose_on_side_stream(frames, everyone)
+                except BaseException as e:   # re-raised on the caller's thread
+                    box["e"] = e
+            th = threading.Thread(target=work)
+            th.start()
+            try:
+                pm, conf = self.stage_match(feats)
+                indices = self.stage_prune(conf)
+            finally:
+                th.join()
+            if "e" in box:
+                raise box["e"]
+            btype, bands = box["r"] if indices == everyone else self._compose_on_side_stream(frames, indices)
+            self.engine.compose_stream.synchronize()     # the accumulators are complete before any exchange
+            with torch.cuda.stream(self.engine.compose_stream):
+                self.stage_reduce()
+                pano, mask = self.stage_finalize()
+        else:
+            pm, conf = self.stage_match(feats)
+            indices = self.stage_prune(conf)
+            btype, bands = self.stage_compose(frames, indices)
+            self.stage_reduce()
+            pano, mask = self.stage_finalize()
         self.engine.sync()      # the job's results are complete when run() returns
         return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,
                 "pano_size": self.engine.pano_size, "num_bands": bands}
@@ -365,7 +407,14 @@ class StitchJob:
             feats = timed("feature all-gather", lambda: self.stage_gather(lf))
             pm, conf = timed("match + RANSAC", lambda: self.stage_match(feats))
             idx = timed("prune (host)", lambda: self.stage_prune(conf))
-            timed("warp + blend feed", lambda: self.stage_compose(frames, idx))
-            timed("pyramid reduce", lambda: self.stage_reduce())
-            timed("blend finalise", lambda: self.stage_finalize())
+            side = getattr(self.engine, "compose_stream", None)
+
+            def on_side(fn):
+                if side is None:
+                    return fn()
+                with torch.cuda.stream(side):
+                    return fn()
+            timed("warp + blend feed", lambda: on_side(lambda: self.stage_compose(frames, idx)))
+            timed("pyramid reduce", lambda: on_side(self.stage_reduce))
+            timed("blend finalise", lambda: on_side(self.stage_finalize))
         return out

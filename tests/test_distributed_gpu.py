@@ -123,3 +123,25 @@ def test_two_ranks_on_one_gpu_match_single_rank(ctx, tmp_path):
     assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
     d = np.abs(got["pano"].astype(np.int32) - ref["pano"].cpu().numpy().astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.02          # f32 weight sums in a different order where >= 3 frames overlap
+
+
+@pytest.mark.parametrize("stray", [False, True])
+def test_speculative_compose_equals_sequential(ctx, stray):
+    """The job composes all frames on a second stream while the matcher runs; when the pruning drops a frame
+    (stray = True: one camera looks elsewhere) the composition is redone -- either way the result equals the
+    sequential order of the reference's main()."""
+    import torch
+    import synth
+    from image_stitching_amd.distributed import StitchJob
+    w, h = 480, 270
+    yaws = [-20.0, -7.0, 6.0, 140.0 if stray else 19.0]
+    cams = [synth.make_camera(w, h, 60.0, y, 0.3 * ((i % 3) - 1)) for i, y in enumerate(yaws)]
+    frames = {i: torch.from_numpy(synth.render_frame(c)).cuda() for i, c in enumerate(cams)}
+    seq_job = StitchJob(ctx, (w, h), cams)
+    seq_job.engine.speculative_compose = False
+    seq = seq_job.run(frames)
+    spec = StitchJob(ctx, (w, h), cams).run(frames)
+    assert spec["indices"] == seq["indices"] == ([0, 1, 2] if stray else [0, 1, 2, 3])
+    assert spec["pano_size"] == seq["pano_size"]
+    assert torch.equal(spec["pano"], seq["pano"]) and torch.equal(spec["mask"], seq["mask"])
+    assert torch.equal(spec["confidence"], seq["confidence"])
