@@ -86,14 +86,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = None
     for _ in range(args.warmup):
-        step()
+        out = step()          # same object lifetimes as the timed loop: the allocators reach their steady state here
+    # the interpreter's cyclic garbage collector is paused for the timed region (as timeit does): a full collection
+    # walks every torch / ctypes object and costs ~40 ms, twice the step being measured
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
+    trace = [] if os.environ.get("BENCH_TRACE") else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         out = step()
+        if trace is not None:
+            trace.append((time.perf_counter() - ts) * 1e3)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if trace is not None:
+        log("per-step ms: " + " ".join("%.2f" % v for v in trace))
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")

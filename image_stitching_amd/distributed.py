@@ -157,7 +157,7 @@ class HipEngine:
         return self.matcher(feats, rank, world)
 
     def confidence_tensor(self, pm, n):
-        return torch.tensor([m.confidence for m in pm], dtype=torch.float64, device=self.ctx.device).view(n, n)
+        return torch.from_numpy(pm.confidences()).to(self.ctx.device).view(n, n)
 
     # ---- compose ----
     def warp_roi(self, scale, cam):

@@ -532,6 +532,43 @@ def _unpack_mi(mi):
     return out
 
 
+class PairwiseMatches:
+    """The n x n cv::detail::MatchesInfo table of one matcher call, kept in the library's C structs and converted to
+    MatchesInfo objects only when an entry is read (a job needs the confidences alone; converting 256 entries with their
+    match arrays costs more host time than the pruning they feed).  Behaves like a list."""
+
+    def __init__(self, ctx, mis, n):
+        self._ctx, self._mis, self.n = ctx, mis, n
+        self._cache = {}
+
+    def __len__(self):
+        return self.n * self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if i not in self._cache:
+            self._cache[i] = _unpack_mi(self._mis[i])
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def confidences(self):
+        """-> float64 array (n * n), row-major"""
+        return np.array([self._mis[i].confidence for i in range(len(self))], np.float64)
+
+    def __del__(self):
+        try:
+            if self._mis is not None and self._ctx.h:
+                self._ctx.lib.mis_matches_free(self._mis, self.n * self.n)
+            self._mis = None
+        except Exception:
+            pass
+
+
 def match_params(**kw):
     p = capi.MisMatchParams()
     capi.load().mis_match_default_params(C.byref(p))
@@ -560,9 +597,7 @@ class BestOf2NearestMatcher:
         else:
             rc = self.ctx.lib.mis_match_pairs_sharded(self.ctx.h, arr, n, C.byref(self.params), rank, world_size, mis)
         self.ctx.check(rc)
-        out = [_unpack_mi(mis[i]) for i in range(n * n)]
-        self.ctx.lib.mis_matches_free(mis, n * n)
-        return out
+        return PairwiseMatches(self.ctx, mis, n)
 
     def collectGarbage(self):
         pass
