@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
     ap.add_argument("--no-single-base", action="store_true", help="N > 1: skip the unsharded run of the same workload on rank 0")
     ap.add_argument("--roofline-launches", type=int, default=200)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the roofline leg (for a rocprofv3 --stats pass in which no other kernel overlaps the warp kernel)")
     return ap.parse_args()
 
 
@@ -87,6 +89,10 @@ def main():
         torch.cuda.synchronize()
 
     out = None
+    if args.roofline_only:
+        roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
+        print(json.dumps({"roofline": roof}), flush=True)
+        return
     for _ in range(args.warmup):
         out = step()          # same object lifetimes as the timed loop: the allocators reach their steady state here
     # the interpreter's cyclic garbage collector is paused for the timed region (as timeit does): a full collection

@@ -508,7 +508,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ void jacobi_eigen_coop(TailShared& S, const int n) {
+template <int n>
+__device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
     double* A = S.A; double* V = S.V; double* W = S.W;
     const int t = threadIdx.x;
     PROF_T0(pj);
@@ -538,15 +539,28 @@ __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
         wave_sync();
         const int maxIters = n * n * 30;
         if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
-            for (k = 0, mv = fabs(A[S.indR[0]]), i = 1; i < n - 1; i++) {
-                double val = fabs(A[n * i + S.indR[i]]);
-                if (mv < val) mv = val, k = i;
-            }
-            l = S.indR[k];
-            for (i = 1; i < n; i++) {
-                double val = fabs(A[n * S.indC[i] + i]);
-                if (mv < val) mv = val, k = S.indC[i], l = i;
-            }
+            // pivot search of the serial loop: all index loads, then all value loads, then the compare chain -- with n a
+            // template parameter the loops unroll and the (broadcast) LDS reads go out back to back
+            int ir[n], ic[n];
+            double rv[n], cv[n];
+#pragma unroll
+            for (i = 0; i < n - 1; i++) ir[i] = S.indR[i];
+#pragma unroll
+            for (i = 1; i < n; i++) ic[i] = S.indC[i];
+#pragma unroll
+            for (i = 0; i < n - 1; i++) rv[i] = fabs(A[n * i + ir[i]]);
+#pragma unroll
+            for (i = 1; i < n; i++) cv[i] = fabs(A[n * ic[i] + i]);
+            k = 0; mv = rv[0];
+#pragma unroll
+            for (i = 1; i < n - 1; i++)
+                if (mv < rv[i]) mv = rv[i], k = i;
+            l = 0;
+#pragma unroll
+            for (i = 0; i < n - 1; i++) l = (k == i) ? ir[i] : l;   // l = indR[k] without a dynamic register index
+#pragma unroll
+            for (i = 1; i < n; i++)
+                if (mv < cv[i]) mv = cv[i], k = ic[i], l = i;
             const double p = A[n * k + l];
             if (fabs(p) <= eps) break;  // uniform: every lane reads the same LDS words
             PROF_INC(1, 1);
@@ -572,17 +586,24 @@ __device__ void jacobi_eigen_coop(TailShared& S, const int n) {
                 const int idx = t < 2 ? k : l;
                 if ((t & 1) == 0) {
                     if (idx < n - 1) {
-                        for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
-                            double val = fabs(A[n * idx + i]);
-                            if (mv < val) mv = val, m = i;
-                        }
+                        // row idx, columns idx+1 .. n-1: fixed-count loop with a predicate (values loaded up front)
+                        double vals[n];
+#pragma unroll
+                        for (i = 1; i < n; i++) vals[i] = fabs(A[n * idx + min(max(i, idx + 1), n - 1)]);
+                        m = idx + 1; mv = -1.;
+#pragma unroll
+                        for (i = 1; i < n; i++)
+                            if (i > idx && mv < vals[i]) mv = vals[i], m = i;
                         S.indR[idx] = m;
                     }
                 } else if (idx > 0) {
-                    for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
-                        double val = fabs(A[n * i + idx]);
-                        if (mv < val) mv = val, m = i;
-                    }
+                    double vals[n];
+#pragma unroll
+                    for (i = 0; i < n - 1; i++) vals[i] = fabs(A[n * min(i, idx - 1) + idx]);
+                    m = 0; mv = -1.;
+#pragma unroll
+                    for (i = 0; i < n - 1; i++)
+                        if (i < idx && mv < vals[i]) mv = vals[i], m = i;
                     S.indC[idx] = m;
                 }
             }
@@ -668,7 +689,7 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
     __syncthreads();
     if (t < 81) { int j = t / 9, k = t % 9; if (k < j) S.A[j * 9 + k] = S.A[k * 9 + j]; }
     __syncthreads();
-    jacobi_eigen_coop(S, 9);
+    jacobi_eigen_coop<9>(S);
     if (t == 0) dlt_denormalise(S.V + 72, S.nrm, S.best);
     __syncthreads();
 }
@@ -731,7 +752,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
     for (int iter = 0;;) {
         if (t < 64) S.A[t] = (t / 8 == t % 8) ? A[t] + sc[4] * D[t / 8] : A[t];
         __syncthreads();
-        jacobi_eigen_coop(S, 8);
+        jacobi_eigen_coop<8>(S);
         if (t == 0) {
             // solve(Ap, v, d, DECOMP_EIG): Jacobi + SVBkSb back substitution
             double thrw = 0;
@@ -781,7 +802,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
             // invert(A, Ap, DECOMP_EIG) -> lambda = lc = 1 / max |diag|, nu halved
             if (t < 64) S.A[t] = A[t];
             __syncthreads();
-            jacobi_eigen_coop(S, 8);
+            jacobi_eigen_coop<8>(S);
             if (t == 0) {
                 double thrw = 0;
                 for (int i = 0; i < 8; i++) thrw += S.W[i];
