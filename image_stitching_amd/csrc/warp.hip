@@ -211,8 +211,13 @@ __device__ __forceinline__ void tile_trig(const WarpArgs& a, int tx0, int ty0, f
 //    LDS with direct global->LDS loads (16-byte pieces, several box rows per instruction, no staging
 //    registers), and gathers the 12 taps per pixel from LDS.  Tiles whose taps need BORDER_REFLECT fold
 //    the box once; boxes that do not fit take a global-memory gather (cold).
-constexpr int FT_W = 32, FT_H = 16;
-constexpr int STAGE_BYTES = 5120;  // 32 single-wave workgroups per CU fit the 160 KB of LDS
+#ifndef WV_LROWS
+#define WV_LROWS 4
+#endif
+constexpr int LROWS = WV_LROWS;          // rows per lane (4 lane rows per tile)
+constexpr int LPX = 2 * LROWS;            // pixels per lane
+constexpr int FT_W = 32, FT_H = 4 * LROWS;
+constexpr int STAGE_BYTES = 1280 * LROWS;  // LROWS = 4: 5 KB, 32 waves per CU fit the 160 KB of LDS
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __host__ __device__ __forceinline__ int trig_cols(int dw) { return (dw + 3) & ~1; }  // >= dw + 2, even: 16-byte aligned row table
@@ -341,7 +346,7 @@ __device__ unsigned g_warp_stats[8];   // tiles: interior, folded, global gather
 #endif
 // Everything a tile needs between its map phase and its sample phase (one lane's share in registers).
 struct TileState {
-    int xq[8], yq[8];   // q = 2 * row + column: 5 fraction bits below the (short-range) integer coordinate
+    int xq[LPX], yq[LPX];   // q = 2 * row + column: 5 fraction bits below the (short-range) integer coordinate
     unsigned msk;       // bit q: the nearest source pixel of pixel q lies inside the frame
     int gx, gy0;        // this lane's first column / row
     bool col_ok, two;
@@ -355,22 +360,22 @@ struct TileState {
 // The separable trig terms of a lane's 2 columns x 4 rows (prefetched one pipeline stage ahead of the map)
 struct TileTrig {
     float4 cs;      // {sin u0, cos u0, sin u1, cos u1}
-    float4 rt[4];   // per row {sin v, m1 cos v, m4 cos v, m7 cos v}
+    float4 rt[LROWS];   // per row {sin v, m1 cos v, m4 cos v, m7 cos v}
 };
 __device__ __forceinline__ void tile_trig(const WarpArgs& a, const float* __restrict__ tab, int tile, int ntx, int lane, TileTrig& g) {
     const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
-    const int gxr = tx0 + 2 * (lane & 15), gy0 = ty0 + 4 * (lane >> 4);
+    const int gxr = tx0 + 2 * (lane & 15), gy0 = ty0 + LROWS * (lane >> 4);
     const int gx = gxr < a.dw ? gxr : ((a.dw - 1) & ~1);
     g.cs = *reinterpret_cast<const float4*>(tab + 2 * gx);
     const float4* rowtab = reinterpret_cast<const float4*>(tab + 2 * trig_cols(a.dw));
 #pragma unroll
-    for (int i = 0; i < 4; i++) g.rt[i] = rowtab[min(gy0 + i, a.dh - 1)];  // rows past the roi shadow the last one
+    for (int i = 0; i < LROWS; i++) g.rt[i] = rowtab[min(gy0 + i, a.dh - 1)];  // rows past the roi shadow the last one
 }
 
 __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, int tile, int ntx, int lane, TileState& t) {
     const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
     const int lx = lane & 15, ly = lane >> 4;
-    const int gxr = tx0 + 2 * lx, gy0 = ty0 + 4 * ly;
+    const int gxr = tx0 + 2 * lx, gy0 = ty0 + LROWS * ly;
     t.col_ok = gxr < a.dw; t.two = gxr + 1 < a.dw;
     const int gx = t.col_ok ? gxr : ((a.dw - 1) & ~1);  // out-of-roi lanes shadow the last column pair (never stored)
     t.gx = gx; t.gy0 = gy0;
@@ -380,12 +385,12 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
     const float xhi2 = xe ? __uint_as_float(__float_as_uint(xhi) + 1u) : xhi, yhi2 = ye ? __uint_as_float(__float_as_uint(yhi) + 1u) : yhi;
     const v2f su = {g.cs.x, g.cs.z}, cu = {g.cs.y, g.cs.w};
     int* xq = t.xq; int* yq = t.yq;
-    unsigned msk = 0xffu;
+    unsigned msk = (1u << LPX) - 1u;
     // ---- fast map: assumes z >= 2^-30 everywhere in the tile (checked below, wave-uniform) ----
     float zlo = 3.0e38f;
     const v2f k32 = {32.f, 32.f}, magic = {12582912.f, 12582912.f};   // 1.5 * 2^23: float add rounds to nearest-even integer
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < LROWS; i++) {
         v2f xx, yy, zz, qx, qy;
         map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
         div2_shared(xx, yy, zz, &qx, &qy);
@@ -400,7 +405,7 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
     auto reduce_box = [&]() {
         xmin = xq[0]; xmax = xq[0]; ymin = yq[0]; ymax = yq[0];
 #pragma unroll
-        for (int q = 1; q < 8; q++) {
+        for (int q = 1; q < LPX; q++) {
             xmin = min(xmin, xq[q]); xmax = max(xmax, xq[q]);
             ymin = min(ymin, yq[q]); ymax = max(ymax, yq[q]);
         }
@@ -417,7 +422,7 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
         WSTAT(3);
         msk = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < LROWS; i++) {
             v2f xx, yy, zz;
             map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
 #pragma unroll
@@ -435,7 +440,7 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
         // some taps leave the frame: the mask (nearest source pixel inside?) needs the unquantised coordinates again
         msk = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < LROWS; i++) {
             v2f xx, yy, zz, qx, qy;
             map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
             div2_shared(xx, yy, zz, &qx, &qy);
@@ -492,7 +497,7 @@ __device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileS
     uint8_t* drow = (uint8_t*)a.dst + (size_t)t.gy0 * a.dstride + (size_t)t.gx * 6;
     uint8_t* mrow = a.mask + (size_t)t.gy0 * a.mstride + t.gx;
 #pragma unroll
-    for (int i = 0; i < 4; i++, drow += a.dstride, mrow += a.mstride) {
+    for (int i = 0; i < LROWS; i++, drow += a.dstride, mrow += a.mstride) {
         if (t.gy0 + i >= a.dh) break;
         int p0[3], p1[3];
         if (t.staged && t.interior) {

@@ -141,3 +141,105 @@ def test_checkpoint_feeds_the_camera_dicts(tmp_path):
     back = [ser.camera_from_checkpoint(c, 3840, 2160) for c in ser.deserializeCameraParams(path)]
     for a, b in zip(cams, back):
         assert np.allclose(a["K"], b["K"], rtol=1e-5) and np.allclose(a["R"], b["R"], atol=1e-6)
+
+
+# ---- cropper (row N2; image_stitching/cropper.cpp) ------------------------------------------------------------
+def _cropper_tool():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "cropper_tool"])
+    return os.path.join(ROOT, "host", "cropper_tool")
+
+
+def _write_pgm(path, a):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+        f.write(np.ascontiguousarray(a, np.uint8).tobytes())
+
+
+def _read_pnm(path):
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = map(int, f.readline().split())
+        f.readline()
+        data = np.frombuffer(f.read(), np.uint8)
+    return data.reshape(h, w, 3)[..., ::-1] if magic == b"P6" else data.reshape(h, w)
+
+
+def _blob(seed, h=90, w=140):
+    """a smooth random blob with a hole and a detached speck"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ang = np.arctan2(yy - h / 2, xx - w / 2)
+    rad = np.hypot((yy - h / 2) / (0.42 * h), (xx - w / 2) / (0.42 * w))
+    wob = 1 + 0.12 * np.sin(3 * ang + rng.uniform(0, 6)) + 0.07 * np.sin(7 * ang + rng.uniform(0, 6))
+    m = (rad < wob).astype(np.uint8) * 255
+    m[h // 2 - 5:h // 2 + 5, w // 2 + 8:w // 2 + 20] = 0     # a hole
+    m[2:5, 3:7] = 255                                        # a speck
+    return m
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_external_contour_is_the_outer_border_and_fill_closes_holes(tmp_path, seed):
+    """Independent definitions (scipy.ndimage): the traced points are exactly the component's pixels with a 4-neighbour
+    in the outer background, consecutive points are 8-adjacent, and the fill equals the hole-filled component.
+    The C++ and Python implementations agree point for point."""
+    from scipy import ndimage as ndi
+    from image_stitching_amd import cropper as crp
+    tool = _cropper_tool()
+    m = _blob(seed)
+    src = str(tmp_path / "m.pgm")
+    _write_pgm(src, m)
+    lines = subprocess.check_output([tool, "contour", src]).decode().strip().split("\n")
+    cpp = [np.array(l.split()[1:], np.int64).reshape(-1, 2) for l in lines]
+    py = crp.findExternalContours(m)
+    assert len(cpp) == len(py) == 2
+    for a, b in zip(cpp, py):
+        assert np.array_equal(a, np.array(b))
+    big = max(cpp, key=len)
+    lab, _ = ndi.label(m > 0, structure=np.ones((3, 3)))
+    comp = lab == lab[big[0][1], big[0][0]]
+    bg, _ = ndi.label(np.pad(~(m > 0), 1, constant_values=True))          # 4-connected background, frame included
+    outer = (bg == bg[0, 0])[1:-1, 1:-1]
+    near = np.zeros_like(outer)
+    near[1:, :] |= outer[:-1, :]; near[:-1, :] |= outer[1:, :]; near[:, 1:] |= outer[:, :-1]; near[:, :-1] |= outer[:, 1:]
+    near[0, :] = near[-1, :] = True; near[:, 0] = near[:, -1] = True      # the frame counts as background
+    want = {(x, y) for y, x in zip(*np.nonzero(comp & near))}
+    assert {tuple(p) for p in big} == want
+    d = np.abs(np.diff(np.vstack([big, big[:1]]), axis=0))
+    assert d.max() == 1 and (d.sum(1) > 0).all()                          # closed 8-connected chain
+    out = str(tmp_path / "f.pgm")
+    subprocess.check_call([tool, "fill", src, out])
+    filled = _read_pnm(out)
+    assert np.array_equal(filled > 0, ndi.binary_fill_holes(comp))
+    assert np.array_equal(crp.fillContour(py[int(np.argmax([len(c) for c in py]))], m.shape[1], m.shape[0]), filled)
+
+
+def test_crop_known_answers_and_cross_language(tmp_path):
+    from image_stitching_amd import cropper as crp
+    tool = _cropper_tool()
+    # a solid rectangle: the first candidate (min/max of the contour) is accepted: x0, y0, (x1 - x0), (y1 - y0)
+    img = np.zeros((60, 100, 3), np.uint8)
+    img[10:50, 20:90] = (30, 200, 90)
+    out, rect = crp.crop(img)
+    assert rect == (20, 10, 69, 39) and out.shape == (39, 69, 3)
+    # a panorama-like outline (slanted sides): both implementations pick the same rectangle, its border is interior
+    yy, xx = np.mgrid[0:120, 0:300]
+    pano = ((xx > 20 + 0.25 * yy) & (xx < 280 - 0.15 * (120 - yy)) & (yy > 8 + 0.03 * xx) & (yy < 112 - 0.02 * xx))
+    img = np.zeros((120, 300, 3), np.uint8)
+    img[pano] = (90, 120, 200)
+    src, dst = str(tmp_path / "p.ppm"), str(tmp_path / "c.ppm")
+    with open(src, "wb") as f:
+        f.write(b"P6\n300 120\n255\n")
+        f.write(img[..., ::-1].tobytes())                                  # PPM is RGB; HostImage / the arrays are BGR
+    r = tuple(int(v) for v in subprocess.check_output([tool, "crop", src, dst]).split())
+    out, rect = crp.crop(img)
+    assert r == rect and np.array_equal(_read_pnm(dst), out)
+    x, y, w, h = rect
+    sub = pano[y:y + h, x:x + w]
+    assert sub[0].all() and sub[-1].all() and sub[:, 0].all() and sub[:, -1].all()
+    assert w * h > 0.6 * pano.sum()                                        # the heuristic keeps most of the area
+    # checkInteriorExterior's out-codes: most exterior pixels on top -> top
+    m = np.full((20, 30), 255, np.uint8)
+    m[0, 5:25] = 0
+    codes = dict(top=0, bottom=0, left=0, right=0)
+    assert crp.checkInteriorExterior(m, (0, 0, 30, 20), codes) is False and codes == dict(top=1, bottom=0, left=0, right=0)
+    assert crp.compareX((1, 9), (2, 0)) and not crp.compareY((1, 9), (2, 0))
