@@ -320,79 +320,103 @@ struct CSlot {
 
 // core/src/lapack.cpp JacobiImpl_<double> for n = 9; the algorithm only ever touches the strict upper
 // triangle and the diagonal (kept in w), eigenvectors are the rows of v, eigenvalues sorted descending
+// One thread = one 9 x 9 problem (JacobiImpl_ of lapack.cpp, the arithmetic and the visiting order of the serial
+// loops).  Written for latency: the two index tables are nibble-packed in registers (a per-thread array with a
+// dynamic index would live in scratch), and every data-dependent loop is a fixed-count loop with a predicate, so the
+// (conflict-free, slot-strided) LDS loads of a step go out back to back.
 __device__ void jacobi9_compact(const CSlot s) {
-    const int n = 9;
+    constexpr int n = 9;
     const double eps = DBL_EPSILON;
-    int i, j, k, m, indR[9], indC[9];
-    double mv;
-    for (i = 0; i < n; i++) { for (j = 0; j < n; j++) s.v(i * n + j) = 0; s.v(i * n + i) = 1; }
-    for (k = 0; k < n; k++) {
-        if (k < n - 1) {
-            for (m = k + 1, mv = fabs(s.u(k, m)), i = k + 2; i < n; i++) {
-                double val = fabs(s.u(k, i));
-                if (mv < val) mv = val, m = i;
-            }
-            indR[k] = m;
-        }
-        if (k > 0) {
-            for (m = 0, mv = fabs(s.u(0, k)), i = 1; i < k; i++) {
-                double val = fabs(s.u(i, k));
-                if (mv < val) mv = val, m = i;
-            }
-            indC[k] = m;
-        }
+    unsigned long long IR = 0, IC = 0;   // indR[k] / indC[k] in bits 4k .. 4k+3
+    auto get = [](unsigned long long t, int k) { return (int)((t >> (4 * k)) & 15ull); };
+    auto set = [](unsigned long long& t, int k, int v) { t = (t & ~(15ull << (4 * k))) | ((unsigned long long)v << (4 * k)); };
+    // max |u(idx, i)| over i in (idx, n): first maximum, as the serial scan
+    auto row_arg = [&](int idx) {
+        double vals[n];
+#pragma unroll
+        for (int i = 1; i < n; i++) vals[i] = fabs(s.u(idx, max(i, idx + 1)));
+        int m = idx + 1;
+        double mv = -1.;
+#pragma unroll
+        for (int i = 1; i < n; i++)
+            if (i > idx && mv < vals[i]) mv = vals[i], m = i;
+        return m;
+    };
+    // max |u(i, idx)| over i in [0, idx)
+    auto col_arg = [&](int idx) {
+        double vals[n];
+#pragma unroll
+        for (int i = 0; i < n - 1; i++) vals[i] = fabs(s.u(min(i, idx - 1), idx));
+        int m = 0;
+        double mv = -1.;
+#pragma unroll
+        for (int i = 0; i < n - 1; i++)
+            if (i < idx && mv < vals[i]) mv = vals[i], m = i;
+        return m;
+    };
+#pragma unroll
+    for (int i = 0; i < n * n; i++) s.v(i) = (i / n == i % n) ? 1. : 0.;
+#pragma unroll
+    for (int k = 0; k < n; k++) {
+        if (k < n - 1) set(IR, k, row_arg(k));
+        if (k > 0) set(IC, k, col_arg(k));
     }
     for (int iters = 0; iters < n * n * 30; iters++) {
-        for (k = 0, mv = fabs(s.u(0, indR[0])), i = 1; i < n - 1; i++) {
-            double val = fabs(s.u(i, indR[i]));
-            if (mv < val) mv = val, k = i;
-        }
-        int l = indR[k];
-        for (i = 1; i < n; i++) {
-            double val = fabs(s.u(indC[i], i));
-            if (mv < val) mv = val, k = indC[i], l = i;
-        }
-        double p = s.u(k, l);
+        // pivot: first maximum over the row candidates 0 .. n-2, then the column candidates 1 .. n-1
+        int ir[n], ic[n];
+        double rv[n], cvv[n];
+#pragma unroll
+        for (int i = 0; i < n - 1; i++) { ir[i] = get(IR, i); rv[i] = fabs(s.u(i, ir[i])); }
+#pragma unroll
+        for (int i = 1; i < n; i++) { ic[i] = get(IC, i); cvv[i] = fabs(s.u(ic[i], i)); }
+        int k = 0, l = ir[0];
+        double mv = rv[0];
+#pragma unroll
+        for (int i = 1; i < n - 1; i++)
+            if (mv < rv[i]) mv = rv[i], k = i, l = ir[i];
+#pragma unroll
+        for (int i = 1; i < n; i++)
+            if (mv < cvv[i]) mv = cvv[i], k = ic[i], l = i;
+        const double p = s.u(k, l);
         if (fabs(p) <= eps) break;
-        double y = (s.w(l) - s.w(k)) * 0.5;
+        const double y = (s.w(l) - s.w(k)) * 0.5;
         double t = fabs(y) + cv_hypot(p, y);
         double sn = cv_hypot(p, t);
-        double c = t / sn;
+        const double c = t / sn;
         sn = p / sn; t = (p / t) * p;
         if (y < 0) sn = -sn, t = -t;
         s.u(k, l) = 0;
         s.w(k) -= t; s.w(l) += t;
-        double a0, b0;
-#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
-        for (i = 0; i < k; i++) MIS_ROT(s.u(i, k), s.u(i, l));
-        for (i = k + 1; i < l; i++) MIS_ROT(s.u(k, i), s.u(i, l));
-        for (i = l + 1; i < n; i++) MIS_ROT(s.u(k, i), s.u(l, i));
-        for (i = 0; i < n; i++) MIS_ROT(s.v(n * k + i), s.v(n * l + i));
-#undef MIS_ROT
-        for (j = 0; j < 2; j++) {
-            int idx = j == 0 ? k : l;
-            if (idx < n - 1) {
-                for (m = idx + 1, mv = fabs(s.u(idx, m)), i = idx + 2; i < n; i++) {
-                    double val = fabs(s.u(idx, i));
-                    if (mv < val) mv = val, m = i;
-                }
-                indR[idx] = m;
-            }
-            if (idx > 0) {
-                for (m = 0, mv = fabs(s.u(0, idx)), i = 1; i < idx; i++) {
-                    double val = fabs(s.u(i, idx));
-                    if (mv < val) mv = val, m = i;
-                }
-                indC[idx] = m;
-            }
+        // rotate rows / columns k and l: element pairs (min(i,k), max(i,k)) and (min(i,l), max(i,l)) for every i != k, l
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            if (i == k || i == l) continue;
+            double& X = i < k ? s.u(i, k) : s.u(k, i);
+            double& Y = i < l ? s.u(i, l) : s.u(l, i);
+            const double a0 = X, b0 = Y;
+            X = a0 * c - b0 * sn;
+            Y = a0 * sn + b0 * c;
         }
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            double& X = s.v(n * k + i);
+            double& Y = s.v(n * l + i);
+            const double a0 = X, b0 = Y;
+            X = a0 * c - b0 * sn;
+            Y = a0 * sn + b0 * c;
+        }
+        if (k < n - 1) set(IR, k, row_arg(k));
+        if (k > 0) set(IC, k, col_arg(k));
+        if (l < n - 1) set(IR, l, row_arg(l));
+        if (l > 0) set(IC, l, col_arg(l));
     }
-    for (k = 0; k < n - 1; k++) {
-        m = k;
-        for (i = k + 1; i < n; i++) if (s.w(m) < s.w(i)) m = i;
+    // sort the eigenvalues (and vectors) in descending order: selection sort of the serial code
+    for (int k = 0; k < n - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < n; i++) if (s.w(m) < s.w(i)) m = i;
         if (k != m) {
             double tw = s.w(m); s.w(m) = s.w(k); s.w(k) = tw;
-            for (i = 0; i < n; i++) { double tv = s.v(n * m + i); s.v(n * m + i) = s.v(n * k + i); s.v(n * k + i) = tv; }
+            for (int i = 0; i < n; i++) { double tv = s.v(n * m + i); s.v(n * m + i) = s.v(n * k + i); s.v(n * k + i) = tv; }
         }
     }
 }
