@@ -106,6 +106,7 @@ PROTOTYPES = {
     "mis_knn2": (_i, [_vp, _P(MisFeatures), _P(MisFeatures), _vp, _vp]),
     "mis_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _P(_i)]),
     "mis_leave_biggest_component": (_i, [_P(MisMatchesInfo), _i, _f, _vp, _P(_i)]),
+    "mis_leave_biggest_component_conf": (_i, [_vp, _i, _f, _vp, _P(_i)]),
     "mis_warp_roi": (_i, [_f, _i, _i, _vp, _vp, _P(MisRect)]),
     "mis_warp_spherical": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _i, _i, _P(MisImage), _P(MisPoint)]),
     "mis_warp_spherical_fused": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint)]),

@@ -667,8 +667,8 @@ extern "C" int mis_find_homography(MisContext* ctx, const float* src, const floa
 
 // myLeaveBiggestComponent (image_stitching.cpp:215-278): union-find over pairs with
 // confidence >= threshold (cv::detail::DisjointSets semantics), indices of the biggest component
-extern "C" int mis_leave_biggest_component(const MisMatchesInfo* pm, int n, float conf_threshold, int* indices, int* n_indices) {
-    if (!pm || !indices || !n_indices || n < 1) return MIS_E_INVALID;
+// myLeaveBiggestComponent's graph part: union-find over the pairs with confidence >= threshold, indices of the largest set
+static int biggest_component(const double* conf, int n, float conf_threshold, int* indices, int* n_indices) {
     std::vector<int> parent(n), rank_(n, 0), size(n, 1);
     for (int i = 0; i < n; i++) parent[i] = i;
     auto find = [&](int elem) {
@@ -679,7 +679,7 @@ extern "C" int mis_leave_biggest_component(const MisMatchesInfo* pm, int n, floa
     };
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
-            if (pm[i * n + j].confidence < conf_threshold) continue;
+            if (conf[(size_t)i * n + j] < conf_threshold) continue;
             int c1 = find(i), c2 = find(j);
             if (c1 == c2) continue;
             if (rank_[c1] < rank_[c2]) { parent[c1] = c2; size[c2] += size[c1]; }
@@ -691,4 +691,16 @@ extern "C" int mis_leave_biggest_component(const MisMatchesInfo* pm, int n, floa
     for (int i = 0; i < n; i++) if (find(i) == max_comp) indices[k++] = i;
     *n_indices = k;
     return MIS_OK;
+}
+
+extern "C" int mis_leave_biggest_component(const MisMatchesInfo* pm, int n, float conf_threshold, int* indices, int* n_indices) {
+    if (!pm || !indices || !n_indices || n < 1) return MIS_E_INVALID;
+    std::vector<double> conf((size_t)n * n);
+    for (size_t i = 0; i < conf.size(); i++) conf[i] = pm[i].confidence;
+    return biggest_component(conf.data(), n, conf_threshold, indices, n_indices);
+}
+
+extern "C" int mis_leave_biggest_component_conf(const double* confidence, int n, float conf_threshold, int* indices, int* n_indices) {
+    if (!confidence || !indices || !n_indices || n < 1) return MIS_E_INVALID;
+    return biggest_component(confidence, n, conf_threshold, indices, n_indices);
 }

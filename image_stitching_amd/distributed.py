@@ -240,9 +240,7 @@ class StitchJob:
         return pm, conf
 
     def stage_prune(self, conf):
-        conf = conf.cpu().numpy()
-        pm = [st.MatchesInfo(confidence=float(c)) for c in conf.reshape(-1)]
-        return list(st.leaveBiggestComponent(pm, self.n, self.cfg.conf_thresh))
+        return [int(i) for i in st.leaveBiggestComponentConf(conf.cpu().numpy().reshape(self.n, self.n), self.cfg.conf_thresh)]
 
     def stage_compose(self, frames, indices):
         eng = self.engine

@@ -617,6 +617,18 @@ def leaveBiggestComponent(pairwise_matches, n, conf_threshold):
     return idx[: k.value].copy()
 
 
+def leaveBiggestComponentConf(confidence, conf_threshold):
+    """myLeaveBiggestComponent on the bare n x n confidence matrix -> kept indices."""
+    conf = np.ascontiguousarray(confidence, np.float64)
+    n = conf.shape[0]
+    idx = np.zeros(n, np.int32)
+    k = C.c_int()
+    rc = capi.load().mis_leave_biggest_component_conf(conf.ctypes.data_as(C.c_void_p), n, float(conf_threshold), idx.ctypes.data_as(C.c_void_p), C.byref(k))
+    if rc != capi.MIS_OK:
+        raise MisError(rc, "mis_leave_biggest_component_conf")
+    return idx[: k.value].copy()
+
+
 def find_homography(ctx, src, dst, thresh=3.0, max_iters=2000, confidence=0.995):
     """cv::findHomography(src, dst, mask, RANSAC) on the GPU -> (ok, H, mask)."""
     src = np.ascontiguousarray(src, np.float32)

@@ -151,6 +151,8 @@ int mis_find_homography(MisContext* ctx, const float* src_xy, const float* dst_x
                         double confidence, double H[9], uint8_t* mask, int* ok);
 /* myLeaveBiggestComponent -- replaces image_stitching.cpp:215-278 (host logic on the matcher output) */
 int mis_leave_biggest_component(const MisMatchesInfo* pairwise, int n, float conf_threshold, int* indices, int* n_indices);
+/* the same on the bare n x n confidence matrix (row-major; what a sharded job has after its all-reduce) */
+int mis_leave_biggest_component_conf(const double* confidence, int n, float conf_threshold, int* indices, int* n_indices);
 
 /* ---------------------------------------------------------------- warp ---------------------- */
 /* warper->warpRoi(sz, K, R) -- replaces image_stitching.cpp:1138 (K, R: 3x3 f32 row-major) */
