@@ -42,6 +42,7 @@ struct HomoBatch {
 };
 
 int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long points, int max_iters);
+int homo_batch_debug_states(MisContext* ctx, const HomoBatch* b, int* out, int cap);
 void homo_batch_release(HomoBatch* b);
 // `calls` (device array of b->count entries) must be filled before this is enqueued on ctx->stream.
 int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence);

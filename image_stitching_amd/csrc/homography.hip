@@ -195,6 +195,41 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     }
     int* didx = draw_idx + (size_t)b * DRAW_CHUNK * 4;
     int* sidx = sub_idx + (size_t)b * max_iters * 4;
+    if (phase == 0 && c.n <= 10) {
+        // Tiny problems (a handful of spurious matches) are often infeasible outright: every ordered 4-tuple of distinct
+        // points fails checkSubset, so getSubset burns its 10000 attempts and the RANSAC loop ends without a model.
+        // All n (n-1)(n-2)(n-3) <= 5040 tuples are tested here; if none passes, that outcome is known without simulating
+        // ~150k stream positions (two such problems set the duration of the whole launch in a 16-frame job).
+        const int n = c.n, total = n * (n - 1) * (n - 2) * (n - 3);
+        int any = 0;
+        for (int q = t; q < total && !any; q += TB) {
+            int r = q, id[4];
+            id[0] = r % n; r /= n;
+            int a1 = r % (n - 1); r /= (n - 1);
+            int a2 = r % (n - 2); r /= (n - 2);
+            int a3 = r;
+            // k-th unused index, in increasing order
+            auto pick = [&](int kth, int cnt) {
+                for (int v = 0; v < n; v++) {
+                    bool used = false;
+                    for (int u = 0; u < cnt; u++) used |= id[u] == v;
+                    if (!used && kth-- == 0) return v;
+                }
+                return 0;
+            };
+            id[1] = pick(a1, 1); id[2] = pick(a2, 2); id[3] = pick(a3, 3);
+            float ms1[8], ms2[8];
+            for (int i = 0; i < 4; i++) {
+                const float2 ps = reinterpret_cast<const float2*>(psrc)[id[i]], pd = reinterpret_cast<const float2*>(pdst)[id[i]];
+                ms1[2 * i] = ps.x; ms1[2 * i + 1] = ps.y; ms2[2 * i] = pd.x; ms2[2 * i + 1] = pd.y;
+            }
+            any |= check_subset(ms1, ms2) ? 1 : 0;
+        }
+        if (!__syncthreads_or(any)) {
+            if (t == 0) { st->draw_fail = 1; st->n_sub = 0; st->draw_k = 0; }
+            return;
+        }
+    }
     while (s_more) {
         const long long base = s_pos;
         for (int o = t; o < DRAW_CHUNK; o += TB) {
@@ -1024,6 +1059,21 @@ extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     return 0;
 }
 #endif
+
+// diagnostics (tools/ransac_states.py): per-problem {n, mode, n_sub, iter, niters, draw_fail, done, max_good} of a finished batch
+int homo_batch_debug_states(MisContext* ctx, const HomoBatch* b, int* out, int cap) {
+    const int n = std::min(cap, b->count);
+    std::vector<RansacState> st(n);
+    std::vector<HomoCall> calls(n);
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIS_HIP(ctx, hipMemcpy(st.data(), b->state, sizeof(RansacState) * n, hipMemcpyDeviceToHost));
+    MIS_HIP(ctx, hipMemcpy(calls.data(), b->calls, sizeof(HomoCall) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        int* o = out + 8 * i;
+        o[0] = calls[i].n; o[1] = st[i].mode; o[2] = st[i].n_sub; o[3] = st[i].iter; o[4] = st[i].niters; o[5] = st[i].draw_fail; o[6] = st[i].done; o[7] = st[i].max_good;
+    }
+    return n;
+}
 
 void homo_batch_release(HomoBatch* b) {
     if (b->mem) hipFree(b->mem);

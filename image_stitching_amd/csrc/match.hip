@@ -560,6 +560,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
 
 }  // namespace
 
+// diagnostics: RANSAC states of the last matcher call (which = 0: first estimation of every pair, 1: the inlier-only one)
+extern "C" int mis_debug_ransac_states(MisContext* ctx, int which, int* out, int cap) {
+    if (!ctx || !ctx->match_ws || !out) return -1;
+    MatchWorkspace* ws = (MatchWorkspace*)ctx->match_ws;
+    return homo_batch_debug_states(ctx, which ? &ws->b2 : &ws->b1, out, cap);
+}
+
 extern "C" void mis_match_default_params(MisMatchParams* p) {
     if (p) *p = MisMatchParams{0.32f, 6, 6, 3.0, 2000, 0.995};
 }

@@ -189,3 +189,32 @@ def test_match_all_pairs_float_descriptors(ctx, oracle_mod):
         _compare_matches_info(g, o)
     # 420 exact inliers of 420 matches: inliers / (8 + 0.3 m) > 3 -> the "too similar images" rule zeroes it
     assert pm[1].num_inliers >= 400 and pm[1].confidence == 0.0 and pm[2].num_inliers < 20
+
+
+@pytest.mark.parametrize("n", [5, 6, 8, 10])
+def test_find_homography_tiny_problems_incl_infeasible(ctx, oracle_mod, n):
+    """Tiny correspondence sets: (a) every 4-subset fails checkSubset (collinear source points) -> getSubset gives up,
+    no model -- the GPU short-cuts the 10000 attempts by testing all ordered 4-tuples; (b) a feasible tiny set must not
+    take the short cut and still equals the oracle bit for bit."""
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(40 + n)
+    # (a) infeasible: all source points on one line
+    t = rng.uniform(-200, 200, n).astype(np.float32)
+    src = np.stack([t, (0.5 * t + 3).astype(np.float32)], 1).astype(np.float32)
+    dst = rng.uniform(-200, 200, (n, 2)).astype(np.float32)
+    ok_g, H_g, m_g = isa.find_homography(ctx, src, dst)
+    ok_o, H_o, m_o, _ = oracle_mod.find_homography_ransac(src, dst)
+    assert bool(ok_o) is False and ok_g is False
+    assert not m_g.any() and not np.asarray(m_o).any()
+    # (b) feasible: an exact homography plus one or two outliers
+    H = np.array([[1.01, 0.02, 12.0], [-0.015, 0.99, -7.0], [2e-5, -1e-5, 1.0]])
+    src = rng.uniform(-300, 300, (n, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(n)] @ H.T
+    dst = (p[:, :2] / p[:, 2:]).astype(np.float32)
+    dst[0] += 40
+    ok_g, H_g, m_g = isa.find_homography(ctx, src, dst)
+    ok_o, H_o, m_o, _ = oracle_mod.find_homography_ransac(src, dst)
+    assert ok_g == bool(ok_o)
+    assert np.array_equal(m_g, m_o)
+    if ok_g:
+        assert np.array_equal(_bits(H_g), _bits(H_o))
