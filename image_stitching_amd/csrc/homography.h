@@ -39,10 +39,13 @@ struct HomoBatch {
     double* rec = nullptr;    // 10 doubles per point: per-point terms of the DLT / LM sums
     unsigned* draw_next = nullptr;  // per problem: stream-position tables of the subset drawing
     int* draw_idx = nullptr;
+    int* fin = nullptr;       // per problem: RANSAC phase in which it finished (0 / 1), -1 while unfinished
 };
 
 int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long points, int max_iters);
 int homo_batch_debug_states(MisContext* ctx, const HomoBatch* b, int* out, int cap);
 void homo_batch_release(HomoBatch* b);
 // `calls` (device array of b->count entries) must be filled before this is enqueued on ctx->stream.
-int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence);
+// phases: 0 = hypotheses [0, PHASE0) + replay + tails of the problems that finish there; 1 = the rest; 2 = both.
+// `stream` = nullptr: the context's stream.
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases = 2, hipStream_t stream = nullptr);

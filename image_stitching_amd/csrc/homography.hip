@@ -903,7 +903,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
 
 __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
-                                                       double confidence, float thr) {
+                                                       double confidence, float thr, int* fin) {
     __shared__ TailShared S;
     __shared__ int s_done_now;
     __shared__ int wcnt[TB / 64];
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     __syncthreads();
     if (mode == 0) {
         for (int i = t; c.mask && c.active && i < n; i += TB) c.mask[i] = 0;
-        if (t == 0) { res->ok = 0; res->iters = 0; res->ninl = 0; st->done = 1; }
+        if (t == 0) { res->ok = 0; res->iters = 0; res->ninl = 0; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
         return;
     }
     if (mode == 1) {
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         dlt_coop(S, c.src, c.dst, 4, rec);
         const int ok = S.go;
         for (int i = t; c.mask && i < n; i += TB) c.mask[i] = ok ? 1 : 0;
-        if (t == 0) { res->ok = ok; res->iters = 0; res->ninl = ok ? 4 : 0; if (ok) for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; st->done = 1; }
+        if (t == 0) { res->ok = ok; res->iters = 0; res->ninl = ok ? 4 : 0; if (ok) for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
         return;
     }
     // ---- replay of RANSACPointSetRegistrator::run over hypotheses [lo, hi) ----
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         }
         st->iter = iter; st->niters = niters; st->max_good = max_good; st->best_k = best_k;
         // the loop ends when iter reaches niters, when getSubset failed (subsets exhausted) or at maxIters
-        if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; }
+        if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
     }
     __syncthreads();
     if (!s_done_now) return;
@@ -1037,7 +1037,7 @@ int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long point
     size_t o_sub = carve(sizeof(int) * 4 * (size_t)count * max_iters), o_hc = carve(sizeof(double) * 9 * (size_t)count * max_iters);
     size_t o_valid = carve(sizeof(int) * (size_t)count * max_iters), o_good = carve(sizeof(int) * (size_t)count * max_iters);
     size_t o_scr = carve(sizeof(float) * 4 * (size_t)points), o_rec = carve(sizeof(double) * 10 * (size_t)points);
-    size_t o_dn = carve(256), o_di = carve(sizeof(int) * 4 * (size_t)count * DRAW_CHUNK);
+    size_t o_dn = carve(256), o_di = carve(sizeof(int) * 4 * (size_t)count * DRAW_CHUNK), o_fin = carve(sizeof(int) * (size_t)count);
     if (off > b->bytes) {
         if (b->mem) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(b->mem)); b->mem = nullptr; b->bytes = 0; }
         MIS_HIP(ctx, hipMalloc(&b->mem, off));
@@ -1046,7 +1046,7 @@ int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long point
     uint8_t* m = (uint8_t*)b->mem;
     b->calls = (HomoCall*)(m + o_calls); b->results = (HomoResult*)(m + o_res); b->state = m + o_state;
     b->sub_idx = (int*)(m + o_sub); b->Hc = (double*)(m + o_hc); b->valid = (int*)(m + o_valid); b->good = (int*)(m + o_good);
-    b->scr = (float*)(m + o_scr); b->rec = (double*)(m + o_rec); b->draw_next = (unsigned*)(m + o_dn); b->draw_idx = (int*)(m + o_di);
+    b->scr = (float*)(m + o_scr); b->rec = (double*)(m + o_rec); b->draw_next = (unsigned*)(m + o_dn); b->draw_idx = (int*)(m + o_di); b->fin = (int*)(m + o_fin);
     b->count = count; b->points = points; b->max_iters = max_iters;
     return MIS_OK;
 }
@@ -1080,7 +1080,7 @@ void homo_batch_release(HomoBatch* b) {
     b->mem = nullptr; b->bytes = 0;
 }
 
-int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence) {
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases, hipStream_t stream) {
     MIS_CHECK(ctx, max_iters >= 1 && max_iters <= b->max_iters, MIS_E_INVALID, "max_iters %d outside the reserved range", max_iters);
     MIS_CHECK(ctx, confidence > 0 && confidence < 1, MIS_E_INVALID, "confidence must be in (0,1)");
     RngTable rt;
@@ -1088,7 +1088,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     if (rc != MIS_OK) return rc;
     if (thresh <= 0) thresh = 3;
     const float thr = (float)(thresh * thresh);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = stream ? stream : ctx->stream;
     static bool attr_set[64] = {false};
     const size_t hyp_lds = sizeof(double) * SLOT_DOUBLES * HYP_TPB;
     if (!attr_set[ctx->device & 63]) {
@@ -1097,17 +1097,20 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     RansacState* states = (RansacState*)b->state;
     const int p0 = std::min(PHASE0, max_iters);
-    hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
-    hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
-                       b->good, 0, max_iters, thr);
-    hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                       max_iters, confidence, thr);
-    if (max_iters > p0) {
+    if (phases == 0 || phases == 2) {
+        MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
+        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
+        hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
+                           b->good, 0, max_iters, thr);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin);
+    }
+    if ((phases == 1 || phases == 2) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
-                           max_iters, max_iters, confidence, thr);
+                           max_iters, max_iters, confidence, thr, b->fin);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

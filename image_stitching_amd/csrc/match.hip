@@ -345,14 +345,16 @@ __global__ void first_calls_kernel(const PairDesc* pairs, int np, const int* n_m
 
 // between the two estimations: determinant check, inlier threshold; the inlier-only point lists are
 // the compacted lists the first estimation left in its scratch
-__global__ void second_calls_kernel(int np, const HomoCall* calls1, const HomoResult* res1, const float* scr1, int thresh2, HomoCall* calls2,
-                                    PairOut* outs) {
+// `want` selects the problems whose first estimation finished in that RANSAC phase (fin1[k]); the others get an
+// inactive call and their PairOut entry is left alone (the launch for the other phase owns it)
+__global__ void second_calls_kernel(int np, const HomoCall* calls1, const HomoResult* res1, const float* scr1, const int* fin1, int want, int thresh2,
+                                    HomoCall* calls2, PairOut* outs) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= np) return;
     const HomoCall c1 = calls1[k];
     HomoCall c;
     c.src = nullptr; c.dst = nullptr; c.mask = nullptr; c.pt_off = c1.pt_off; c.n = 0; c.active = 0;
-    if (c1.active && res1[k].ok && !(fabs(det3(res1[k].H)) < DBL_EPSILON)) {
+    if (fin1[k] == want && c1.active && res1[k].ok && !(fabs(det3(res1[k].H)) < DBL_EPSILON)) {
         outs[k].passed = 1;
         const int ninl = res1[k].ninl;
         if (ninl >= thresh2) {
@@ -389,9 +391,19 @@ struct Arena {
 
 struct MatchWorkspace : MisWorkspace {
     Arena dev, pinned, l2;
-    HomoBatch b1, b2;
+    // b1: first estimation of every pair; b2 / b3: the inlier-only estimation of the pairs whose first one finished in
+    // RANSAC phase 0 / phase 1.  b2 runs on `side` concurrently with phase 1 of b1 (the chains are latency bound).
+    HomoBatch b1, b2, b3;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr;
     MatchWorkspace() { pinned.host = true; }
-    ~MatchWorkspace() override { dev.release(); pinned.release(); l2.release(); homo_batch_release(&b1); homo_batch_release(&b2); }
+    ~MatchWorkspace() override {
+        dev.release(); pinned.release(); l2.release();
+        homo_batch_release(&b1); homo_batch_release(&b2); homo_batch_release(&b3);
+        if (side) hipStreamDestroy(side);
+        if (ev_phase0) hipEventDestroy(ev_phase0);
+        if (ev_side_done) hipEventDestroy(ev_side_done);
+    }
 };
 
 MatchWorkspace* workspace(MisContext* ctx) {
@@ -460,10 +472,11 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     int rc;
     if ((rc = homo_batch_reserve(ctx, &ws->b1, np, (long long)m_total, p->max_iters)) != MIS_OK) return rc;
     if ((rc = homo_batch_reserve(ctx, &ws->b2, np, (long long)m_total, p->max_iters)) != MIS_OK) return rc;
+    if ((rc = homo_batch_reserve(ctx, &ws->b3, np, (long long)m_total, p->max_iters)) != MIS_OK) return rc;
     // pinned host mirror of everything that comes back
     Carver hc;
     const size_t h_in = hc.take(sizeof(FeatDev) * n + sizeof(PairDesc) * np + 512), h_nm = hc.take(sizeof(int) * np), h_out = hc.take(sizeof(PairOut) * np),
-                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total);
+                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total);
     MIS_HIP(ctx, ws->pinned.reserve(hc.off));
     uint8_t* Hh = (uint8_t*)ws->pinned.p;
     memcpy(Hh + h_in, fd.data(), sizeof(FeatDev) * n);
@@ -499,21 +512,41 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
                        (const float*)d_dist, 1.f - p->match_conf, d_matches, d_src, d_dst, d_nm);
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
                        (const float*)d_dst, d_mask, p->num_matches_thresh1, ws->b1.calls, d_out);
-    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence)) != MIS_OK) return rc;
+    if (!ws->side) {
+        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase0, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
+    }
+    // first estimation, phase 0 (pairs with a clear overlap finish here)
+    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 0, st)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
+    // side stream: the inlier-only estimation of those pairs ...
+    MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
+    hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out);
+    if ((rc = homo_batch_run(ctx, &ws->b2, p->ransac_thresh, p->max_iters, p->confidence, 2, ws->side)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
+    // ... while the main stream finishes the first estimation of the others and runs their second one
+    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 1, st)) != MIS_OK) return rc;
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
-                       (const float*)ws->b1.scr, p->num_matches_thresh2, ws->b2.calls, d_out);
-    if ((rc = homo_batch_run(ctx, &ws->b2, p->ransac_thresh, p->max_iters, p->confidence)) != MIS_OK) return rc;
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out);
+    if ((rc = homo_batch_run(ctx, &ws->b3, p->ransac_thresh, p->max_iters, p->confidence, 2, st)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_side_done, 0));
     MIS_HIP(ctx, hipGetLastError());
     int* nm = (int*)(Hh + h_nm);
     PairOut* po = (PairOut*)(Hh + h_out);
     HomoResult* r1 = (HomoResult*)(Hh + h_r1);
     HomoResult* r2 = (HomoResult*)(Hh + h_r2);
+    HomoResult* r3 = (HomoResult*)(Hh + h_r3);
+    int* fin = (int*)(Hh + h_fin);
     MisDMatch* hm = (MisDMatch*)(Hh + h_m);
     uint8_t* hmask = Hh + h_mask;
     MIS_HIP(ctx, hipMemcpyAsync(nm, d_nm, sizeof(int) * np, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(po, d_out, sizeof(PairOut) * np, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(r1, ws->b1.results, sizeof(HomoResult) * np, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(r2, ws->b2.results, sizeof(HomoResult) * np, hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipMemcpyAsync(r3, ws->b3.results, sizeof(HomoResult) * np, hipMemcpyDeviceToHost, st));
+    MIS_HIP(ctx, hipMemcpyAsync(fin, ws->b1.fin, sizeof(int) * np, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(hm, d_matches, sizeof(MisDMatch) * m_total, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(hmask, d_mask, m_total, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipStreamSynchronize(st));
@@ -532,7 +565,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             memcpy(a->inliers_mask, hmask + pd.m_off, (size_t)nm[k]);
         }
         // H of the inlier-only estimation when it ran (it may come back empty), else of the first one
-        const HomoResult& hr = po[k].second ? r2[k] : r1[k];
+        const HomoResult& hr = po[k].second ? (fin[k] == 0 ? r2[k] : r3[k]) : r1[k];
         a->has_H = po[k].ran_ransac ? hr.ok : 0;
         if (a->has_H) memcpy(a->H, hr.H, sizeof(a->H));
         a->num_inliers = po[k].passed ? r1[k].ninl : 0;
