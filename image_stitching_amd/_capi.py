@@ -80,6 +80,8 @@ _P = C.POINTER
 # name -> (restype, argtypes); must list every function declared in include/mistitch.h
 PROTOTYPES = {
     "mis_context_create": (_i, [_i, _vp, _P(_vp)]),
+    "mis_stream_create": (_i, [_i, _i, _P(_vp)]),
+    "mis_stream_destroy": (_i, [_vp]),
     "mis_context_destroy": (_i, [_vp]),
     "mis_context_synchronize": (_i, [_vp]),
     "mis_last_error": (C.c_char_p, [_vp]),

@@ -66,6 +66,24 @@ extern "C" int mis_context_destroy(MisContext* ctx) {
     return MIS_OK;
 }
 
+extern "C" int mis_stream_create(int device, int priority, void** out) {
+    if (!out) return MIS_E_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return MIS_E_HIP;
+    const int pr = priority > 0 ? least : (priority < 0 ? greatest : 0);   // HIP: numerically smaller = more urgent
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr) != hipSuccess) return MIS_E_HIP;
+    *out = (void*)s;
+    return MIS_OK;
+}
+
+extern "C" int mis_stream_destroy(void* stream) {
+    if (!stream) return MIS_OK;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MIS_OK : MIS_E_HIP;
+}
+
 extern "C" int mis_context_synchronize(MisContext* ctx) {
     if (!ctx) return MIS_E_INVALID;
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));

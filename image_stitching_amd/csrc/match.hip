@@ -513,7 +513,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
                        (const float*)d_dst, d_mask, p->num_matches_thresh1, ws->b1.calls, d_out);
     if (!ws->side) {
-        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));   // default priority (an urgent one measured no gain)
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase0, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }

@@ -108,8 +108,12 @@ class HipEngine:
         self._keep = []
         # warp + blend run in a context of their own (second stream): StitchJob composes speculatively while the
         # latency-bound RANSAC chains of the matcher leave most of the device idle
-        self.compose_stream = torch.cuda.Stream(device=ctx.device)
-        self.cctx = st.Context(ctx.device.index, stream=self.compose_stream.cuda_stream)
+        # (normal priority: a low-priority stream was measured -- the compose work then finishes after the matcher, 20.1 ms)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mis_stream_create(ctx.device.index, 0, C.byref(h)))
+        self._compose_stream_handle = h
+        self.compose_stream = torch.cuda.ExternalStream(h.value, device=ctx.device)
+        self.cctx = st.Context(ctx.device.index, stream=h.value)
         self.speculative_compose = True
 
     # ---- features ----

@@ -61,6 +61,10 @@ typedef struct {
 /* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL is the device's
  * default (null) stream.  All work of the context is enqueued on that stream. */
 int mis_context_create(int device, void* stream, MisContext** out);
+/* A non-blocking HIP stream for a second context on the same device (priority > 0: background work that yields
+ * to the default-priority streams, < 0: urgent, 0: normal).  Pass the handle as `stream` to mis_context_create. */
+int mis_stream_create(int device, int priority, void** stream);
+int mis_stream_destroy(void* stream);
 int mis_context_destroy(MisContext* ctx);
 int mis_context_synchronize(MisContext* ctx);
 const char* mis_last_error(const MisContext* ctx);
