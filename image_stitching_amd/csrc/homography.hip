@@ -610,16 +610,25 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
             for (i = 0; i < n - 1; i++) rv[i] = fabs(A[n * i + ir[i]]);
 #pragma unroll
             for (i = 1; i < n; i++) cv[i] = fabs(A[n * ic[i] + i]);
-            k = 0; mv = rv[0];
+            // "first maximum" of the serial scan = a tournament in which the earlier candidate wins ties: depth 4-5
+            // instead of a chain of 16 dependent f64 compares.  Candidate order: rows 0 .. n-2, then columns 1 .. n-1.
+            double cand_v[2 * n - 2];
+            int cand_k[2 * n - 2], cand_l[2 * n - 2];
 #pragma unroll
-            for (i = 1; i < n - 1; i++)
-                if (mv < rv[i]) mv = rv[i], k = i;
-            l = 0;
+            for (i = 0; i < n - 1; i++) { cand_v[i] = rv[i]; cand_k[i] = i; cand_l[i] = ir[i]; }
 #pragma unroll
-            for (i = 0; i < n - 1; i++) l = (k == i) ? ir[i] : l;   // l = indR[k] without a dynamic register index
+            for (i = 1; i < n; i++) { cand_v[n - 2 + i] = cv[i]; cand_k[n - 2 + i] = ic[i]; cand_l[n - 2 + i] = i; }
 #pragma unroll
-            for (i = 1; i < n; i++)
-                if (mv < cv[i]) mv = cv[i], k = ic[i], l = i;
+            for (int width = 1; width < 2 * n - 2; width *= 2) {
+#pragma unroll
+                for (i = 0; i + width < 2 * n - 2; i += 2 * width) {
+                    const bool right = cand_v[i] < cand_v[i + width];   // strictly greater: the later candidate must beat the earlier
+                    cand_v[i] = right ? cand_v[i + width] : cand_v[i];
+                    cand_k[i] = right ? cand_k[i + width] : cand_k[i];
+                    cand_l[i] = right ? cand_l[i + width] : cand_l[i];
+                }
+            }
+            k = cand_k[0]; l = cand_l[0];
             const double p = A[n * k + l];
             if (fabs(p) <= eps) break;  // uniform: every lane reads the same LDS words
             PROF_INC(1, 1);
