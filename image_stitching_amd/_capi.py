@@ -53,6 +53,11 @@ class MisSiftParams(C.Structure):
                 ("edge_threshold", C.c_double), ("sigma", C.c_double)]
 
 
+class MisCameraParams(C.Structure):
+    _fields_ = [("focal", C.c_double), ("aspect", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double), ("R", C.c_double * 9),
+                ("t", C.c_double * 3)]
+
+
 class MisFeatures(C.Structure):
     _fields_ = [("img_idx", C.c_int), ("img_w", C.c_int), ("img_h", C.c_int), ("n", C.c_int),
                 ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("desc_cols", C.c_int),
@@ -109,6 +114,8 @@ PROTOTYPES = {
     "mis_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _P(_i)]),
     "mis_leave_biggest_component": (_i, [_P(MisMatchesInfo), _i, _f, _vp, _P(_i)]),
     "mis_leave_biggest_component_conf": (_i, [_vp, _i, _f, _vp, _P(_i)]),
+    "mis_bundle_adjust_reproj": (_i, [_vp, _P(MisFeatures), _P(MisMatchesInfo), _i, _f, C.c_char_p, _P(MisCameraParams)]),
+    "mis_wave_correct": (_i, [_vp, _i, _i]),
     "mis_warp_roi": (_i, [_f, _i, _i, _vp, _vp, _P(MisRect)]),
     "mis_warp_spherical": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _i, _i, _P(MisImage), _P(MisPoint)]),
     "mis_warp_spherical_fused": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint)]),

@@ -1,0 +1,475 @@
+// motion.hip -- camera refinement between matching and warping, host logic of the library:
+//   (*adjuster)(features, pairwise_matches, cameras) with BundleAdjusterReproj   image_stitching/image_stitching.cpp:681-712
+//   waveCorrect(rmats, WAVE_CORRECT_HORIZ)                                       image_stitching/image_stitching.cpp:718-726
+// The reference runs both on the CPU inside OpenCV (stitching/src/motion_estimators.cpp, calib3d CvLevMarq, core
+// JacobiSVD / Jacobi eigen, calib3d Rodrigues); restated here from the published algorithms, f64 throughout, plain
+// sequential arithmetic.  PARITY UNPINNED (OpenCV absent offline): the checks are behavioural (tests/test_motion_gpu.py).
+// No kernels: the data is a few thousand inlier correspondences and 7 parameters per camera.
+#include "common.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- small dense linear algebra ---
+struct Mat {
+    int r = 0, c = 0;
+    std::vector<double> v;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), v((size_t)r_ * c_, 0.) {}
+    double& operator()(int i, int j) { return v[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return v[(size_t)i * c + j]; }
+};
+
+void mul3(const double* a, const double* b, double* o) {   // o = a * b (3x3)
+    double t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+    memcpy(o, t, sizeof(t));
+}
+void transpose3(const double* a, double* o) { double t[9] = {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; memcpy(o, t, sizeof(t)); }
+double det3(const double* a) { return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]); }
+bool inv3(const double* a, double* o) {
+    double d = det3(a);
+    if (d == 0) return false;
+    d = 1. / d;
+    double t[9] = {(a[4] * a[8] - a[5] * a[7]) * d, (a[2] * a[7] - a[1] * a[8]) * d, (a[1] * a[5] - a[2] * a[4]) * d,
+                   (a[5] * a[6] - a[3] * a[8]) * d, (a[0] * a[8] - a[2] * a[6]) * d, (a[2] * a[3] - a[0] * a[5]) * d,
+                   (a[3] * a[7] - a[4] * a[6]) * d, (a[1] * a[6] - a[0] * a[7]) * d, (a[0] * a[4] - a[1] * a[3]) * d};
+    memcpy(o, t, sizeof(t));
+    return true;
+}
+
+// core/src/lapack.cpp JacobiSVDImpl_<double>: one-sided Jacobi on the rows of At (n rows of length m); W = singular
+// values (descending), rows of At become the left vectors scaled to unit length, Vt the right vectors.
+void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n) {
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    std::vector<double> W(n);
+    const int max_iter = std::max(m, 30);
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[i * astep + k]; sd += t * t; }
+        W[i] = sd;
+        for (int k = 0; k < n; k++) Vt[i * vstep + k] = 0;
+        Vt[i * vstep + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + i * astep, *Aj = At + j * astep;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (std::abs(p) <= eps * std::sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = hypot(p, beta), c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = std::sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = std::sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
+                for (int k = 0; k < n; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[i * astep + k]; sd += t * t; }
+        W[i] = std::sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            std::swap(W[i], W[j]);
+            for (int k = 0; k < m; k++) std::swap(At[i * astep + k], At[j * astep + k]);
+            for (int k = 0; k < n; k++) std::swap(Vt[i * vstep + k], Vt[j * vstep + k]);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        Wout[i] = W[i];
+        const double s = W[i] > minval ? 1 / W[i] : 0.;   // (degenerate directions: zeroed; the random completion of
+        for (int k = 0; k < m; k++) At[i * astep + k] *= s;   //  OpenCV only matters for full bases, not for solve)
+    }
+}
+
+// cv::solve(A, b, x, DECOMP_SVD) for a square system: SVD of A, then SVBkSb with the threshold 2 eps sum(w)
+bool solve_svd(const Mat& A, const std::vector<double>& b, std::vector<double>& x) {
+    const int n = A.r;
+    // JacobiSVD works on the transposed matrix: rows of At = columns of A; A = U diag(w) Vt with At rows -> u_i
+    Mat At(n, n), Vt(n, n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) At(i, j) = A(j, i);
+    std::vector<double> w(n);
+    jacobi_svd(At.v.data(), n, w.data(), Vt.v.data(), n, n, n);
+    // after the call: At(i, :) = i-th left singular vector (as a row), Vt(i, :) = i-th right singular vector
+    double thr = 0;
+    for (int i = 0; i < n; i++) thr += w[i];
+    thr *= 2 * DBL_EPSILON;
+    x.assign(n, 0.);
+    for (int i = 0; i < n; i++) {
+        if (!(w[i] > thr)) continue;
+        double s = 0;
+        for (int k = 0; k < n; k++) s += At(i, k) * b[k];
+        s /= w[i];
+        for (int k = 0; k < n; k++) x[k] += s * Vt(i, k);
+    }
+    return true;
+}
+
+// 3x3 SVD through the same routine: R = U diag(w) Vt  (u, vt as 3x3 row-major)
+void svd3(const double* R, double* u, double* w, double* vt) {
+    double At[9], Vt[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i * 3 + j] = R[j * 3 + i];
+    jacobi_svd(At, 3, w, Vt, 3, 3, 3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { u[j * 3 + i] = At[i * 3 + j]; vt[i * 3 + j] = Vt[i * 3 + j]; }
+}
+
+// calib3d Rodrigues: rotation vector -> matrix
+void rodrigues_to_mat(const double* r, double* R) {
+    const double theta = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) { double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; memcpy(R, I, sizeof(I)); return; }
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, it = 1 / theta;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * rx[k];
+}
+// matrix -> rotation vector (R is first projected on SO(3) by the caller)
+void rodrigues_to_vec(const double* R, double* r) {
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : (c < -1. ? -1. : c);
+    const double theta = std::acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; rx = std::sqrt(std::max(t, 0.));
+        t = (R[4] + 1) * 0.5; ry = std::sqrt(std::max(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; rz = std::sqrt(std::max(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+        if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+        const double k = theta / std::sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * k; r[1] = ry * k; r[2] = rz * k;
+        return;
+    }
+    const double vth = 1 / (2 * s) * theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+// ---------------------------------------------------------------- CvLevMarq ---------------------
+// calib3d compat_ptsetreg.cpp: the state machine of the Levenberg-Marquardt solver BundleAdjusterBase drives
+struct LevMarq {
+    enum { DONE = 0, STARTED = 1, CALC_J = 2, CHECK_ERR = 3 };
+    int nparams, nerrs, max_iter, state = STARTED, iters = 0, lambdaLg10 = -3;
+    double epsilon, prevErrNorm = DBL_MAX, errNorm = 0;
+    std::vector<double> param, prevParam, err, JtErr;
+    Mat J, JtJ;
+    LevMarq(int np, int ne, int maxit, double eps) : nparams(np), nerrs(ne), max_iter(maxit), epsilon(eps), param(np, 0.), prevParam(np, 0.), err(ne, 0.), JtErr(np, 0.), J(ne, np), JtJ(np, np) {}
+    void step() {
+        const double lambda = std::exp(lambdaLg10 * std::log(10.));
+        Mat A = JtJ;
+        for (int i = 0; i < nparams; i++) for (int j = 0; j < i; j++) A(i, j) = A(j, i);   // completeSymm (upper -> lower)
+        for (int i = 0; i < nparams; i++) A(i, i) *= 1. + lambda;
+        std::vector<double> d;
+        solve_svd(A, JtErr, d);
+        for (int i = 0; i < nparams; i++) param[i] = prevParam[i] - d[i];
+    }
+    static double norm2(const std::vector<double>& a) { double s = 0; for (double v : a) s += v * v; return std::sqrt(s); }
+    // returns proceed; want_J / want_err tell the caller what to compute for `param`
+    bool update(bool& want_J, bool& want_err) {
+        want_J = want_err = false;
+        if (state == DONE) return false;
+        if (state == STARTED) {
+            std::fill(J.v.begin(), J.v.end(), 0.); std::fill(err.begin(), err.end(), 0.);
+            want_J = want_err = true; state = CALC_J;
+            return true;
+        }
+        if (state == CALC_J) {
+            for (int i = 0; i < nparams; i++)          // JtJ = J^T J (upper triangle), JtErr = J^T err
+                for (int j = i; j < nparams; j++) {
+                    double s = 0;
+                    for (int k = 0; k < nerrs; k++) s += J(k, i) * J(k, j);
+                    JtJ(i, j) = s;
+                }
+            for (int i = 0; i < nparams; i++) { double s = 0; for (int k = 0; k < nerrs; k++) s += J(k, i) * err[k]; JtErr[i] = s; }
+            prevParam = param;
+            step();
+            if (iters == 0) prevErrNorm = norm2(err);
+            std::fill(err.begin(), err.end(), 0.);
+            want_err = true; state = CHECK_ERR;
+            return true;
+        }
+        errNorm = norm2(err);
+        if (errNorm > prevErrNorm) {
+            if (++lambdaLg10 <= 16) {
+                step();
+                std::fill(err.begin(), err.end(), 0.);
+                want_err = true; state = CHECK_ERR;
+                return true;
+            }
+        }
+        lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+        double change = 0;
+        {
+            double num = 0, den = 0;
+            for (int i = 0; i < nparams; i++) { num += (param[i] - prevParam[i]) * (param[i] - prevParam[i]); den += prevParam[i] * prevParam[i]; }
+            change = std::sqrt(num) / (std::sqrt(den) + DBL_EPSILON);   // cvNorm(param, prevParam, CV_RELATIVE_L2)
+        }
+        if (++iters >= max_iter || change < epsilon) { state = DONE; return true; }
+        prevErrNorm = errNorm;
+        std::fill(J.v.begin(), J.v.end(), 0.);
+        want_J = want_err = true; state = CALC_J;
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- BundleAdjusterReproj ----------
+struct Edge { int i, j; };
+struct Obs { float x1, y1, x2, y2; };   // inlier correspondence of an edge: keypoint of image i, keypoint of image j
+
+struct Adjuster {
+    int n = 0;
+    std::vector<Edge> edges;
+    std::vector<std::vector<Obs>> obs;    // per edge
+    int total = 0;
+    std::vector<double> cam;              // 7 per camera: focal, ppx, ppy, aspect, rvec
+    uint8_t refine[5] = {1, 1, 1, 1, 1};   // focal, skew (unused), ppx, aspect, ppy  -- ba_refine_mask "xxxxx"
+
+    void calc_error(std::vector<double>& err) const {
+        err.assign((size_t)total * 2, 0.);
+        int m = 0;
+        for (size_t e = 0; e < edges.size(); e++) {
+            const int i = edges[e].i, j = edges[e].j;
+            const double f1 = cam[i * 7], f2 = cam[j * 7], ppx1 = cam[i * 7 + 1], ppx2 = cam[j * 7 + 1], ppy1 = cam[i * 7 + 2], ppy2 = cam[j * 7 + 2];
+            const double a1 = cam[i * 7 + 3], a2 = cam[j * 7 + 3];
+            double R1[9], R2[9], R2i[9];
+            rodrigues_to_mat(&cam[i * 7 + 4], R1);
+            rodrigues_to_mat(&cam[j * 7 + 4], R2);
+            const double K1[9] = {f1, 0, ppx1, 0, f1 * a1, ppy1, 0, 0, 1}, K2[9] = {f2, 0, ppx2, 0, f2 * a2, ppy2, 0, 0, 1};
+            double K1i[9], H[9];
+            inv3(K1, K1i);
+            inv3(R2, R2i);
+            mul3(K2, R2i, H); mul3(H, R1, H); mul3(H, K1i, H);      // H1to2 = K2 * R2^-1 * R1 * K1^-1
+            for (const Obs& o : obs[e]) {
+                const double x = H[0] * o.x1 + H[1] * o.y1 + H[2], y = H[3] * o.x1 + H[4] * o.y1 + H[5], z = H[6] * o.x1 + H[7] * o.y1 + H[8];
+                err[2 * m] = o.x2 - x / z;
+                err[2 * m + 1] = o.y2 - y / z;
+                m++;
+            }
+        }
+    }
+    void calc_jacobian(Mat& J) {
+        const double step = 1e-4;
+        std::vector<double> e1, e2;
+        for (int i = 0; i < n; i++) {
+            // columns: 0 focal, 1 ppx, 2 ppy, 3 aspect, 4..6 rotation; refinement mask positions (0,0) (0,2) (1,2) (1,1)
+            const bool on[7] = {(bool)refine[0], (bool)refine[2], (bool)refine[4], (bool)refine[3], true, true, true};
+            for (int j = 0; j < 7; j++) {
+                if (!on[j]) continue;
+                const double val = cam[i * 7 + j];
+                cam[i * 7 + j] = val - step; calc_error(e1);
+                cam[i * 7 + j] = val + step; calc_error(e2);
+                for (int k = 0; k < J.r; k++) J(k, i * 7 + j) = (e2[k] - e1[k]) / (2 * step);
+                cam[i * 7 + j] = val;
+            }
+        }
+    }
+};
+
+// stitching/src/motion_estimators.cpp findMaxSpanningTree: Kruskal on num_inliers (descending), then the tree's centres
+void max_spanning_tree_centers(int n, const MisMatchesInfo* pm, std::vector<int>& centers) {
+    struct GE { int from, to; float w; };
+    std::vector<GE> all;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            if (pm[i * n + j].has_H == 0) continue;
+            const float w = (float)pm[i * n + j].num_inliers;
+            all.push_back({i, j, w});
+        }
+    std::stable_sort(all.begin(), all.end(), [](const GE& a, const GE& b) { return a.w > b.w; });
+    std::vector<int> parent(n), rnk(n, 0);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int e) { int s = e; while (s != parent[s]) s = parent[s]; while (e != parent[e]) { int nx = parent[e]; parent[e] = s; e = nx; } return s; };
+    std::vector<std::vector<int>> adj(n);
+    std::vector<int> power(n, 0);
+    for (const GE& e : all) {
+        int c1 = find(e.from), c2 = find(e.to);
+        if (c1 == c2) continue;
+        if (rnk[c1] < rnk[c2]) parent[c1] = c2; else if (rnk[c2] < rnk[c1]) parent[c2] = c1; else { parent[c1] = c2; rnk[c2]++; }
+        adj[e.from].push_back(e.to); adj[e.to].push_back(e.from);
+        power[e.from]++; power[e.to]++;
+    }
+    std::vector<int> leafs;
+    for (int i = 0; i < n; i++) if (power[i] == 1) leafs.push_back(i);
+    // distance from every leaf (BFS); the centres minimise the maximum distance to a leaf
+    std::vector<int> max_dists(n, 0);
+    for (int leaf : leafs) {
+        std::vector<int> dist(n, -1), q{leaf};
+        dist[leaf] = 0;
+        for (size_t h = 0; h < q.size(); h++) for (int v : adj[q[h]]) if (dist[v] < 0) { dist[v] = dist[q[h]] + 1; q.push_back(v); }
+        for (int i = 0; i < n; i++) if (dist[i] >= 0) max_dists[i] = std::max(max_dists[i], dist[i]);
+    }
+    int mn = max_dists.empty() ? 0 : *std::min_element(max_dists.begin(), max_dists.end());
+    centers.clear();
+    for (int i = 0; i < n; i++) if (max_dists[i] == mn) centers.push_back(i);
+}
+
+// symmetric 3x3 eigen decomposition (cv::eigen = Jacobi): eigenvalues descending, eigenvectors as rows
+void eigen3(const double* Ain, double* evals, double* evecs) {
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(A, Ain, sizeof(A));
+    for (int sweep = 0; sweep < 60; sweep++) {
+        int p = 0, q = 1;
+        double mx = std::fabs(A[1]);
+        if (std::fabs(A[2]) > mx) { mx = std::fabs(A[2]); p = 0; q = 2; }
+        if (std::fabs(A[5]) > mx) { mx = std::fabs(A[5]); p = 1; q = 2; }
+        if (mx <= DBL_EPSILON) break;
+        const double app = A[p * 3 + p], aqq = A[q * 3 + q], apq = A[p * 3 + q];
+        const double y = (aqq - app) * 0.5;
+        double t = std::fabs(y) + hypot(apq, y), s = hypot(apq, t), c = t / s;
+        s = apq / s; t = (apq / t) * apq;
+        if (y < 0) { s = -s; t = -t; }
+        A[p * 3 + q] = A[q * 3 + p] = 0;
+        A[p * 3 + p] -= t; A[q * 3 + q] += t;
+        const int r = 3 - p - q;
+        const double arp = A[r * 3 + p], arq = A[r * 3 + q];
+        A[r * 3 + p] = A[p * 3 + r] = arp * c - arq * s;
+        A[r * 3 + q] = A[q * 3 + r] = arp * s + arq * c;
+        for (int k = 0; k < 3; k++) { const double vp = V[p * 3 + k], vq = V[q * 3 + k]; V[p * 3 + k] = vp * c - vq * s; V[q * 3 + k] = vp * s + vq * c; }
+    }
+    int idx[3] = {0, 1, 2};
+    std::sort(idx, idx + 3, [&](int a, int b) { return A[a * 3 + a] > A[b * 3 + b]; });
+    for (int i = 0; i < 3; i++) { evals[i] = A[idx[i] * 3 + idx[i]]; for (int k = 0; k < 3; k++) evecs[i * 3 + k] = V[idx[i] * 3 + k]; }
+}
+
+}  // namespace
+
+extern "C" int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* features, const MisMatchesInfo* pairwise, int n, float conf_thresh,
+                                        const char* refine_mask, MisCameraParams* cameras) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, features && pairwise && cameras && n >= 2, MIS_E_INVALID, "null argument or fewer than two cameras");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    Adjuster ad;
+    ad.n = n;
+    if (refine_mask && strlen(refine_mask) >= 5)
+        for (int k = 0; k < 5; k++) ad.refine[k] = refine_mask[k] == 'x';
+    // keypoints of every image to the host (a few hundred KB)
+    std::vector<std::vector<MisKeyPoint>> kps(n);
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) {
+        kps[i].resize((size_t)std::max(features[i].n, 0));
+        if (features[i].n > 0) MIS_HIP(ctx, hipMemcpy(kps[i].data(), features[i].keypoints, sizeof(MisKeyPoint) * (size_t)features[i].n, hipMemcpyDeviceToHost));
+    }
+    // setUpInitialCameraParams: R projected on SO(3) through its SVD, then Rodrigues
+    ad.cam.assign((size_t)n * 7, 0.);
+    for (int i = 0; i < n; i++) {
+        ad.cam[i * 7] = cameras[i].focal; ad.cam[i * 7 + 1] = cameras[i].ppx; ad.cam[i * 7 + 2] = cameras[i].ppy; ad.cam[i * 7 + 3] = cameras[i].aspect;
+        double u[9], w[3], vt[9], R[9];
+        svd3(cameras[i].R, u, w, vt);
+        mul3(u, vt, R);
+        if (det3(R) < 0) for (double& v : R) v = -v;
+        rodrigues_to_vec(R, &ad.cam[i * 7 + 4]);
+    }
+    // leave only consistent image pairs
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++) {
+            const MisMatchesInfo& mi = pairwise[i * n + j];
+            if (!(mi.confidence > conf_thresh)) continue;
+            std::vector<Obs> ob;
+            for (int k = 0; k < mi.n_matches; k++) {
+                if (!mi.inliers_mask || !mi.inliers_mask[k]) continue;
+                const MisDMatch& m = mi.matches[k];
+                MIS_CHECK(ctx, m.query_idx >= 0 && m.query_idx < (int)kps[i].size() && m.train_idx >= 0 && m.train_idx < (int)kps[j].size(), MIS_E_INVALID,
+                          "match indices of pair (%d, %d) exceed the feature counts", i, j);
+                ob.push_back({kps[i][m.query_idx].x, kps[i][m.query_idx].y, kps[j][m.train_idx].x, kps[j][m.train_idx].y});
+            }
+            ad.edges.push_back({i, j});
+            ad.total += (int)ob.size();
+            ad.obs.push_back(std::move(ob));
+        }
+    MIS_CHECK(ctx, ad.total > 0, MIS_E_INVALID, "bundle adjustment: no image pair above the confidence threshold");
+    LevMarq solver(n * 7, ad.total * 2, 1000, DBL_EPSILON);   // TermCriteria(EPS + COUNT, 1000, DBL_EPSILON)
+    solver.param = ad.cam;
+    const bool trace = getenv("MIS_BA_TRACE") != nullptr;
+    for (;;) {
+        bool want_J, want_err;
+        const bool proceed = solver.update(want_J, want_err);
+        if (trace) fprintf(stderr, "[ba] state %d iters %d lambdaLg10 %d prevErr %.6g err %.6g\n", solver.state, solver.iters, solver.lambdaLg10, solver.prevErrNorm, solver.errNorm);
+        ad.cam = solver.param;
+        if (!proceed || !want_err) break;
+        if (want_J) ad.calc_jacobian(solver.J);
+        if (want_err) ad.calc_error(solver.err);
+    }
+    for (double v : ad.cam) MIS_CHECK(ctx, std::isfinite(v), MIS_E_INVALID, "bundle adjustment diverged (non-finite camera parameter)");
+    // obtainRefinedCameraParams
+    for (int i = 0; i < n; i++) {
+        cameras[i].focal = ad.cam[i * 7]; cameras[i].ppx = ad.cam[i * 7 + 1]; cameras[i].ppy = ad.cam[i * 7 + 2]; cameras[i].aspect = ad.cam[i * 7 + 3];
+        rodrigues_to_mat(&ad.cam[i * 7 + 4], cameras[i].R);
+    }
+    // normalise the motion to the centre image of the maximum spanning tree
+    std::vector<int> centers;
+    max_spanning_tree_centers(n, pairwise, centers);
+    if (!centers.empty()) {
+        double Rinv[9];
+        if (inv3(cameras[centers[0]].R, Rinv))
+            for (int i = 0; i < n; i++) mul3(Rinv, cameras[i].R, cameras[i].R);
+    }
+    return MIS_OK;
+}
+
+// detail::waveCorrect (motion_estimators.cpp): kind 0 = WAVE_CORRECT_HORIZ, 1 = WAVE_CORRECT_VERT; rmats: n x 9 doubles
+extern "C" int mis_wave_correct(double* rmats, int n, int kind) {
+    if (!rmats || n < 1 || (kind != 0 && kind != 1)) return MIS_E_INVALID;
+    if (n <= 1) return MIS_OK;
+    double moment[9] = {0};
+    for (int i = 0; i < n; i++) {
+        const double* R = rmats + 9 * i;
+        const double col[3] = {R[0], R[3], R[6]};   // first column: the camera's x axis
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) moment[a * 3 + b] += col[a] * col[b];
+    }
+    double evals[3], evecs[9];
+    eigen3(moment, evals, evecs);
+    double rg1[3];
+    if (kind == 0) memcpy(rg1, evecs + 6, sizeof(rg1));   // HORIZ: the eigenvector of the smallest eigenvalue
+    else memcpy(rg1, evecs, sizeof(rg1));                 // VERT: of the largest
+    double img_k[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) { img_k[0] += rmats[9 * i + 2]; img_k[1] += rmats[9 * i + 5]; img_k[2] += rmats[9 * i + 8]; }   // sum of the z axes
+    double rg0[3] = {rg1[1] * img_k[2] - rg1[2] * img_k[1], rg1[2] * img_k[0] - rg1[0] * img_k[2], rg1[0] * img_k[1] - rg1[1] * img_k[0]};
+    const double rg0n = std::sqrt(rg0[0] * rg0[0] + rg0[1] * rg0[1] + rg0[2] * rg0[2]);
+    if (rg0n <= DBL_MIN) return MIS_OK;
+    for (double& v : rg0) v /= rg0n;
+    double rg2[3] = {rg0[1] * rg1[2] - rg0[2] * rg1[1], rg0[2] * rg1[0] - rg0[0] * rg1[2], rg0[0] * rg1[1] - rg0[1] * rg1[0]};
+    double conf = 0;
+    if (kind == 0) {
+        for (int i = 0; i < n; i++) conf += rg0[0] * rmats[9 * i] + rg0[1] * rmats[9 * i + 3] + rg0[2] * rmats[9 * i + 6];
+        if (conf < 0) { for (double& v : rg0) v = -v; for (double& v : rg1) v = -v; }
+    } else {
+        for (int i = 0; i < n; i++) conf -= rg1[0] * rmats[9 * i] + rg1[1] * rmats[9 * i + 3] + rg1[2] * rmats[9 * i + 6];
+        if (conf < 0) { for (double& v : rg0) v = -v; for (double& v : rg1) v = -v; }
+    }
+    const double Rg[9] = {rg0[0], rg0[1], rg0[2], rg1[0], rg1[1], rg1[2], rg2[0], rg2[1], rg2[2]};
+    for (int i = 0; i < n; i++) mul3(Rg, rmats + 9 * i, rmats + 9 * i);
+    return MIS_OK;
+}

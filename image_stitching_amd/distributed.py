@@ -163,6 +163,9 @@ class HipEngine:
     def confidence_tensor(self, pm, n):
         return torch.from_numpy(pm.confidences()).to(self.ctx.device).view(n, n)
 
+    def refine_cameras(self, feats, pm, indices, cams):
+        return st.refine_cameras(self.ctx, feats, pm, indices, cams, self.cfg)
+
     # ---- compose ----
     def warp_roi(self, scale, cam):
         return st.warp_roi(scale, self.frame_size, cam["K"], cam["R"])
@@ -210,6 +213,8 @@ class StitchJob:
 
     def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
         self.cfg = config or st.StitchConfig()
+        if self.cfg.ba_cost_func != "no" and world_size > 1:
+            raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
         self.n = len(cameras)
@@ -355,7 +360,10 @@ class StitchJob:
 
     def run(self, frames):
         feats = self.stage_gather(self.stage_features(frames))
-        spec = getattr(self.engine, "speculative_compose", False)
+        refine = self.cfg.ba_cost_func != "no"
+        if refine and self.world > 1:
+            raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
+        spec = getattr(self.engine, "speculative_compose", False) and not refine   # refined cameras: compose must wait
         if spec:
             # Speculation: almost always every frame survives the pruning, and warp + blend do not depend on the
             # matches otherwise (the cameras are inputs).  Compose for ALL frames on the second stream from a helper
@@ -386,6 +394,14 @@ class StitchJob:
         else:
             pm, conf = self.stage_match(feats)
             indices = self.stage_prune(conf)
+            if refine:
+                if self.cfg.ba_cost_func != "reproj":
+                    raise ValueError("ba_cost_func must be 'no' or 'reproj'")
+                refined = self.engine.refine_cameras(feats, pm, indices, self.cams)
+                self.cams = list(self.cams)
+                for i, c in zip(indices, refined):
+                    self.cams[i] = c
+                self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])
             btype, bands = self.stage_compose(frames, indices)
             self.stage_reduce()
             pano, mask = self.stage_finalize()

@@ -629,6 +629,75 @@ def leaveBiggestComponentConf(confidence, conf_threshold):
     return idx[: k.value].copy()
 
 
+WAVE_CORRECT_HORIZ, WAVE_CORRECT_VERT = 0, 1
+
+
+def refine_cameras(ctx, features, pairwise_matches, indices, cameras, cfg):
+    """The reference's sequence after the pruning (image_stitching.cpp:671-726) on the kept subset: bundle adjustment
+    of the subset's cameras (features / matches re-indexed as leaveBiggestComponent does), then wave correction.
+    cameras: dicts with K (3x3), R; returns new dicts for the kept frames, in the order of `indices`."""
+    n, k = pairwise_matches.n, len(indices)
+    sub = (capi.MisMatchesInfo * (k * k))()
+    for a, i in enumerate(indices):
+        for b, j in enumerate(indices):
+            C.memmove(C.byref(sub[a * k + b]), C.byref(pairwise_matches._mis[i * n + j]), C.sizeof(capi.MisMatchesInfo))
+            sub[a * k + b].src_img_idx, sub[a * k + b].dst_img_idx = a, b
+    view = PairwiseMatches.__new__(PairwiseMatches)
+    view._ctx, view._mis, view.n, view._cache = ctx, sub, k, {}
+    view._owner = pairwise_matches              # the match arrays belong to the full table
+    start = [dict(focal=float(cameras[i]["K"][0, 0]), aspect=float(cameras[i]["K"][1, 1] / cameras[i]["K"][0, 0]), ppx=float(cameras[i]["K"][0, 2]),
+                  ppy=float(cameras[i]["K"][1, 2]), R=cameras[i]["R"]) for i in indices]
+    try:
+        refined = bundle_adjust_reproj(ctx, [features[i] for i in indices], view, start, cfg.conf_thresh, cfg.ba_refine_mask)
+    finally:
+        view._mis = None                        # borrowed entries: nothing to free
+    if cfg.wave_correct != "no":
+        Rs = wave_correct([c["R"] for c in refined], WAVE_CORRECT_VERT if cfg.wave_correct == "vert" else WAVE_CORRECT_HORIZ)
+        for c, R in zip(refined, Rs):
+            c["R"] = R
+    out = []
+    for i, c in zip(indices, refined):
+        d = dict(cameras[i])
+        d["K"] = np.array([[c["focal"], 0, c["ppx"]], [0, c["focal"] * c["aspect"], c["ppy"]], [0, 0, 1]], np.float64)
+        d["R"] = c["R"]
+        d["f"] = c["focal"]
+        out.append(d)
+    return out
+
+
+def bundle_adjust_reproj(ctx, features, pairwise_matches, cameras, conf_thresh=0.95, refine_mask="xxxxx"):
+    """(*makePtr<detail::BundleAdjusterReproj>())(features, pairwise_matches, cameras) with setConfThresh /
+    setRefinementMask (image_stitching.cpp:681-712).  cameras: list of dicts with focal, ppx, ppy, R (3x3) and
+    optionally aspect, t -> new list of dicts (refined; rotations relative to the spanning tree's centre image)."""
+    n = len(features)
+    if not isinstance(pairwise_matches, PairwiseMatches):
+        raise TypeError("pairwise_matches must be the PairwiseMatches object a BestOf2NearestMatcher call returned")
+    arr = (capi.MisFeatures * n)()
+    for k, f in enumerate(features):
+        C.memmove(C.byref(arr[k]), C.byref(f.raw), C.sizeof(capi.MisFeatures))
+    cams = (capi.MisCameraParams * n)()
+    for k, c in enumerate(cameras):
+        cams[k].focal, cams[k].aspect, cams[k].ppx, cams[k].ppy = float(c["focal"]), float(c.get("aspect", 1.0)), float(c["ppx"]), float(c["ppy"])
+        R = np.asarray(c["R"], np.float64).reshape(9)
+        t = np.asarray(c.get("t", np.zeros(3)), np.float64).reshape(3)
+        for i in range(9):
+            cams[k].R[i] = R[i]
+        for i in range(3):
+            cams[k].t[i] = t[i]
+    ctx.check(ctx.lib.mis_bundle_adjust_reproj(ctx.h, arr, pairwise_matches._mis, n, float(conf_thresh), refine_mask.encode(), cams))
+    return [dict(focal=cams[k].focal, aspect=cams[k].aspect, ppx=cams[k].ppx, ppy=cams[k].ppy, R=np.array(list(cams[k].R)).reshape(3, 3),
+                 t=np.array(list(cams[k].t))) for k in range(n)]
+
+
+def wave_correct(rmats, kind=WAVE_CORRECT_HORIZ):
+    """detail::waveCorrect(rmats, kind) (image_stitching.cpp:718-726) -> list of corrected 3x3 rotations."""
+    a = np.ascontiguousarray(np.stack([np.asarray(r, np.float64).reshape(3, 3) for r in rmats]))
+    rc = capi.load().mis_wave_correct(a.ctypes.data_as(C.c_void_p), len(rmats), int(kind))
+    if rc != capi.MIS_OK:
+        raise MisError(rc, "mis_wave_correct")
+    return [a[i].copy() for i in range(len(rmats))]
+
+
 def find_homography(ctx, src, dst, thresh=3.0, max_iters=2000, confidence=0.995):
     """cv::findHomography(src, dst, mask, RANSAC) on the GPU -> (ok, H, mask)."""
     src = np.ascontiguousarray(src, np.float32)
@@ -657,6 +726,11 @@ class StitchConfig:
     warp_type: str = "spherical"
     blend_type: int = capi.BLEND_MULTI_BAND
     blend_strength: float = 5.0
+    # camera refinement between matching and warping (image_stitching.cpp:681-726).  The reference's default is
+    # "reproj"; here the default is "no" because the jobs of this package take exact (sensor / ground-truth) cameras.
+    ba_cost_func: str = "no"          # "no" | "reproj"
+    ba_refine_mask: str = "xxxxx"
+    wave_correct: str = "horiz"       # "horiz" | "vert" | "no"; applied after the bundle adjustment only
 
 
 class Stitcher:

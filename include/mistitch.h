@@ -158,6 +158,22 @@ int mis_leave_biggest_component(const MisMatchesInfo* pairwise, int n, float con
 /* the same on the bare n x n confidence matrix (row-major; what a sharded job has after its all-reduce) */
 int mis_leave_biggest_component_conf(const double* confidence, int n, float conf_threshold, int* indices, int* n_indices);
 
+/* ---------------------------------------------------------------- camera refinement --------- */
+/* cv::detail::CameraParams (focal, aspect, ppx, ppy, R, t) as the reference fills it (image_stitching.cpp:485-517) */
+typedef struct {
+    double focal, aspect, ppx, ppy;
+    double R[9];   /* row-major */
+    double t[3];
+} MisCameraParams;
+/* (*adjuster)(features, pairwise_matches, cameras) with makePtr<detail::BundleAdjusterReproj>(), setConfThresh,
+ * setRefinementMask -- replaces image_stitching.cpp:681-712.  Host logic (as in OpenCV): Levenberg-Marquardt over 7
+ * parameters per camera on the inlier correspondences of the pairs above conf_thresh; refine_mask = the reference's
+ * ba_refine_mask string ("xxxxx"); the rotations are normalised to the centre of the maximum spanning tree. */
+int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* features, const MisMatchesInfo* pairwise, int n, float conf_thresh,
+                             const char* refine_mask, MisCameraParams* cameras);
+/* waveCorrect(rmats, wave_correct) -- replaces image_stitching.cpp:718-726; rmats: n x 9 doubles in place; kind 0 = HORIZ, 1 = VERT */
+int mis_wave_correct(double* rmats, int n, int kind);
+
 /* ---------------------------------------------------------------- warp ---------------------- */
 /* warper->warpRoi(sz, K, R) -- replaces image_stitching.cpp:1138 (K, R: 3x3 f32 row-major) */
 int mis_warp_roi(float scale, int src_width, int src_height, const float K[9], const float R[9], MisRect* roi);
