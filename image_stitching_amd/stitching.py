@@ -729,7 +729,7 @@ class StitchConfig:
     # camera refinement between matching and warping (image_stitching.cpp:681-726).  The reference's default is
     # "reproj"; here the default is "no" because the jobs of this package take exact (sensor / ground-truth) cameras.
     ba_cost_func: str = "no"          # "no" | "reproj"
-    ba_refine_mask: str = "xxxxx"
+    ba_refine_mask: str = "_____"     # the reference's default (image_stitching.cpp:67): rotations only
     wave_correct: str = "horiz"       # "horiz" | "vert" | "no"; applied after the bundle adjustment only
 
 

@@ -117,7 +117,7 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
         d = dict(c)
         d["R"] = synth.rotation_yxz(*np.radians(rng.normal(0, 0.5, 3))) @ c["R"]
         noisy.append(d)
-    job = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig(ba_cost_func="reproj"))
+    job = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig(ba_cost_func="reproj", ba_refine_mask="xxxxx"))
     out = job.run(frames)
     assert out["indices"] == list(range(n))
     # The adjustment minimises the reprojection error of the inlier matches; with focal, aspect and principal point free
@@ -130,6 +130,12 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
     e_refined = _reproj_rms(feats, pm, n, [_as_params(c) for c in job.cams], strong)
     print("reprojection rms (px): noisy %.2f exact %.2f refined %.2f" % (e_noisy, e_exact, e_refined))
     assert e_noisy > 4 * e_exact and e_refined < 1.2 * e_exact + 0.2
+    # the reference's default mask "_____" refines the rotations only: intrinsics stay, the error still collapses
+    job2 = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig(ba_cost_func="reproj"))
+    job2.run(frames)
+    for a, b in zip(job2.cams, noisy):
+        assert np.array_equal(a["K"], b["K"])
+    assert _reproj_rms(feats, pm, n, [_as_params(c) for c in job2.cams], strong) < 1.3 * e_exact + 0.3
     pw, ph = out["pano_size"]
     assert pw > 2 * w * 0.8 and out["mask"].float().mean() > 100            # a panorama of sensible extent came out
     # the multi-rank path refuses the refinement (matches are sharded)
