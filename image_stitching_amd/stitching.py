@@ -224,6 +224,66 @@ def seam_mask_apply(ctx, seam_mask_warped, mask_warped):
     return mask_warped
 
 
+class BlocksGainCompensator:
+    """cv::detail::BlocksGainCompensator as the reference configures it (image_stitching.cpp:1002-1023): 64x64 blocks,
+    one feed, two gain-filtering passes.  feed() takes the seam-scale warped images / masks and their corners;
+    apply() multiplies an 8UC3 (or the fused warp's 16SC3) image by the gains, in place."""
+
+    def __init__(self, ctx, bl_width=64, bl_height=64, nr_gain_filtering_iterations=2):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mis_compensator_create(ctx.h, bl_width, bl_height, nr_gain_filtering_iterations, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mis_compensator_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def feed(self, corners, images, masks):
+        n = len(images)
+        cs = (capi.MisPoint * n)(*[capi.MisPoint(int(c[0]), int(c[1])) for c in corners])
+        im = (capi.MisImage * n)(*[as_image(i) for i in images])
+        mk = (capi.MisImage * n)(*[as_image(m) for m in masks])
+        self.ctx.check(self.ctx.lib.mis_compensator_feed(self.h, cs, im, mk, n))
+
+    def gain_map(self, index):
+        bx, by = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.mis_compensator_gain_map(self.h, index, None, 0, C.byref(bx), C.byref(by)))
+        out = np.zeros((by.value, bx.value), np.float32)
+        self.ctx.check(self.ctx.lib.mis_compensator_gain_map(self.h, index, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, None, None))
+        return out
+
+    def apply(self, index, corner, image, mask=None):
+        """corner and mask are accepted for signature parity (OpenCV ignores them too)."""
+        img = as_image(image)
+        self.ctx.check(self.ctx.lib.mis_compensator_apply(self.h, index, C.byref(img)))
+        return image
+
+
+class NoSeamFinder:
+    """seam_find_type "no" (image_stitching.cpp:1029): masks stay as warped."""
+
+    def find(self, images, corners, masks):
+        return masks
+
+
+class VoronoiSeamFinder:
+    """seam_find_type "voronoi" (image_stitching.cpp:1031); images are not looked at."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def find(self, images, corners, masks):
+        n = len(masks)
+        cs = (capi.MisPoint * n)(*[capi.MisPoint(int(c[0]), int(c[1])) for c in corners])
+        mk = (capi.MisImage * n)(*[as_image(m) for m in masks])
+        self.ctx.check(self.ctx.lib.mis_seam_voronoi(self.ctx.h, cs, mk, n))
+        return masks
+
+
 # ------------------------------------------------------------------------------------------------
 # blend: cv::detail::Blender / MultiBandBlender / FeatherBlender (image_stitching.cpp:1173-1225)
 def result_roi(corners, sizes):
@@ -731,13 +791,19 @@ class StitchConfig:
     ba_cost_func: str = "no"          # "no" | "reproj"
     ba_refine_mask: str = "_____"     # the reference's default (image_stitching.cpp:67): rotations only
     wave_correct: str = "horiz"       # "horiz" | "vert" | "no"; applied after the bundle adjustment only
+    # the seam-scale step between warp and blend (image_stitching.cpp:940-1070, :1162-1171).  The reference's defaults are
+    # "gain_blocks" and "dp_color"; DpSeamFinder is not implemented here (asking for it raises), so both default to "no".
+    expos_comp_type: str = "no"       # "no" | "gain_blocks"
+    expos_comp_block_size: int = 64
+    expos_comp_nr_filtering: int = 2
+    seam_find_type: str = "no"        # "no" | "voronoi"
 
 
 class Stitcher:
     """The hot-path sequence of main() (image_stitching.cpp:567-1228) for frames already in HBM:
     features -> pairwise matches (+RANSAC) -> [cameras supplied by the caller] -> compose-scale
-    warp -> blend.  Bundle adjustment, exposure compensation and seam finding are outside the
-    hot path and are not run."""
+    warp -> blend.  Optional (off by default): reprojection bundle adjustment with wave
+    correction (refine_cameras), block gain compensation and the "voronoi" seam finder (seam_step)."""
 
     def __init__(self, ctx, frame_size, config=None):
         self.ctx = ctx
@@ -780,10 +846,49 @@ class Stitcher:
             else:
                 blender = Blender(self.ctx)
         blender.prepare(corners, sizes)
+        seam = self.seam_step(frames, cameras, indices, scale)
         for k, i in enumerate(indices):
             tl, img_s, mask = warper.warp_fused(frames[i], cameras[i]["K"], cameras[i]["R"], rois[k])
+            if seam is not None:
+                compensator, seam_masks = seam
+                if compensator is not None:
+                    compensator.apply(k, corners[k], img_s, mask)       # :1162 (on the 16S copy: same values)
+                seam_mask_apply(self.ctx, seam_masks[k], mask)           # :1169-1171
             blender.feed(img_s, mask, tl)
         return blender.blend()
+
+    def seam_step(self, frames, cameras, indices, warped_image_scale, work_scale=1.0):
+        """The seam-scale pass of main() (image_stitching.cpp:604-622 resize, :973-990 warp, :1002-1023 exposure
+        compensator feed, :1029-1065 seam finder) -> (compensator | None, masks_warped) or None when both are off."""
+        cfg = self.cfg
+        if cfg.seam_find_type not in ("no", "voronoi"):
+            raise NotImplementedError("seam_find_type %r: only 'no' and 'voronoi' are implemented (DpSeamFinder / GraphCut "
+                                      "are outside this library; DESIGN.md section 9)" % (cfg.seam_find_type,))
+        if cfg.expos_comp_type not in ("no", "gain_blocks"):
+            raise NotImplementedError("expos_comp_type %r: only 'no' and 'gain_blocks' are implemented" % (cfg.expos_comp_type,))
+        if cfg.expos_comp_type == "no" and cfg.seam_find_type == "no":
+            return None
+        w, h = self.frame_size
+        seam_scale = min(1.0, float(np.sqrt(cfg.seam_megapix * 1e6 / (w * h))))
+        swa = np.float32(seam_scale / work_scale)
+        warper = SphericalWarper(self.ctx, np.float32(np.float32(warped_image_scale) * swa))
+        corners, images_warped, masks_warped = [], [], []
+        for i in indices:
+            img = resize(self.ctx, frames[i], fx=seam_scale, fy=seam_scale) if seam_scale < 1.0 else frames[i]
+            K = np.array(cameras[i]["K"], np.float32).copy()
+            K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
+            R = np.asarray(cameras[i]["R"], np.float32)
+            tl, iw = warper.warp(img, K, R, capi.INTER_LINEAR, capi.BORDER_REFLECT)
+            full = torch.full((img.shape[0], img.shape[1]), 255, dtype=torch.uint8, device=self.ctx.device)
+            _, mw = warper.warp(full, K, R, capi.INTER_NEAREST, capi.BORDER_CONSTANT)
+            corners.append(tl); images_warped.append(iw); masks_warped.append(mw)
+        compensator = None
+        if cfg.expos_comp_type == "gain_blocks":
+            compensator = BlocksGainCompensator(self.ctx, cfg.expos_comp_block_size, cfg.expos_comp_block_size, cfg.expos_comp_nr_filtering)
+            compensator.feed(corners, images_warped, masks_warped)
+        if cfg.seam_find_type == "voronoi":
+            VoronoiSeamFinder(self.ctx).find(images_warped, corners, masks_warped)
+        return compensator, masks_warped
 
     def stitch(self, frames, cameras):
         feats = self.features(frames)

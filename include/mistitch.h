@@ -219,6 +219,23 @@ int mis_rotate(MisContext* ctx, const MisImage* src, int rotate_code, MisImage* 
  * pass -- replaces image_stitching.cpp:1169-1171.  Both 8UC1; mask_warped is updated in place. */
 int mis_seam_mask_apply(MisContext* ctx, const MisImage* seam_mask_warped, MisImage* mask_warped);
 
+/* ---- exposure compensation and seam finders between warp and blend ----
+ * Replaces ExposureCompensator::createDefault(GAIN_BLOCKS) with setNrFeeds(1), setNrGainsFilteringIterations(2),
+ * setBlockSize(64, 64) (image_stitching.cpp:1002-1016), compensator->feed(corners, images_warped, masks_warped) (:1023) and
+ * compensator->apply(img_idx, corners[img_idx], img_warped, mask_warped) (:1162).  One feed only (the reference's value).
+ * Images are 8UC3, masks 8UC1 (255 = valid), host or device. */
+typedef struct MisCompensator MisCompensator;
+int mis_compensator_create(MisContext* ctx, int block_width, int block_height, int nr_gain_filtering_iterations, MisCompensator** out);
+int mis_compensator_destroy(MisCompensator* c);
+int mis_compensator_feed(MisCompensator* c, const MisPoint* corners, const MisImage* images, const MisImage* masks, int n);
+/* smoothed gain map of one image (one float per block, row-major); map_host may be NULL to query the grid size */
+int mis_compensator_gain_map(const MisCompensator* c, int index, float* map_host, int capacity, int* blocks_x, int* blocks_y);
+/* image *= gains, in place; 8UC3, or the 16SC3 image the fused warp produces (values 0..255) */
+int mis_compensator_apply(MisCompensator* c, int index, MisImage* image);
+/* VoronoiSeamFinder::find (seam_find_type "voronoi", image_stitching.cpp:1031): masks (8UC1) are edited in place.
+ * "no" (NoSeamFinder) needs no call.  The reference's default, DpSeamFinder(COLOR) ("dp_color"), is not implemented. */
+int mis_seam_voronoi(MisContext* ctx, const MisPoint* corners, MisImage* masks, int n);
+
 /* ---------------------------------------------------------------- blend --------------------- */
 /* reference-side blender sizing, image_stitching.cpp:1176-1190: returns the blend type to use in
  * *type_out and fills num_bands (MULTI_BAND) or sharpness (FEATHER) */

@@ -710,3 +710,64 @@ def gaussian_taps_f32(sigma):
     buf = (C.c_float * 64)()
     n = lib().mo_gaussian_taps_f32(C.c_double(sigma), buf)
     return np.array(buf[:n], np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# exposure compensation (GAIN_BLOCKS) and the Voronoi seam finder (mo_expos.c)
+class Compensator:
+    """BlocksGainCompensator(block 64x64, 1 feed, 2 gain-filtering passes by default)."""
+
+    def __init__(self, block_w=64, block_h=64, nr_filtering=2):
+        L = lib()
+        L.mo_compensator_create.restype = C.c_void_p
+        self.h_ = C.c_void_p(L.mo_compensator_create(block_w, block_h, nr_filtering))
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            lib().mo_compensator_destroy(self.h_)
+            self.h_ = None
+
+    def feed(self, corners, images, masks):
+        n = len(images)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+        msks = [np.ascontiguousarray(m, np.uint8) for m in masks]
+        c = np.ascontiguousarray(corners, np.int32).reshape(n, 2)
+        s = np.array([[m.shape[1], m.shape[0]] for m in msks], np.int32)
+        ip = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        mp = (C.c_void_p * n)(*[m.ctypes.data for m in msks])
+        rc = lib().mo_compensator_feed(self.h_, n, _p(c), _p(s), ip, mp)
+        if rc:
+            raise RuntimeError("mo_compensator_feed failed: %d" % rc)
+
+    def gain_map(self, index):
+        p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+        rc = lib().mo_compensator_gain_map(self.h_, index, C.byref(p), C.byref(w), C.byref(h))
+        if rc:
+            raise IndexError(index)
+        return _from_ptr(p.value, (h.value, w.value), np.float32)
+
+    def apply(self, index, image):
+        img = np.ascontiguousarray(image, np.uint8).copy()
+        h, w = img.shape[:2]
+        rc = lib().mo_compensator_apply(self.h_, index, _p(img), w, h)
+        if rc:
+            raise IndexError(index)
+        return img
+
+
+def solve_lu(A, b):
+    A = np.array(A, np.float64, order="C")
+    b = np.array(b, np.float64).reshape(-1).copy()
+    ok = lib().mo_solve_lu(_p(A), _p(b), A.shape[0])
+    return b if ok else None
+
+
+def voronoi_seams(corners, masks):
+    """VoronoiSeamFinder::find; returns the updated masks."""
+    n = len(masks)
+    msks = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
+    c = np.ascontiguousarray(corners, np.int32).reshape(n, 2)
+    s = np.array([[m.shape[1], m.shape[0]] for m in msks], np.int32)
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in msks])
+    lib().mo_voronoi_seams(n, _p(c), _p(s), mp)
+    return msks

@@ -1,0 +1,213 @@
+"""Exposure compensation (GAIN_BLOCKS) and the Voronoi seam finder through the C ABI against the oracle (SURVEY row N1b;
+image_stitching.cpp:1002-1065, :1162).  Gain maps are floats and must agree bit for bit; images and masks are bytes."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, n=3, with_holes=True):
+    """n overlapping 'warped' images cut from one random panorama with per-image gains, ragged sizes and mask holes."""
+    rng = np.random.default_rng(seed)
+    pano = rng.integers(30, 180, (420, 2000, 3)).astype(np.float32)
+    # smooth a little so blocks have structure
+    pano = (pano + np.roll(pano, 1, 0) + np.roll(pano, 1, 1)) / 3
+    corners, images, masks = [], [], []
+    x = 0
+    for i in range(n):
+        w, h = int(rng.integers(300, 420)), int(rng.integers(250, 330))
+        y = int(rng.integers(0, 60))
+        g = float(rng.uniform(0.7, 1.35))
+        img = np.clip(pano[y:y + h, x:x + w] * g, 0, 255).astype(np.uint8)
+        m = np.full((h, w), 255, np.uint8)
+        if with_holes:
+            # a slanted invalid wedge as warping leaves, plus a stray hole
+            yy, xx = np.mgrid[0:h, 0:w]
+            m[(xx + 2 * yy) < 90] = 0
+            m[40:60, w - 70:w - 30] = 0
+            img[m == 0] = 0
+        corners.append((x - 17, y - 9))
+        images.append(img)
+        masks.append(m)
+        x += int(w * rng.uniform(0.45, 0.7))
+    return corners, images, masks
+
+
+@pytest.mark.parametrize("seed,n,device_inputs", [(0, 3, True), (1, 4, False), (2, 2, True)])
+def test_blocks_gain_compensator_matches_oracle(ctx, seed, n, device_inputs):
+    from image_stitching_amd import stitching as S
+    corners, images, masks = _scene(seed, n)
+    ref = oracle.Compensator(64, 64, 2)
+    ref.feed(corners, images, masks)
+    comp = S.BlocksGainCompensator(ctx)
+    if device_inputs:
+        comp.feed(corners, [torch.from_numpy(i).cuda() for i in images], [torch.from_numpy(m).cuda() for m in masks])
+    else:
+        comp.feed(corners, images, masks)
+    moved = 0
+    for i in range(n):
+        g, r = comp.gain_map(i), ref.gain_map(i)
+        assert g.shape == r.shape
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), "gain map %d differs" % i
+        moved += int((np.abs(r - 1) > 0.02).sum())
+        # apply at a different ("compose") size than the fed one: the map is resized to the image
+        big = np.repeat(np.repeat(images[i], 2, 0), 2, 1)[: 2 * images[i].shape[0] - 3, : 2 * images[i].shape[1] - 5].copy()
+        want = ref.apply(i, big)
+        t = torch.from_numpy(big).cuda()
+        comp.apply(i, corners[i], t)
+        assert np.array_equal(t.cpu().numpy(), want)
+        t16 = torch.from_numpy(big.astype(np.int16)).cuda()
+        comp.apply(i, corners[i], t16)
+        assert np.array_equal(t16.cpu().numpy(), want.astype(np.int16))
+        host = big.copy()
+        comp.apply(i, corners[i], host)
+        assert np.array_equal(host, want)
+    assert moved > 0, "the scene must produce gains away from 1"
+
+
+def test_compensation_reduces_the_overlap_difference(ctx):
+    from image_stitching_amd import stitching as S
+    corners, images, masks = _scene(5, 3, with_holes=False)
+    comp = S.BlocksGainCompensator(ctx)
+    comp.feed(corners, images, masks)
+    out = []
+    for i, img in enumerate(images):
+        t = torch.from_numpy(img.copy()).cuda()
+        comp.apply(i, corners[i], t)
+        out.append(t.cpu().numpy())
+
+    def overlap_diff(imgs):
+        tot = 0.0
+        for i in range(len(imgs) - 1):
+            x0 = corners[i + 1][0] - corners[i][0]
+            w = imgs[i].shape[1] - x0
+            ya, yb = max(corners[i][1], corners[i + 1][1]), min(corners[i][1] + imgs[i].shape[0], corners[i + 1][1] + imgs[i + 1].shape[0])
+            a = imgs[i][ya - corners[i][1]:yb - corners[i][1], x0:x0 + w].astype(np.float64)
+            b = imgs[i + 1][ya - corners[i + 1][1]:yb - corners[i + 1][1], :w].astype(np.float64)
+            tot += np.abs(a - b).mean()
+        return tot
+
+    assert overlap_diff(out) < 0.5 * overlap_diff(images)
+
+
+def test_compensator_rejects_bad_arguments(ctx):
+    from image_stitching_amd import stitching as S
+    comp = S.BlocksGainCompensator(ctx)
+    img = np.zeros((10, 10, 3), np.uint8)
+    with pytest.raises(S.MisError):
+        comp.apply(0, (0, 0), img)            # nothing fed yet
+    with pytest.raises(S.MisError):
+        comp.feed([(0, 0)], [img], [np.zeros((9, 10), np.uint8)])   # mask size mismatch
+    with pytest.raises(S.MisError):
+        S.BlocksGainCompensator(ctx, 0, 64)
+
+
+@pytest.mark.parametrize("seed,n,device_inputs", [(0, 3, True), (3, 4, False)])
+def test_voronoi_seam_finder_matches_oracle(ctx, seed, n, device_inputs):
+    from image_stitching_amd import stitching as S
+    corners, images, masks = _scene(seed, n)
+    want = oracle.voronoi_seams(corners, masks)
+    finder = S.VoronoiSeamFinder(ctx)
+    if device_inputs:
+        ms = [torch.from_numpy(m.copy()).cuda() for m in masks]
+        finder.find(None, corners, ms)
+        got = [m.cpu().numpy() for m in ms]
+    else:
+        got = [m.copy() for m in masks]
+        finder.find(None, corners, got)
+    changed = 0
+    for g, w, m in zip(got, want, masks):
+        assert np.array_equal(g, w)
+        changed += int((g != m).sum())
+    assert changed > 0
+    # after the seams no pano pixel is claimed by two images
+    x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + m.shape[1] for c, m in zip(corners, got)); y1 = max(c[1] + m.shape[0] for c, m in zip(corners, got))
+    cover = np.zeros((y1 - y0, x1 - x0), np.int32)
+    before = np.zeros_like(cover)
+    for c, g, m in zip(corners, got, masks):
+        cover[c[1] - y0:c[1] - y0 + g.shape[0], c[0] - x0:c[0] - x0 + g.shape[1]] += g > 0
+        before[c[1] - y0:c[1] - y0 + g.shape[0], c[0] - x0:c[0] - x0 + g.shape[1]] += m > 0
+    assert cover.max() == 1
+    assert np.array_equal(cover > 0, before > 0), "the seams must not uncover any pano pixel"
+
+
+def test_no_seam_finder_is_identity():
+    from image_stitching_amd import stitching as S
+    m = [np.full((4, 4), 255, np.uint8)]
+    assert S.NoSeamFinder().find(None, [(0, 0)], m) is m
+
+
+def _oracle_compose(o, frames, cams, cfg, frame_size):
+    """main()'s seam-scale pass and compositing loop restated with the oracle (image_stitching.cpp:940-1225)."""
+    import image_stitching_amd as isa
+    w, h = frame_size
+    scale = isa.Stitcher.warped_image_scale(cams)
+    seam_scale = min(1.0, float(np.sqrt(cfg.seam_megapix * 1e6 / (w * h))))
+    swa = np.float32(seam_scale)
+    sscale = float(np.float32(np.float32(scale) * swa))
+    corners, iw, mw = [], [], []
+    for f, cam in zip(frames, cams):
+        img = o.resize_exact(f, fx=seam_scale, fy=seam_scale) if seam_scale < 1 else f
+        K = cam["K"].astype(np.float32).copy()
+        K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
+        R = cam["R"].astype(np.float32)
+        wi, tl = o.warp_spherical(img, sscale, K, R)
+        wm, _ = o.warp_spherical(np.full(img.shape[:2], 255, np.uint8), sscale, K, R, o.INTER_NEAREST, o.BORDER_CONSTANT)
+        corners.append(tl); iw.append(wi); mw.append(wm)
+    comp = None
+    if cfg.expos_comp_type == "gain_blocks":
+        comp = o.Compensator(cfg.expos_comp_block_size, cfg.expos_comp_block_size, cfg.expos_comp_nr_filtering)
+        comp.feed(corners, iw, mw)
+    if cfg.seam_find_type == "voronoi":
+        mw = o.voronoi_seams(corners, mw)
+    items = []
+    for k, (f, cam) in enumerate(zip(frames, cams)):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        img, tl = o.warp_spherical(f, scale, K, R)
+        msk, _ = o.warp_spherical(np.full(f.shape[:2], 255, np.uint8), scale, K, R, o.INTER_NEAREST, o.BORDER_CONSTANT)
+        if comp is not None:
+            img = comp.apply(k, img)
+        msk = o.seam_mask_apply(mw[k], msk)
+        items.append((img.astype(np.int16), msk, tl))
+    cs = [i[2] for i in items]; ss = [(i[1].shape[1], i[1].shape[0]) for i in items]
+    x0 = min(c[0] for c in cs); y0 = min(c[1] for c in cs)
+    x1 = max(c[0] + s[0] for c, s in zip(cs, ss)); y1 = max(c[1] + s[1] for c, s in zip(cs, ss))
+    btype, bands, sharp = o.blend_config(cfg.blend_type, cfg.blend_strength, x1 - x0, y1 - y0)
+    b = o.Blender(btype, bands, sharp)
+    b.prepare(cs, ss)
+    for img, msk, tl in items:
+        b.feed(img, msk, tl)
+    return b.blend()
+
+
+@pytest.mark.parametrize("expos,seam", [("gain_blocks", "voronoi"), ("gain_blocks", "no"), ("no", "voronoi")])
+def test_stitcher_compose_with_seam_step_matches_oracle(ctx, oracle_mod, expos, seam):
+    """Three frames with different exposures through seam-scale warp -> gains -> seams -> compose -> multiband blend."""
+    import synth
+    import image_stitching_amd as isa
+    W, H = 960, 540
+    cams = [synth.make_camera(W, H, 60.0, y, p, r) for y, p, r in [(0.0, 0.0, 0.0), (14.0, 0.8, -0.5), (27.0, -0.6, 0.4)]]
+    gains = [0.75, 1.0, 1.25]
+    frames = [np.clip(synth.render_frame(c).astype(np.float32) * g, 0, 255).astype(np.uint8) for c, g in zip(cams, gains)]
+    cfg = isa.StitchConfig(expos_comp_type=expos, seam_find_type=seam, seam_megapix=0.1)
+    st = isa.Stitcher(ctx, (W, H), cfg)
+    pano, mask = st.compose([torch.from_numpy(f).cuda() for f in frames], cams)
+    want, wmask = _oracle_compose(oracle_mod, frames, cams, cfg, (W, H))
+    assert np.array_equal(mask.cpu().numpy(), wmask)
+    assert np.array_equal(pano.cpu().numpy(), want)
+    plain, _ = isa.Stitcher(ctx, (W, H), isa.StitchConfig()).compose([torch.from_numpy(f).cuda() for f in frames], cams)
+    assert not np.array_equal(plain.cpu().numpy(), want), "the seam step must change the panorama"
+
+
+def test_unbuilt_seam_finders_are_refused(ctx):
+    import image_stitching_amd as isa
+    st = isa.Stitcher(ctx, (64, 64), isa.StitchConfig(seam_find_type="dp_color"))
+    with pytest.raises(NotImplementedError):
+        st.seam_step([], [], [], 100.0)
+    st = isa.Stitcher(ctx, (64, 64), isa.StitchConfig(expos_comp_type="channels"))
+    with pytest.raises(NotImplementedError):
+        st.seam_step([], [], [], 100.0)

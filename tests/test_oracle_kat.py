@@ -334,3 +334,50 @@ def test_sift_helpers(oracle_mod):
     t = o.gaussian_taps_f32(1.6)
     assert len(t) == 15 and abs(float(t.sum()) - 1.0) < 1e-6 and np.array_equal(t, t[::-1]) and t.argmax() == 7
     assert len(o.gaussian_taps_f32(1.2489996)) == 11
+
+
+# ---- exposure compensation / Voronoi seams (mo_expos.c; parity unpinned: analytic checks only) ----
+def test_oracle_lu_solve_matches_numpy(oracle_mod):
+    oracle = oracle_mod
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 40):
+        A = rng.normal(size=(n, n)) + np.eye(n) * 3
+        x = rng.normal(size=n)
+        got = oracle.solve_lu(A, A @ x)
+        assert got is not None and np.abs(got - x).max() < 1e-10
+    assert oracle.solve_lu(np.zeros((3, 3)), np.ones(3)) is None      # singular -> cv::solve returns false
+
+
+def test_oracle_gain_compensator_pulls_two_exposures_together(oracle_mod):
+    oracle = oracle_mod
+    rng = np.random.default_rng(0)
+    base = rng.integers(40, 200, (300, 700, 3)).astype(np.float32)
+    a = np.clip(base[:, :400] * 0.8, 0, 255).astype(np.uint8)
+    b = np.clip(base[:, 300:] * 1.2, 0, 255).astype(np.uint8)
+    ma, mb = np.full(a.shape[:2], 255, np.uint8), np.full(b.shape[:2], 255, np.uint8)
+    c = oracle.Compensator(64, 64, 2)
+    c.feed([(0, 0), (300, 0)], [a, b], [ma, mb])
+    ga, gb = c.gain_map(0), c.gain_map(1)
+    assert ga.shape == (5, 7) and gb.shape == (5, 7)                   # ceil(300/64) x ceil(400/64)
+    assert np.all(ga[:, :3] == 1.0) and np.all(gb[:, 4:] == 1.0)       # blocks that meet no other image keep gain 1
+    assert ga[:, -1].min() > 1.05 and gb[:, 0].max() < 0.9              # the dark image is lifted, the bright one lowered
+    oa, ob = c.apply(0, a), c.apply(1, b)
+    before = np.abs(a[:, 300:].astype(int) - b[:, :100].astype(int)).mean()
+    after = np.abs(oa[:, 300:].astype(int) - ob[:, :100].astype(int)).mean()
+    assert after < 0.4 * before
+    # a single image: every gain stays exactly 1 and apply is the identity
+    c.feed([(0, 0)], [a], [ma])
+    assert np.all(c.gain_map(0) == 1.0) and np.array_equal(c.apply(0, a), a)
+
+
+def test_oracle_voronoi_splits_a_symmetric_overlap_in_the_middle(oracle_mod):
+    oracle = oracle_mod
+    ma, mb = np.full((50, 400), 255, np.uint8), np.full((50, 400), 255, np.uint8)
+    a, b = oracle.voronoi_seams([(0, 0), (300, 0)], [ma, mb])
+    # overlap = pano x 300..399; equidistant pixels go to the first image ("dist1 < dist2" is strict -> mask1 is cleared)
+    assert np.all(a[:, :349] == 255) and np.all(a[:, 350:] == 0)
+    assert np.all(b[:, :49] == 0) and np.all(b[:, 50:] == 255)
+    assert ((a[:, 300:] > 0).astype(int) + (b[:, :100] > 0).astype(int)).max() == 1
+    # disjoint images are left alone
+    c, d = oracle.voronoi_seams([(0, 0), (500, 0)], [ma, mb])
+    assert np.array_equal(c, ma) and np.array_equal(d, mb)
