@@ -88,36 +88,57 @@ __global__ __launch_bounds__(256) void sift_upsample_kernel(const uint8_t* __res
 // tap index tests fold away.  N = 0: generic tap count (t.n).  The column pass optionally writes the DoG image
 // (this layer minus the previous one) as well, saving a pass over both.
 constexpr int BLK = 8;
+// Row pass: a workgroup owns ROW_SPAN consecutive outputs of one row.  The inputs (span + taps - 1, borders reflected)
+// are staged in LDS with coalesced loads, each thread then computes its BLK consecutive outputs out of registers
+// filled from LDS, and the results go back through LDS so that the stores are coalesced too.  LDS index i is stored at
+// i + i / 8: a thread's k-th read is word 9 * tid + k + k / 8, and 9 is odd, so the 64 lanes hit 64 different banks.
+constexpr int ROW_SPAN = 256 * BLK;
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 3); }
 template <int N>
 __global__ __launch_bounds__(256) void sift_blur_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Taps t) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * BLK, y = blockIdx.y;
-    if (x0 >= w) return;
+    __shared__ float lds[(ROW_SPAN + MAX_TAPS) + (ROW_SPAN + MAX_TAPS) / 8 + 8];
     const int n = N ? N : t.n, r = n / 2;
+    const int xb = blockIdx.x * ROW_SPAN, y = blockIdx.y, tid = threadIdx.x;
+    const int outs = min(ROW_SPAN, w - xb), span = outs + n - 1;
     const float* row = src + (size_t)y * w;
+    const bool inner = xb - r >= 0 && xb + outs - 1 + r < w;
+    if (inner)
+        for (int i = tid; i < span; i += 256) lds[lds_pad(i)] = row[xb + i - r];
+    else
+        for (int i = tid; i < span; i += 256) lds[lds_pad(i)] = row[mis_reflect101(xb + i - r, w)];
+    __syncthreads();
     float acc[BLK];
 #pragma unroll
     for (int j = 0; j < BLK; j++) acc[j] = 0.f;
-    const bool inner = x0 - r >= 0 && x0 + BLK - 1 + r < w;
-    if (N) {
+    const bool live = tid * BLK < outs;
+    if (live) {
+        const float* my = lds + 9 * tid;     // lds_pad(8 * tid + k) = 9 * tid + k + k / 8
+        if (N) {
 #pragma unroll
-        for (int k = 0; k < N + BLK - 1; k++) {
-            const int xs = x0 + k - r;
-            const float v = inner ? row[xs] : row[mis_reflect101(xs, w)];
+            for (int k = 0; k < N + BLK - 1; k++) {
+                // inputs past the span (a partial last block) are never combined with a live output
+                const float v = (tid * BLK + k < span) ? my[k + (k >> 3)] : 0.f;
 #pragma unroll
-            for (int j = 0; j < BLK; j++)
-                if (k - j >= 0 && k - j < N) acc[j] += t.k[k - j] * v;
-        }
-    } else {
-        for (int k = 0; k < n + BLK - 1; k++) {
-            const float v = row[mis_reflect101(x0 + k - r, w)];
+                for (int j = 0; j < BLK; j++)
+                    if (k - j >= 0 && k - j < N) acc[j] += t.k[k - j] * v;
+            }
+        } else {
+            for (int k = 0; k < n + BLK - 1; k++) {
+                const float v = (tid * BLK + k < span) ? my[k + (k >> 3)] : 0.f;
 #pragma unroll
-            for (int j = 0; j < BLK; j++)
-                if (k - j >= 0 && k - j < n) acc[j] += t.k[k - j] * v;
+                for (int j = 0; j < BLK; j++)
+                    if (k - j >= 0 && k - j < n) acc[j] += t.k[k - j] * v;
+            }
         }
     }
+    __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < BLK; j++)
-        if (x0 + j < w) dst[(size_t)y * w + x0 + j] = acc[j];
+        for (int j = 0; j < BLK; j++) lds[9 * tid + j] = acc[j];
+    }
+    __syncthreads();
+    float* orow = dst + (size_t)y * w + xb;
+    for (int i = tid; i < outs; i += 256) orow[i] = lds[lds_pad(i)];
 }
 
 template <int N>
@@ -170,8 +191,67 @@ __global__ __launch_bounds__(256) void sift_decimate_kernel(const float* __restr
 
 #define AT(img, r, c) ((img)[(size_t)(r) * w + (c)])
 
-// findScaleSpaceExtrema, the scan: layer = blockIdx.z + 1
+// findScaleSpaceExtrema, the scan.  "val >= all 26 neighbours" is "val >= the maximum of the 3 x 3 x 3 block" (the block
+// contains val), and that maximum is separable: a thread owns one column and walks EXT_ROWS rows; per DoG layer it
+// keeps the horizontal 3-max / 3-min of the previous two rows, so a new row costs three loads and four max3 / min3 per
+// layer, and the three scale layers share the per-layer 3 x 3 results (15 loads per pixel for all three layers where the
+// direct test needs 81).  Candidates are collected per workgroup in LDS and appended with one global atomic (same-address
+// global atomics serialise at ~11 ns each).  The list order is arbitrary: the keypoints are sorted into a total order later.
+constexpr int EXT_ROWS = 32, EXT_LIST = 1024;
+template <int NL>
 __global__ __launch_bounds__(256) void sift_extrema_kernel(Pyr P, int o, int threshold, int4* __restrict__ cand, unsigned* __restrict__ n_cand, unsigned cap) {
+    constexpr int ND = NL + 2;
+    __shared__ int4 list[EXT_LIST];
+    __shared__ unsigned cnt, base;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int w = P.w[o], h = P.h[o];
+    const int c = blockIdx.x * 256 + threadIdx.x + SIFT_IMG_BORDER, r0 = blockIdx.y * EXT_ROWS + SIFT_IMG_BORDER, r1 = min(r0 + EXT_ROWS, h - SIFT_IMG_BORDER);
+    if (c < w - SIFT_IMG_BORDER) {
+        const float thr = (float)threshold;
+        float amx[ND], amn[ND], bmx[ND], bmn[ND], cen[ND];
+#pragma unroll
+        for (int l = 0; l < ND; l++) amx[l] = amn[l] = bmx[l] = bmn[l] = cen[l] = 0.f;
+        for (int rr = r0 - 1; rr <= r1; rr++) {
+            float nmx[ND], nmn[ND], ncen[ND];
+#pragma unroll
+            for (int l = 0; l < ND; l++) {
+                const float* row = P.dog[o * ND + l] + (size_t)rr * w + c;
+                const float a = row[-1], b = row[0], d = row[1];
+                nmx[l] = fmaxf(fmaxf(a, b), d); nmn[l] = fminf(fminf(a, b), d); ncen[l] = b;
+            }
+            if (rr > r0) {   // rows rr - 2, rr - 1, rr are in a / b / n: evaluate row rr - 1
+                float vmx[ND], vmn[ND];
+#pragma unroll
+                for (int l = 0; l < ND; l++) { vmx[l] = fmaxf(fmaxf(amx[l], bmx[l]), nmx[l]); vmn[l] = fminf(fminf(amn[l], bmn[l]), nmn[l]); }
+#pragma unroll
+                for (int l = 1; l <= NL; l++) {
+                    const float val = cen[l];
+                    if (!(fabsf(val) > thr)) continue;
+                    const bool ext = val > 0 ? val >= fmaxf(fmaxf(vmx[l - 1], vmx[l]), vmx[l + 1]) : val <= fminf(fminf(vmn[l - 1], vmn[l]), vmn[l + 1]);
+                    if (!ext) continue;
+                    const unsigned slot = atomicAdd(&cnt, 1u);
+                    if (slot < EXT_LIST) list[slot] = make_int4(o, l, rr - 1, c);
+                    else {   // a pathological tile: append directly
+                        const unsigned g = atomicAdd(n_cand, 1u);
+                        if (g < cap) cand[g] = make_int4(o, l, rr - 1, c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < ND; l++) { amx[l] = bmx[l]; amn[l] = bmn[l]; bmx[l] = nmx[l]; bmn[l] = nmn[l]; cen[l] = ncen[l]; }
+        }
+    }
+    __syncthreads();
+    const unsigned m = min(cnt, (unsigned)EXT_LIST);
+    if (threadIdx.x == 0 && m) base = atomicAdd(n_cand, m);
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < m; i += 256)
+        if (base + i < cap) cand[base + i] = list[i];
+}
+
+// any other number of octave layers: the direct 26-neighbour test, layer = blockIdx.z + 1, one thread per pixel
+__global__ __launch_bounds__(256) void sift_extrema_generic_kernel(Pyr P, int o, int threshold, int4* __restrict__ cand, unsigned* __restrict__ n_cand, unsigned cap) {
     const int w = P.w[o], h = P.h[o], nl = P.nl;
     const int c = blockIdx.x * 256 + threadIdx.x + SIFT_IMG_BORDER, r = blockIdx.y + SIFT_IMG_BORDER, layer = blockIdx.z + 1;
     if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
@@ -211,12 +291,7 @@ struct SiftConsts {
 };
 
 // adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one thread per candidate
-__global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, const int4* __restrict__ cand, const unsigned* __restrict__ n_cand, unsigned cand_cap,
-                                                        MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
-    const unsigned q = blockIdx.x * 64 + threadIdx.x;
-    const unsigned nc = min(*n_cand, cand_cap);
-    if (q >= nc) return;
-    const int4 cd = cand[q];
+__device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd, MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
     const int octv = cd.x, nl = P.nl, w = P.w[octv], h = P.h[octv];
     int layer = cd.y, r = cd.z, c = cd.w;
     const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
@@ -310,17 +385,25 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, co
     }
 }
 
+// grid-stride over the candidate list, whose length only the device knows at launch time
+__global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, const int4* __restrict__ cand, const unsigned* __restrict__ n_cand, unsigned cand_cap,
+                                                        MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
+    const unsigned nc = min(*n_cand, cand_cap);
+    for (unsigned q = blockIdx.x * 64 + threadIdx.x; q < nc; q += gridDim.x * 64) sift_refine_one(P, K, cand[q], kps, n_kps, kp_cap);
+}
+
 // calcSIFTDescriptor: one wave per keypoint.  The float sums into the (d+2)(d+2)(n+2) histogram are order
 // dependent, so the CPU's order is kept: samples are evaluated 64 at a time in raster order (one per lane: gradient,
 // exp weight, atan2, trilinear split), compacted in that order, and then lanes 0..7 -- one per trilinear corner --
 // walk the compacted samples sequentially.  The 8 corners of one sample are 8 distinct bins, and a wave's LDS
 // operations execute in program order, so every bin receives its contributions in sample order.
 constexpr int HISTLEN = 6 * 6 * 10;
-__global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, int nk, float* __restrict__ desc) {
+__global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, const unsigned* __restrict__ nk, float* __restrict__ desc) {
     __shared__ float hist[HISTLEN];
     __shared__ int s_idx[64];
     __shared__ float s_val[64 * 8];
     const int q = blockIdx.x, lane = threadIdx.x;
+    if ((unsigned)q >= *nk) return;    // the grid covers the raw keypoints; duplicates were removed on the device
     const int d = 4, n = 8, nl = P.nl, firstOctave = -1;
     const MisKeyPoint k = kps[q];
     int octave = k.octave & 255;
@@ -419,14 +502,89 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKey
     }
 }
 
-bool kp_less(const MisKeyPoint& a, const MisKeyPoint& b) {   // KeyPoint_LessThan of KeyPointsFilter::removeDuplicatedSorted
-    if (a.x != b.x) return a.x < b.x;
-    if (a.y != b.y) return a.y < b.y;
-    if (a.size != b.size) return a.size > b.size;
-    if (a.angle != b.angle) return a.angle < b.angle;
-    if (a.response != b.response) return a.response > b.response;
-    if (a.octave != b.octave) return a.octave > b.octave;
-    return false;
+// ---- KeyPointsFilter::removeDuplicatedSorted on the device ----
+// The order of KeyPoint_LessThan (x, y ascending; size descending; angle ascending; response, octave descending) as three
+// 64-bit keys whose unsigned lexicographic order is that order (floats through the usual order-preserving bit map; none
+// of the fields can be -0 or NaN here).  Rank sort: element i goes to position #{j : j before i}; ties (identical
+// keypoints) are broken by the list index.  i is a duplicate when an element with the same (x, y, size, angle) precedes it.
+__device__ __forceinline__ unsigned ford(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+struct KpKey { unsigned long long a, b, c; };
+__device__ __forceinline__ KpKey kp_key(const MisKeyPoint& k) {
+    KpKey q;
+    q.a = ((unsigned long long)ford(k.x) << 32) | ford(k.y);
+    q.b = ((unsigned long long)(~ford(k.size)) << 32) | ford(k.angle);
+    q.c = ((unsigned long long)(~ford(k.response)) << 32) | (~((unsigned)k.octave ^ 0x80000000u));
+    return q;
+}
+constexpr int RANK_SLICES = 8;
+__global__ __launch_bounds__(256) void sift_rank_kernel(const MisKeyPoint* __restrict__ raw, const unsigned* __restrict__ n_raw, unsigned cap, unsigned* __restrict__ rank_out,
+                                                        unsigned* __restrict__ dup_out) {
+    __shared__ unsigned long long sa[256], sb[256], sc[256];
+    const unsigned n = min(*n_raw, cap), i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= n) return;
+    KpKey me{~0ull, ~0ull, ~0ull};
+    if (i < n) me = kp_key(raw[i]);
+    unsigned rank = 0;
+    bool isdup = false;
+    // this workgroup's slice of the list (multiples of 256)
+    const unsigned tiles = (n + 255) / 256, per = (tiles + RANK_SLICES - 1) / RANK_SLICES;
+    const unsigned jb = blockIdx.y * per * 256, je = min(n, (blockIdx.y + 1) * per * 256);
+    for (unsigned base = jb; base < je; base += 256) {
+        const unsigned j = base + threadIdx.x;
+        KpKey kj{~0ull, ~0ull, ~0ull};
+        if (j < n) kj = kp_key(raw[j]);
+        __syncthreads();
+        sa[threadIdx.x] = kj.a; sb[threadIdx.x] = kj.b; sc[threadIdx.x] = kj.c;
+        __syncthreads();
+        const unsigned m = min(256u, n - base);
+        for (unsigned jj = 0; jj < m; jj++) {
+            const unsigned long long a = sa[jj], b = sb[jj], c = sc[jj];
+            const bool same4 = a == me.a && b == me.b;
+            const bool lt = a < me.a || (a == me.a && (b < me.b || (b == me.b && (c < me.c || (c == me.c && base + jj < i)))));
+            rank += lt;
+            isdup |= lt && same4;
+        }
+    }
+    if (i < n) {
+        if (rank) atomicAdd(&rank_out[i], rank);
+        if (isdup) atomicOr(&dup_out[i], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void sift_scatter_kernel(const unsigned* __restrict__ n_raw, unsigned cap, const unsigned* __restrict__ rank, const unsigned* __restrict__ dupi,
+                                                           unsigned* __restrict__ perm, uint8_t* __restrict__ dup) {
+    const unsigned n = min(*n_raw, cap), i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { perm[rank[i]] = i; dup[rank[i]] = (uint8_t)dupi[i]; }
+}
+// stable compaction of the sorted list (one workgroup walks it 1024 at a time) + the firstOctave = -1 rescaling of
+// SIFT::detectAndCompute; writes the final count
+__global__ __launch_bounds__(1024) void sift_compact_kernel(const MisKeyPoint* __restrict__ raw, const unsigned* __restrict__ n_raw, unsigned cap,
+                                                            const unsigned* __restrict__ perm, const uint8_t* __restrict__ dup, int firstOctave,
+                                                            MisKeyPoint* __restrict__ out, unsigned* __restrict__ nk) {
+    __shared__ unsigned wsum[16];
+    const unsigned n = min(*n_raw, cap), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned running = 0;
+    for (unsigned base = 0; base < n; base += 1024) {
+        const unsigned p = base + threadIdx.x;
+        const bool keep = p < n && !dup[p];
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(mask);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (unsigned k = 0; k < 16; k++) { const unsigned v = wsum[k]; total += v; before += k < wave ? v : 0; }
+        if (keep) {
+            MisKeyPoint k = raw[perm[p]];
+            const float scale = 1.f / (float)(1 << -firstOctave);
+            k.octave = (k.octave & ~255) | ((k.octave + firstOctave) & 255);
+            k.x *= scale; k.y *= scale; k.size *= scale;
+            out[running + before + __popcll(mask & ((1ull << lane) - 1))] = k;
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nk = running;
 }
 
 }  // namespace
@@ -443,7 +601,10 @@ struct MisSift {
     float *tmp = nullptr, *grayf = nullptr;
     int4* cand = nullptr;
     MisKeyPoint* raw = nullptr;
-    unsigned* counters = nullptr;   // [0] candidates, [1] raw keypoints
+    unsigned* counters = nullptr;   // [0] candidates, [1] raw keypoints, [2] keypoints after duplicate removal
+    unsigned* perm = nullptr;       // sorted position -> raw index
+    uint8_t* dup = nullptr;         // sorted position -> duplicate of an earlier one
+    unsigned* rank = nullptr;       // raw index -> sorted position, and raw index -> duplicate flag (2 x kp_cap, zeroed per frame)
     unsigned cand_cap = 0, kp_cap = 0;
     double sig[MAX_LAYERS + 4];
 };
@@ -476,6 +637,9 @@ static int sift_plan(MisSift* s, int w, int h) {
     s->cand = (int4*)carve(sizeof(int4) * s->cand_cap);
     s->raw = (MisKeyPoint*)carve(sizeof(MisKeyPoint) * s->kp_cap);
     s->counters = (unsigned*)carve(256);
+    s->perm = (unsigned*)carve(sizeof(unsigned) * s->kp_cap);
+    s->dup = carve(s->kp_cap);
+    s->rank = (unsigned*)carve(2 * sizeof(unsigned) * s->kp_cap);
     s->bytes = off;
     s->cur_w = w; s->cur_h = h;
     return MIS_OK;
@@ -589,52 +753,46 @@ extern "C" int mis_sift_detect(MisSift* s, const MisImage* bgr, MisFeatures* out
     for (int o = 0; o < P.noct; o++) {
         const int iw = P.w[o] - 2 * SIFT_IMG_BORDER, ih = P.h[o] - 2 * SIFT_IMG_BORDER;
         if (iw <= 0 || ih <= 0) continue;
-        hipLaunchKernelGGL(sift_extrema_kernel, dim3((iw + 255) / 256, ih, nl), dim3(256), 0, st, P, o, threshold, s->cand, s->counters, s->cand_cap);
+        if (nl == 3)
+            hipLaunchKernelGGL(sift_extrema_kernel<3>, dim3((iw + 255) / 256, (ih + EXT_ROWS - 1) / EXT_ROWS), dim3(256), 0, st, P, o, threshold, s->cand, s->counters, s->cand_cap);
+        else
+            hipLaunchKernelGGL(sift_extrema_generic_kernel, dim3((iw + 255) / 256, ih, nl), dim3(256), 0, st, P, o, threshold, s->cand, s->counters, s->cand_cap);
     }
-    unsigned counts[2] = {0, 0};
-    MIS_HIP(ctx, hipMemcpyAsync(counts, s->counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    const SiftConsts K{(float)s->p.contrast_threshold, (float)s->p.edge_threshold, (float)s->p.sigma};
+    hipLaunchKernelGGL(sift_refine_kernel, dim3(32 * ctx->num_cu), dim3(64), 0, st, P, K, (const int4*)s->cand, (const unsigned*)s->counters, s->cand_cap, s->raw,
+                       s->counters + 1, s->kp_cap);
+    // the one mid-frame synchronisation: the raw keypoint count sizes the output block and the grids that follow
+    unsigned counts[3] = {0, 0, 0};
+    MIS_HIP(ctx, hipMemcpyAsync(counts, s->counters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipStreamSynchronize(st));
     MIS_CHECK(ctx, counts[0] <= s->cand_cap, MIS_E_INVALID, "SIFT: %u extrema candidates exceed the capacity %u", counts[0], s->cand_cap);
-    const SiftConsts K{(float)s->p.contrast_threshold, (float)s->p.edge_threshold, (float)s->p.sigma};
-    if (counts[0])
-        hipLaunchKernelGGL(sift_refine_kernel, dim3((counts[0] + 63) / 64), dim3(64), 0, st, P, K, (const int4*)s->cand, (const unsigned*)s->counters, s->cand_cap, s->raw,
-                           s->counters + 1, s->kp_cap);
-    MIS_HIP(ctx, hipMemcpyAsync(&counts[1], s->counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    MIS_HIP(ctx, hipStreamSynchronize(st));
     MIS_CHECK(ctx, counts[1] <= s->kp_cap, MIS_E_INVALID, "SIFT: %u keypoints exceed the capacity %u", counts[1], s->kp_cap);
-    // KeyPointsFilter::removeDuplicatedSorted (a total order) + the firstOctave < 0 rescaling -- host, between the phases
-    std::vector<MisKeyPoint> kp(counts[1]);
-    if (counts[1]) {
-        MIS_HIP(ctx, hipMemcpyAsync(kp.data(), s->raw, sizeof(MisKeyPoint) * counts[1], hipMemcpyDeviceToHost, st));
-        MIS_HIP(ctx, hipStreamSynchronize(st));
-    }
-    std::sort(kp.begin(), kp.end(), kp_less);
-    size_t m = 0;
-    for (size_t i = 0; i < kp.size(); i++) {
-        if (m > 0 && kp[m - 1].x == kp[i].x && kp[m - 1].y == kp[i].y && kp[m - 1].size == kp[i].size && kp[m - 1].angle == kp[i].angle) continue;
-        kp[m++] = kp[i];
-    }
-    kp.resize(m);
-    for (MisKeyPoint& k : kp) {
-        const float scale = 1.f / (float)(1 << -firstOctave);
-        k.octave = (k.octave & ~255) | ((k.octave + firstOctave) & 255);
-        k.x *= scale; k.y *= scale; k.size *= scale;
-    }
-    // output block: keypoints + descriptors
-    const int nk = (int)kp.size();
+    // output block: keypoints + descriptors, sized for the raw count (duplicates only shrink it)
+    const int nraw = (int)counts[1];
     memset(out, 0, sizeof(*out));
-    out->img_w = bgr->width; out->img_h = bgr->height; out->n = nk; out->desc_cols = 128; out->desc_dtype = MIS_F32;
-    const size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)std::max(nk, 1), 256), db = sizeof(float) * 128 * (size_t)std::max(nk, 1);
+    out->img_w = bgr->width; out->img_h = bgr->height; out->desc_cols = 128; out->desc_dtype = MIS_F32;
+    const size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)std::max(nraw, 1), 256), db = sizeof(float) * 128 * (size_t)std::max(nraw, 1);
     uint8_t* blk = nullptr;
     MIS_HIP(ctx, hipMalloc((void**)&blk, kb + db));
     out->owner_ = blk; out->keypoints = (MisKeyPoint*)blk; out->descriptors = blk + kb;
-    if (nk) {
-        MIS_HIP(ctx, hipMemcpyAsync(out->keypoints, kp.data(), sizeof(MisKeyPoint) * (size_t)nk, hipMemcpyHostToDevice, st));
-        MIS_HIP(ctx, hipStreamSynchronize(st));   // kp is a local vector
-        hipLaunchKernelGGL(sift_descriptor_kernel, dim3(nk), dim3(64), 0, st, P, (const MisKeyPoint*)out->keypoints, nk,
+    if (nraw) {
+        // KeyPointsFilter::removeDuplicatedSorted (a total order, so the atomics' append order never shows) + the
+        // firstOctave < 0 rescaling, then the descriptors of the survivors
+        MIS_HIP(ctx, hipMemsetAsync(s->rank, 0, 2 * sizeof(unsigned) * (size_t)nraw, st));
+        unsigned* dupi = s->rank + nraw;
+        hipLaunchKernelGGL(sift_rank_kernel, dim3((nraw + 255) / 256, RANK_SLICES), dim3(256), 0, st, (const MisKeyPoint*)s->raw, (const unsigned*)(s->counters + 1), s->kp_cap,
+                           s->rank, dupi);
+        hipLaunchKernelGGL(sift_scatter_kernel, dim3((nraw + 255) / 256), dim3(256), 0, st, (const unsigned*)(s->counters + 1), s->kp_cap, (const unsigned*)s->rank,
+                           (const unsigned*)dupi, s->perm, s->dup);
+        hipLaunchKernelGGL(sift_compact_kernel, dim3(1), dim3(1024), 0, st, (const MisKeyPoint*)s->raw, (const unsigned*)(s->counters + 1), s->kp_cap, (const unsigned*)s->perm,
+                           (const uint8_t*)s->dup, firstOctave, out->keypoints, s->counters + 2);
+        hipLaunchKernelGGL(sift_descriptor_kernel, dim3(nraw), dim3(64), 0, st, P, (const MisKeyPoint*)out->keypoints, (const unsigned*)(s->counters + 2),
                            (float*)out->descriptors);
         MIS_HIP(ctx, hipGetLastError());
+        MIS_HIP(ctx, hipMemcpyAsync(&counts[2], s->counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        MIS_HIP(ctx, hipStreamSynchronize(st));
     }
+    out->n = (int)counts[2];
     return mis_dev_image_release(ctx, &din);
 }
 
