@@ -104,111 +104,168 @@ __device__ __forceinline__ void top2_insert(float d, int i, float& d0, int& i0, 
 typedef int int16v __attribute__((ext_vector_type(16)));
 constexpr int L2_MAX_SLICES = 16;
 
-// A workgroup of 4 waves owns 128 queries (32 per wave, A fragments in registers) and walks the train set in
+// A workgroup of 4 waves owns 256 queries (two sets of 32 per wave, their fragments in registers) and walks the train set in
 // tiles of 32 descriptors that are staged ONCE per workgroup in LDS (double buffered, rows padded to 272 bytes so
-// the 16-byte fragment reads of the 32 lanes fall into different banks).  Per tile a wave issues 8 MFMAs
-// (32 x 32 x 128) and keeps, per accumulator register, the best two trains its lane (= column class) has seen.
-// The insertion is filtered: thr[g] = the smallest second-best of the 32 lanes that share the row, refreshed every
-// 8 tiles, is an upper bound of the row's final second-best distance, and it only contains trains of earlier tiles
-// (smaller indices), so a candidate with d >= thr[g] can never enter the row's top two -- also not through the
-// (distance, index) tie rule.  Candidates below the bound take the exact insertion.
-// The query norm is the same for every candidate of a row, so the ordering is decided on e = |t|^2 - 2 q.t (an
-// exact integer, possibly negative); |q|^2 is added at the end.  Train indices are kept as tile numbers (index =
-// 32 tile + lane column), two per register.  The train set is split into `gridDim.y` slices so that small query
-// sets still fill the device; slice results go to part_* and a second kernel merges them by (distance, index).
-constexpr int L2_TB = 32, L2_PITCH = 272;
-__global__ __launch_bounds__(256, 2) void l2_knn2_mfma_kernel(L2Set Q, L2Set T, int tiles_per_slice, int* part_idx, float* part_e) {
-    __shared__ __attribute__((aligned(16))) uint8_t sb[2][L2_TB * L2_PITCH];
+// the 16-byte fragment reads of the 32 lanes fall into different banks).  Per tile and query set a wave issues 8 MFMAs
+// (32 x 32 x 128) with the TRAIN tile as the A operand and the queries as B: the accumulator of lane (r, hh) then
+// holds, for query r of the wave, the dot products with the 16 trains (g & 3) + 8 (g >> 2) + 4 hh of the tile --
+// the search dimension lies along the lane's registers, so the running top two of a query are four registers of
+// one lane (two lanes per query, merged at the end), the filter "below my current second best" needs no cross-lane
+// traffic, and after the first tiles a tile costs the MFMAs plus ~25 vector instructions (16 fused e = |t|^2 - 2 q.t,
+// a min3 tree, one compare).  An earlier version kept queries along the registers and one top-two per (register,
+// column class): its shared bound was so loose that the insertion ran on nearly every tile (0.72 ms per 24 k x 24 k).
+// The query norm is the same for every candidate of a query, so the ordering is decided on e (an exact integer,
+// possibly negative); |q|^2 is added at the end.  Within a lane the train index only grows, so strict comparisons
+// keep the earlier train on ties, as the CPU's (distance, index) order does.  The train set is split into
+// `gridDim.y` slices so that small query sets still fill the device; slice results go to part_* and a second kernel
+// merges them by (distance, index).
+struct Top2 { float e0, e1; int i0, i1; };
+// one tile's 16 candidates of a lane (e = |t|^2 - 2 q.t from the accumulator) against the lane's running top two
+__device__ __forceinline__ void l2_tile_update(const float16v& acc, const float (&tn)[16], int ib, Top2& t) {
+    float e[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) e[g] = __builtin_fmaf(-2.f, acc[g], tn[g]);   // exact integers below 2^24 (fused or not), ~3e38 for a padded row
+    float m4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) m4[j] = fminf(fminf(e[4 * j], e[4 * j + 1]), fminf(e[4 * j + 2], e[4 * j + 3]));
+    const float m = fminf(fminf(m4[0], m4[1]), fminf(m4[2], m4[3]));
+    if (!__any(m < t.e1)) return;
+    // some lane improves its top two: visit only the groups of four trains that hold such a candidate
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!__any(m4[j] < t.e1)) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float v = e[4 * j + k];
+            const int idx = ib + 8 * j + k;   // ascending in (j, k): ties keep the earlier entry
+            const bool b0 = v < t.e0, b1 = v < t.e1;
+            t.i1 = b0 ? t.i0 : (b1 ? idx : t.i1);
+            t.e1 = b0 ? t.e0 : (b1 ? v : t.e1);
+            t.i0 = b0 ? idx : t.i0;
+            t.e0 = b0 ? v : t.e0;
+        }
+    }
+}
+#ifndef K8_WG_PER_CU
+#define K8_WG_PER_CU 2
+#endif
+#ifndef K8_SUB
+#define K8_SUB 1
+#endif
+constexpr int L2_TB = 32, L2_PITCH = 272, L2_QW = 2, L2_SUB = K8_SUB;   // L2_QW sets of 32 queries per wave, L2_SUB tiles per barrier step
+__global__ __launch_bounds__(256, 2) void l2_knn2_mfma_kernel(L2Set Q, L2Set T, int tiles_per_slice, int slices, int qblocks, int* part_idx, float* part_e) {
+    // two tiles (64 trains) per barrier: half the synchronisations, twice the work to hide the next fetch behind
+    __shared__ __attribute__((aligned(16))) uint8_t sb[2][L2_SUB][L2_TB * L2_PITCH];
+    __shared__ __attribute__((aligned(16))) float sn[2][L2_SUB][L2_TB];   // squared norms of the staged trains (3e38 for padded rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32;   // this wave's 32 queries
-    // A fragments: lane holds A[row r][k = 16 s + 8 hh + j] for the 8 k-steps
-    half8 a[8];
-    const int qa = min(q0 + r, Q.n - 1);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const half8*>(Q.h + (size_t)qa * 128 + 16 * s8 + 8 * hh);
-    float16v e0, e1, thr;
-    int16v it;   // tile of the best | tile of the second best << 16 (0xffff = none)
-#pragma unroll
-    for (int g = 0; g < 16; g++) { e0[g] = 3.0e38f; e1[g] = 3.0e38f; thr[g] = 3.0e38f; it[g] = -1; }
-    // staging role of a thread: 16-byte chunk (t & 15) of train rows (t >> 4) and (t >> 4) + 16 of the tile
-    const int srow = threadIdx.x >> 4, schunk = threadIdx.x & 15;
-    const int ntiles_all = (T.n + L2_TB - 1) / L2_TB;
-    const int tile_lo = blockIdx.y * tiles_per_slice, tile_hi = min(ntiles_all, tile_lo + tiles_per_slice);
-    uint4 st0, st1;
-    auto fetch = [&](int tile) {
-        const int ta = tile * L2_TB + srow, tb = ta + 16;
-        st0 = ta < T.n ? *reinterpret_cast<const uint4*>(T.h + (size_t)ta * 128 + 8 * schunk) : make_uint4(0, 0, 0, 0);
-        st1 = tb < T.n ? *reinterpret_cast<const uint4*>(T.h + (size_t)tb * 128 + 8 * schunk) : make_uint4(0, 0, 0, 0);
-    };
-    auto stash = [&](int buf) {
-        *reinterpret_cast<uint4*>(sb[buf] + srow * L2_PITCH + 16 * schunk) = st0;
-        *reinterpret_cast<uint4*>(sb[buf] + (srow + 16) * L2_PITCH + 16 * schunk) = st1;
-    };
-    if (tile_lo < tile_hi) {
-        fetch(tile_lo);
-        stash(0);
-    }
-    __syncthreads();
-    for (int tile = tile_lo; tile < tile_hi; tile++) {
-        const int buf = (tile - tile_lo) & 1;
-        if (tile + 1 < tile_hi) fetch(tile + 1);      // in flight during the MFMAs of this tile
-        const int tc = tile * L2_TB + r;              // this lane's train column
-        const float tn = tc < T.n ? T.nrm[tc] : 3.0e38f;
-        float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const uint8_t* brow = sb[buf] + r * L2_PITCH + 16 * hh;
+    // XCD-aware order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  All workgroups of an XCD walk the
+    // same slice(s) of the train set (slices is a power of two), so a slice is fetched into one L2 once and then
+    // served from it; with slices spread over all XCDs every L2 had to hold the whole train set (6 MB at 24 k) and
+    // the tile prefetch, not the MFMAs, set the kernel's time.
+    const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+    int slice, qb;
+    if (slices >= 8) { const int s8 = slices >> 3; slice = xcd * s8 + grp % s8; qb = grp / s8; }
+    else { slice = xcd % slices; qb = grp * (8 / slices) + xcd / slices; }
+    if (qb >= qblocks) return;
+    const int q0 = (qb * 4 + wave) * (32 * L2_QW);   // this wave's queries: q0 + 32 u + r
+    // query fragments: lane holds Q[query][k = 16 s + 8 hh + j] for the 8 k-steps; every train fragment read from
+    // LDS feeds L2_QW independent MFMA chains
+    static_assert(L2_QW == 2, "two query sets per wave are spelled out below");
+    half8 a0[8], a1[8];
+    {
+        const int qa = min(q0 + r, Q.n - 1), qb = min(q0 + 32 + r, Q.n - 1);
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) {
-            const half8 b = *reinterpret_cast<const half8*>(brow + 32 * s8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s8], b, acc, 0, 0, 0);
+            a0[s8] = *reinterpret_cast<const half8*>(Q.h + (size_t)qa * 128 + 16 * s8 + 8 * hh);
+            a1[s8] = *reinterpret_cast<const half8*>(Q.h + (size_t)qb * 128 + 16 * s8 + 8 * hh);
         }
-        bool hit = false;
+    }
+    Top2 ta{3.0e38f, 3.0e38f, 0x7fffffff, 0x7fffffff}, tb = ta;
+    // staging role of a thread: 16-byte chunk (t & 15) of train rows (t >> 4) and (t >> 4) + 16 of both tiles of a step
+    const int srow = threadIdx.x >> 4, schunk = threadIdx.x & 15;
+    const int ntiles_all = (T.n + L2_TB - 1) / L2_TB;
+    // slices are whole steps (tiles_per_slice is even), so only the last step of the train set can hold a tile past
+    // the end; its rows read as zeros with norm 3e38 and never enter a top two
+    const int tile_lo = slice * tiles_per_slice, tile_hi = min(ntiles_all, tile_lo + tiles_per_slice);
+    // The norms travel with the tiles (threads 0 .. 32 L2_SUB - 1 carry one each), so the loop's only global loads are
+    // this prefetch: waiting for anything else in the loop would also wait for it (vmcnt counts in order).
+    uint4 st[2 * L2_SUB];
+    float stn = 3.0e38f;
+    auto fetch = [&](int tile) {
 #pragma unroll
-        for (int g = 0; g < 16; g++) hit |= (tn - 2.f * acc[g]) < thr[g];   // exact integers below 2^24 (or ~3e38 for a padded column)
-        if (__any(hit)) {
+        for (int k = 0; k < 2 * L2_SUB; k++) {
+            const int t = tile * L2_TB + srow + 16 * k;
+            st[k] = t < T.n ? *reinterpret_cast<const uint4*>(T.h + (size_t)t * 128 + 8 * schunk) : make_uint4(0, 0, 0, 0);
+        }
+        const int tnrm = tile * L2_TB + (int)threadIdx.x;
+        stn = (threadIdx.x < L2_SUB * L2_TB && tnrm < T.n) ? T.nrm[tnrm] : 3.0e38f;
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const float e = tn - 2.f * acc[g];
-                if (e < thr[g]) {
-                    // within a lane the train index only grows: ties keep the earlier entry
-                    if (e < e0[g]) { e1[g] = e0[g]; e0[g] = e; it[g] = (it[g] << 16) | tile; }
-                    else if (e < e1[g]) { e1[g] = e; it[g] = (it[g] & 0xffff) | (tile << 16); }
+        for (int k = 0; k < 2 * L2_SUB; k++)
+            *reinterpret_cast<uint4*>(sb[buf][k >> 1] + (srow + 16 * (k & 1)) * L2_PITCH + 16 * schunk) = st[k];
+        if (threadIdx.x < L2_SUB * L2_TB) sn[buf][threadIdx.x >> 5][threadIdx.x & 31] = stn;
+    };
+    // This first, unconditional wait for all loads also covers the query fragments: were it conditional, the compiler
+    // would guard every MFMA of the loop with a vmcnt wait for its fragment, and such a wait also waits for the
+    // prefetch issued before it.  A slice past the end of a short train set reports "nothing found".
+    if (tile_lo >= tile_hi) {
+        if (hh == 0)
+            for (int u = 0; u < L2_QW; u++) {
+                const int q = q0 + 32 * u + r;
+                if (q < Q.n) {
+                    const size_t o = ((size_t)slice * Q.n + q) * 2;
+                    part_idx[o] = part_idx[o + 1] = 0x7fffffff;
+                    part_e[o] = part_e[o + 1] = 3.0e38f;
                 }
             }
-        }
-        if (((tile - tile_lo) & 7) == 7) {
-            // refresh the bound: the smallest second-best among the 32 lanes of the row (lanes with equal hh)
+        return;
+    }
+    fetch(tile_lo);
+    stash(0);
+    __syncthreads();
+    for (int tile = tile_lo, step = 0; tile < tile_hi; tile += L2_SUB, step++) {
+        const int buf = step & 1;
+        if (tile + L2_SUB < tile_hi) fetch(tile + L2_SUB);      // in flight during the MFMAs of this step
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                float m = e1[g];
+        for (int sub = 0; sub < L2_SUB; sub++) {
+            // squared norms of this lane's 16 trains: rows 8 j + 4 hh + (0..3), j = 0..3
+            float tn[16];
+            const int tbase = (tile + sub) * L2_TB + 4 * hh;
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-                thr[g] = m;
+            for (int j = 0; j < 4; j++) {
+                const float4 v = *reinterpret_cast<const float4*>(&sn[buf][sub][4 * hh + 8 * j]);
+                tn[4 * j] = v.x; tn[4 * j + 1] = v.y; tn[4 * j + 2] = v.z; tn[4 * j + 3] = v.w;
             }
+            float16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+            const uint8_t* brow = sb[buf][sub] + r * L2_PITCH + 16 * hh;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) {
+                const half8 b = *reinterpret_cast<const half8*>(brow + 32 * s8);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a0[s8], acc0, 0, 0, 0);   // rows: trains, columns: queries
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a1[s8], acc1, 0, 0, 0);
+            }
+            l2_tile_update(acc0, tn, tbase, ta);
+            l2_tile_update(acc1, tn, tbase, tb);
         }
-        if (tile + 1 < tile_hi) stash(buf ^ 1);
+        if (tile + L2_SUB < tile_hi) stash(buf ^ 1);
         __syncthreads();
     }
-    // merge across the 32 lanes (columns) that share a row; lane r == 0 of each half writes its 16 rows
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        float a0 = e0[g], a1 = e1[g];
-        const int t0 = it[g] & 0xffff, t1 = (it[g] >> 16) & 0xffff;
-        int b0 = a0 < 1.0e38f ? t0 * L2_TB + r : 0x7fffffff, b1 = a1 < 1.0e38f ? t1 * L2_TB + r : 0x7fffffff;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            const float od0 = __shfl_xor(a0, o), od1 = __shfl_xor(a1, o);
-            const int oi0 = __shfl_xor(b0, o), oi1 = __shfl_xor(b1, o);
-            top2_insert(od0, oi0, a0, b0, a1, b1);
-            top2_insert(od1, oi1, a0, b0, a1, b1);
+    // merge the two lanes of a query (hh = 0 / 1) by (e, index); lanes with hh == 0 write
+    auto finish = [&](Top2 t, int q) {
+        const float od0 = __shfl_xor(t.e0, 32), od1 = __shfl_xor(t.e1, 32);
+        const int oi0 = __shfl_xor(t.i0, 32), oi1 = __shfl_xor(t.i1, 32);
+        top2_insert(od0, oi0, t.e0, t.i0, t.e1, t.i1);
+        top2_insert(od1, oi1, t.e0, t.i0, t.e1, t.i1);
+        if (hh == 0 && q < Q.n) {
+            const size_t o = ((size_t)slice * Q.n + q) * 2;
+            part_idx[o] = t.i0; part_idx[o + 1] = t.i1;
+            part_e[o] = t.e0; part_e[o + 1] = t.e1;
         }
-        const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, q = q0 + row;
-        if (r == 0 && q < Q.n) {
-            const size_t o = ((size_t)blockIdx.y * Q.n + q) * 2;
-            part_idx[o] = b0; part_idx[o + 1] = b1;
-            part_e[o] = a0; part_e[o + 1] = a1;
-        }
-    }
+    };
+    finish(ta, q0 + r);
+    finish(tb, q0 + 32 + r);
 }
 
 // merge of the train slices of one query set: top two by (e, index), then distance = sqrt(|q|^2 + e)
@@ -231,14 +288,16 @@ __global__ __launch_bounds__(256) void l2_merge_kernel(L2Set Q, int slices, cons
 
 // launches the sliced distance pass + merge for one directed pair; `part` holds 2 * slices * Q.n (int + float)
 static void l2_knn2_launch(hipStream_t st, int num_cu, const L2Set& Q, const L2Set& T, void* part, int* idx2, float* dist2) {
-    const int qblocks = (Q.n + 127) / 128, ntiles = (T.n + L2_TB - 1) / L2_TB;
-    int slices = std::max(1, std::min({(4 * num_cu + qblocks - 1) / qblocks, ntiles / 16, L2_MAX_SLICES}));   // >= 16 tiles per slice
-    if (slices < 1) slices = 1;
-    const int tiles_per_slice = (ntiles + slices - 1) / slices;
-    slices = (ntiles + tiles_per_slice - 1) / tiles_per_slice;
+    const int qblocks = (Q.n + 128 * L2_QW - 1) / (128 * L2_QW), ntiles = (T.n + L2_TB - 1) / L2_TB;
+    // every slice restarts the search bound, so as few slices as fill the device (K8_WG_PER_CU workgroups per CU), at
+    // least 16 tiles each; a power of two (<= 16) for the XCD mapping of the kernel
+    int slices = 1;
+    while (slices < L2_MAX_SLICES && qblocks * slices < K8_WG_PER_CU * num_cu && ntiles / (2 * slices) >= 16) slices *= 2;
+    const int tiles_per_slice = ((ntiles + slices - 1) / slices + L2_SUB - 1) / L2_SUB * L2_SUB;   // whole steps
+    const int nwg = slices >= 8 ? qblocks * slices : (qblocks + 8 / slices - 1) / (8 / slices) * 8;
     int* pi = (int*)part;
     float* pe = (float*)(pi + (size_t)2 * L2_MAX_SLICES * Q.n);
-    hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3(qblocks, slices), dim3(256), 0, st, Q, T, tiles_per_slice, pi, pe);
+    hipLaunchKernelGGL(l2_knn2_mfma_kernel, dim3(nwg), dim3(256), 0, st, Q, T, tiles_per_slice, slices, qblocks, pi, pe);
     hipLaunchKernelGGL(l2_merge_kernel, dim3((Q.n + 255) / 256), dim3(256), 0, st, Q, slices, (const int*)pi, (const float*)pe, idx2, dist2);
 }
 

@@ -1,12 +1,14 @@
-"""Per-step wall time of the config-3 job (diagnostics): python tools/step_times.py [steps]"""
+"""Per-step wall time of a job (diagnostics): python tools/step_times.py [steps] [config3|config5]"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_stitching_amd as isa, synth
 from image_stitching_amd.distributed import StitchJob
 ctx = isa.Context(0)
-cams = synth.workload("config3")
+wl = sys.argv[2] if len(sys.argv) > 2 else "config3"
+cams = synth.workload(wl)
 frames = {i: synth.render_frame_gpu(c) for i, c in enumerate(cams)}
-job = StitchJob(ctx, (3840, 2160), cams)
+size = (cams[0]["width"], cams[0]["height"]) if "width" in cams[0] else ((7680, 4320) if wl == "config5" else (3840, 2160))
+job = StitchJob(ctx, size, cams, config=isa.StitchConfig(features_type="sift" if wl == "config5" else "orb"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 ts = []
 for k in range(n):
