@@ -105,6 +105,7 @@ PROTOTYPES = {
     "mis_sift_create": (_i, [_vp, _P(MisSiftParams), _i, _i, _P(_vp)]),
     "mis_sift_destroy": (_i, [_vp]),
     "mis_sift_detect": (_i, [_vp, _P(MisImage), _P(MisFeatures)]),
+    "mis_sift_detect_batch": (_i, [_vp, _P(MisImage), _i, _P(MisFeatures)]),
     "mis_sift_debug_level": (_i, [_vp, _P(MisImage), _i, _i, _i, _vp, _P(_i), _P(_i)]),
     "mis_match_default_params": (None, [_P(MisMatchParams)]),
     "mis_match_all_pairs": (_i, [_vp, _P(MisFeatures), _i, _P(MisMatchParams), _P(MisMatchesInfo)]),

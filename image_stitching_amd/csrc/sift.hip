@@ -15,6 +15,7 @@
 #include "dev_math.h"
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -607,6 +608,10 @@ struct MisSift {
     unsigned* rank = nullptr;       // raw index -> sorted position, and raw index -> duplicate flag (2 x kp_cap, zeroed per frame)
     unsigned cand_cap = 0, kp_cap = 0;
     double sig[MAX_LAYERS + 4];
+    // second lane of mis_sift_detect_batch: a finder of its own on its own context / stream, driven by a host thread
+    MisSift* helper = nullptr;
+    MisContext* helper_ctx = nullptr;
+    void* helper_stream = nullptr;
 };
 
 static int sift_plan(MisSift* s, int w, int h) {
@@ -680,6 +685,9 @@ extern "C" int mis_sift_create(MisContext* ctx, const MisSiftParams* params, int
 
 extern "C" int mis_sift_destroy(MisSift* s) {
     if (!s) return MIS_OK;
+    if (s->helper) { mis_sift_destroy(s->helper); s->helper = nullptr; }
+    if (s->helper_ctx) { mis_context_destroy(s->helper_ctx); s->helper_ctx = nullptr; }
+    if (s->helper_stream) { mis_stream_destroy(s->helper_stream); s->helper_stream = nullptr; }
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     if (s->mem) hipFree(s->mem);
@@ -815,4 +823,38 @@ extern "C" int mis_sift_debug_level(MisSift* s, const MisImage* bgr, int octave,
         MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return mis_dev_image_release(ctx, &din);
+}
+
+// Several frames: two lanes (this finder and a helper with its own scale space, context and stream), one host thread
+// each, frame i on lane i % 2.  A frame's kernels are partly bandwidth bound (the blurs) and partly latency bound (one
+// thread or wave per keypoint, two host synchronisations), so two frames in flight keep the device busier than one.
+extern "C" int mis_sift_detect_batch(MisSift* s, const MisImage* imgs, int n, MisFeatures* out) {
+    if (!s) return MIS_E_INVALID;
+    MisContext* ctx = s->ctx;
+    MIS_CHECK(ctx, imgs && out && n >= 1, MIS_E_INVALID, "null argument");
+    if (n == 1) return mis_sift_detect(s, imgs, out);
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!s->helper) {
+        int rc = mis_stream_create(ctx->device, 0, &s->helper_stream);
+        if (rc == MIS_OK) rc = mis_context_create(ctx->device, s->helper_stream, &s->helper_ctx);
+        if (rc == MIS_OK) rc = mis_sift_create(s->helper_ctx, &s->p, s->max_w, s->max_h, &s->helper);
+        if (rc != MIS_OK) return mis_set_error(ctx, rc, "SIFT batch: cannot create the second lane (%s)", s->helper_ctx ? s->helper_ctx->err.c_str() : "stream / context");
+    }
+    // the frames' producers were enqueued on the context's stream; the helper's stream does not see them otherwise
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MisSift* lanes[2] = {s, s->helper};
+    int rcs[2] = {MIS_OK, MIS_OK};
+    auto work = [&](int lane) {
+        for (int i = lane; i < n; i += 2) {
+            const int rc = mis_sift_detect(lanes[lane], &imgs[i], &out[i]);
+            if (rc != MIS_OK) { rcs[lane] = rc; return; }
+            out[i].img_idx = i;
+        }
+    };
+    std::thread t1(work, 1);
+    work(0);
+    t1.join();
+    if (rcs[0] != MIS_OK) return rcs[0];
+    if (rcs[1] != MIS_OK) return mis_set_error(ctx, rcs[1], "SIFT batch, second lane: %s", s->helper_ctx->err.c_str());
+    return MIS_OK;
 }

@@ -532,11 +532,17 @@ class SiftFeatureFinder:
         return ImageFeatures(self.ctx, raw)
 
     def detect_batch(self, imgs):
+        n = len(imgs)
+        if n == 0:
+            return []
+        arr = (capi.MisImage * n)(*[as_image(im) for im in imgs])
+        raws = (capi.MisFeatures * n)()
+        self.ctx.check(self.ctx.lib.mis_sift_detect_batch(self.h, arr, n, raws))
         out = []
-        for k, im in enumerate(imgs):
-            f = self.detect(im)
-            f.img_idx = k
-            out.append(f)
+        for k in range(n):
+            raw = capi.MisFeatures()
+            C.memmove(C.byref(raw), C.byref(raws[k]), C.sizeof(capi.MisFeatures))
+            out.append(ImageFeatures(self.ctx, raw))
         return out
 
     def debug_level(self, img, octave, layer, dog=False):

@@ -204,6 +204,8 @@ int mis_sift_destroy(MisSift* sift);
 /* computeImageFeatures(finder, img, features) -- replaces image_stitching.cpp:613 for the SIFT finder: keypoints in the
  * order of KeyPointsFilter::removeDuplicatedSorted, descriptors n x 128 f32 with integer values 0..255 (feeds K8). */
 int mis_sift_detect(MisSift* sift, const MisImage* bgr, MisFeatures* out);
+/* n frames of one size, two in flight (second scale space allocated on first use); out[i].img_idx = i as at :614 */
+int mis_sift_detect_batch(MisSift* sift, const MisImage* bgr, int n_images, MisFeatures* out);
 /* test aid: one image of the Gaussian (dog = 0) or DoG (dog = 1) pyramid of `bgr`, copied to host_out (may be NULL) */
 int mis_sift_debug_level(MisSift* sift, const MisImage* bgr, int octave, int layer, int dog, float* host_out, int* width, int* height);
 

@@ -89,3 +89,22 @@ def test_sift_features_feed_the_l2_matcher(ctx, oracle_mod):
     m = pm[1]
     assert m.num_inliers == ref["num_inliers"] and m.num_inliers >= 10
     assert np.array_equal(np.asarray(m.H, np.float64).view(np.uint64).reshape(-1), np.asarray(ref["H"], np.float64).view(np.uint64).reshape(-1))
+
+
+def test_batch_of_frames_equals_single_calls(ctx):
+    """mis_sift_detect_batch keeps two frames in flight (second lane: own scale space, stream and host thread);
+    results and their order must be those of one call per frame.  Device and host inputs."""
+    import torch
+    import image_stitching_amd as isa
+    w, h = 480, 270
+    frames = [_frame(w, h, yaw, 1.0) for yaw in (0.0, 20.0, 40.0, 60.0, 80.0)]
+    f = isa.SiftFeatureFinder(ctx, (w, h))
+    singles = [f.detect(torch.from_numpy(fr).cuda()).download() for fr in frames]
+    for inputs in ([torch.from_numpy(fr).cuda() for fr in frames], frames):
+        batch = f.detect_batch(inputs)
+        assert [b.img_idx for b in batch] == list(range(len(frames)))
+        for (ks, ds), b in zip(singles, batch):
+            kb, db = b.download()
+            assert len(kb) == len(ks) and len(ks) > 100
+            assert kb.tobytes() == ks.tobytes() and np.array_equal(db, ds)
+    assert f.detect_batch([]) == []
