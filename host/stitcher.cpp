@@ -77,14 +77,28 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
 
     // ---- features (image_stitching.cpp:545, :567-622; work_megapix = -1: full resolution) ----
     double t = now();
-    MisOrbParams op;
-    mis_orb_default_params(&op);
+    if (cfg_.features_type != "orb" && cfg_.features_type != "sift") throw std::runtime_error("Unknown 2D features type: '" + cfg_.features_type + "'.");
+    if (cfg_.ba_cost_func != "no" && cfg_.ba_cost_func != "reproj")
+        throw std::runtime_error("bundle adjustment cost function '" + cfg_.ba_cost_func + "' is not implemented (only 'no' and 'reproj')");
+    if (cfg_.expos_comp_type != "no" && cfg_.expos_comp_type != "gain_blocks")
+        throw std::runtime_error("exposure compensation '" + cfg_.expos_comp_type + "' is not implemented (only 'no' and 'gain_blocks')");
+    if (cfg_.seam_find_type != "no" && cfg_.seam_find_type != "voronoi")
+        throw std::runtime_error("seam finder '" + cfg_.seam_find_type + "' is not implemented (only 'no' and 'voronoi'; DpSeamFinder is outside this library)");
     MisOrb* orb = nullptr;
-    check(mis_orb_create(ctx_, &op, W, H, &orb), "mis_orb_create");
+    MisSift* sift = nullptr;
     std::vector<MisFeatures> features(n);
+    std::vector<MisImage> views(n);
+    for (int i = 0; i < n; i++) views[i] = view(frames[i]);
+    if (cfg_.features_type == "sift") {
+        check(mis_sift_create(ctx_, nullptr, W, H, &sift), "mis_sift_create");
+        check(mis_sift_detect_batch(sift, views.data(), n, features.data()), "mis_sift_detect_batch");
+    } else {
+        MisOrbParams op;
+        mis_orb_default_params(&op);
+        check(mis_orb_create(ctx_, &op, W, H, &orb), "mis_orb_create");
+        check(mis_orb_detect_batch(orb, views.data(), n, features.data()), "mis_orb_detect_batch");
+    }
     for (int i = 0; i < n; i++) {
-        MisImage v = view(frames[i]);
-        check(mis_orb_detect(orb, &v, &features[i]), "mis_orb_detect");
         features[i].img_idx = i;
         std::cout << "Features in image #" << i + 1 << ": " << features[i].n << std::endl;
         out.num_features.push_back(features[i].n);
@@ -103,12 +117,46 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
     int kept = 0;
     mis_leave_biggest_component(pairwise.data(), n, cfg_.conf_thresh, out.indices.data(), &kept);
     out.indices.resize(kept);
+    // ---- camera refinement on the kept subset (:671-726): bundle adjustment (reprojection cost), wave correction ----
+    if (kept >= 2 && cfg_.ba_cost_func == "reproj") {
+        std::vector<MisFeatures> fsub(kept);
+        std::vector<MisMatchesInfo> psub((size_t)kept * kept);
+        std::vector<MisCameraParams> cp(kept);
+        for (int a = 0; a < kept; a++) {
+            fsub[a] = features[out.indices[a]];
+            fsub[a].img_idx = a;
+            for (int b = 0; b < kept; b++) {
+                psub[(size_t)a * kept + b] = pairwise[(size_t)out.indices[a] * n + out.indices[b]];   // borrowed arrays
+                psub[(size_t)a * kept + b].src_img_idx = a; psub[(size_t)a * kept + b].dst_img_idx = b;
+            }
+            const CameraParams& c = cameras[out.indices[a]];
+            cp[a].focal = c.focal; cp[a].aspect = c.aspect; cp[a].ppx = c.ppx; cp[a].ppy = c.ppy;
+            std::copy(c.R.m.begin(), c.R.m.end(), cp[a].R);
+            std::copy(c.t.begin(), c.t.end(), cp[a].t);
+        }
+        if (mis_bundle_adjust_reproj(ctx_, fsub.data(), psub.data(), kept, cfg_.conf_thresh, cfg_.ba_refine_mask.c_str(), cp.data()) != MIS_OK)
+            throw std::runtime_error(std::string("Camera parameters adjusting failed: ") + mis_last_error(ctx_));
+        if (cfg_.wave_correct != "no") {
+            std::vector<double> rm((size_t)kept * 9);
+            for (int a = 0; a < kept; a++) std::copy(cp[a].R, cp[a].R + 9, rm.begin() + 9 * a);
+            check(mis_wave_correct(rm.data(), kept, cfg_.wave_correct == "vert" ? 1 : 0), "mis_wave_correct");
+            for (int a = 0; a < kept; a++) std::copy(rm.begin() + 9 * a, rm.begin() + 9 * a + 9, cp[a].R);
+        }
+        for (int a = 0; a < kept; a++) {
+            CameraParams& c = cameras[out.indices[a]];
+            c.focal = cp[a].focal; c.aspect = cp[a].aspect; c.ppx = cp[a].ppx; c.ppy = cp[a].ppy;
+            std::copy(cp[a].R, cp[a].R + 9, c.R.m.begin());
+            std::copy(cp[a].t, cp[a].t + 3, c.t.begin());
+        }
+    }
     mis_matches_free(pairwise.data(), n * n);
     for (auto& f : features) mis_features_free(ctx_, &f);
-    mis_orb_destroy(orb);
+    if (orb) mis_orb_destroy(orb);
+    if (sift) mis_sift_destroy(sift);
     out.t_matching = now() - t;
     if (kept < 2) throw std::runtime_error("Need more images");
-    // (bundle adjustment / wave correction are outside the hot path: the supplied cameras are used as is)
+    out.cameras.clear();
+    for (int i : out.indices) out.cameras.push_back(cameras[i]);
 
     // ---- warped image scale = median focal (:884-895) ----
     std::vector<double> focals;
@@ -143,15 +191,53 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
     MisBlender* blender = nullptr;
     check(mis_blender_create(ctx_, btype, bands, sharp, &blender), "mis_blender_create");
     check(mis_blender_prepare(blender, corners.data(), sizes.data(), kept), "mis_blender_prepare");
+    // ---- seam-scale pass (:604-622 resize, :973-990 warp, :1002-1023 exposure compensator, :1029-1065 seam finder) ----
+    const bool seam_step = cfg_.expos_comp_type != "no" || cfg_.seam_find_type != "no";
+    MisCompensator* compensator = nullptr;
+    std::vector<MisImage> masks_warped(kept);
+    if (seam_step) {
+        const double seam_scale = std::min(1.0, std::sqrt(cfg_.seam_megapix * 1e6 / ((double)W * H)));
+        const float swa = (float)seam_scale;   // seam_work_aspect with work_scale = 1
+        const float seam_warp_scale = warped_image_scale * swa;
+        std::vector<MisImage> images_warped(kept);
+        std::vector<MisPoint> seam_corners(kept);
+        for (int k = 0; k < kept; k++) {
+            MisImage full = view(frames[out.indices[k]]), img{};
+            if (seam_scale < 1.0) check(mis_resize_linear_exact(ctx_, &full, 0, 0, seam_scale, seam_scale, &img), "mis_resize_linear_exact");
+            else img = full;
+            std::array<float, 9> Ks_ = Ks[k];
+            Ks_[0] *= swa; Ks_[2] *= swa; Ks_[4] *= swa; Ks_[5] *= swa;
+            check(mis_warp_spherical(ctx_, &img, seam_warp_scale, Ks_.data(), Rs[k].data(), MIS_INTER_LINEAR, MIS_BORDER_REFLECT, &images_warped[k], &seam_corners[k]),
+                  "mis_warp_spherical (seam scale)");
+            std::vector<uint8_t> ones((size_t)img.width * img.height, 255);
+            MisImage m{ones.data(), img.width, img.height, 1, (size_t)img.width, MIS_U8, MIS_MEM_HOST};
+            MisPoint tl;
+            check(mis_warp_spherical(ctx_, &m, seam_warp_scale, Ks_.data(), Rs[k].data(), MIS_INTER_NEAREST, MIS_BORDER_CONSTANT, &masks_warped[k], &tl),
+                  "mis_warp_spherical (seam-scale mask)");
+            if (seam_scale < 1.0) mis_image_free(ctx_, &img);
+        }
+        if (cfg_.expos_comp_type == "gain_blocks") {
+            check(mis_compensator_create(ctx_, 64, 64, 2, &compensator), "mis_compensator_create");
+            check(mis_compensator_feed(compensator, seam_corners.data(), images_warped.data(), masks_warped.data(), kept), "mis_compensator_feed");
+        }
+        if (cfg_.seam_find_type == "voronoi") check(mis_seam_voronoi(ctx_, seam_corners.data(), masks_warped.data(), kept), "mis_seam_voronoi");
+        for (auto& im : images_warped) mis_image_free(ctx_, &im);
+    }
     for (int k = 0; k < kept; k++) {
         std::cout << "Compositing image #" << out.indices[k] + 1 << std::endl;
         MisImage src = view(frames[out.indices[k]]), img_warped_s{}, mask_warped{};
         MisPoint tl;
         check(mis_warp_spherical_fused(ctx_, &src, warped_image_scale, Ks[k].data(), Rs[k].data(), &img_warped_s, &mask_warped, &tl), "mis_warp_spherical_fused");
+        if (compensator) check(mis_compensator_apply(compensator, k, &img_warped_s), "mis_compensator_apply");   // :1162
+        if (seam_step) {
+            check(mis_seam_mask_apply(ctx_, &masks_warped[k], &mask_warped), "mis_seam_mask_apply");                // :1169-1171
+            mis_image_free(ctx_, &masks_warped[k]);
+        }
         check(mis_blender_feed(blender, &img_warped_s, &mask_warped, tl), "mis_blender_feed");
         mis_image_free(ctx_, &img_warped_s);
         mis_image_free(ctx_, &mask_warped);
     }
+    if (compensator) mis_compensator_destroy(compensator);
     std::vector<int16_t> res16((size_t)pano.width * pano.height * 3);
     out.mask.width = pano.width; out.mask.height = pano.height; out.mask.channels = 1;
     out.mask.data.resize((size_t)pano.width * pano.height);

@@ -20,6 +20,15 @@ struct StitchConfig {
     float match_conf = 0.32f;
     int blend_type = MIS_BLEND_MULTI_BAND;
     float blend_strength = 5;
+    std::string features_type = "orb";     // "orb" | "sift" (:543-563)
+    // camera refinement (:681-726).  The reference's default is "reproj"; "no" keeps the supplied (sensor) cameras.
+    std::string ba_cost_func = "no";       // "no" | "reproj"
+    std::string ba_refine_mask = "_____";  // the reference's default: rotations only
+    std::string wave_correct = "horiz";    // "horiz" | "vert" | "no"; applied after the bundle adjustment only
+    // seam-scale step (:940-1070, :1162-1171).  The reference's defaults are "gain_blocks" and "dp_color"; DpSeamFinder is
+    // not implemented in the library, so both default to "no" here.
+    std::string expos_comp_type = "no";    // "no" | "gain_blocks" (64 x 64 blocks, 1 feed, 2 filtering passes)
+    std::string seam_find_type = "no";     // "no" | "voronoi"
 };
 
 // cv::detail::CameraParams as main() fills it (focal, aspect, ppx, ppy, R, t)
@@ -50,6 +59,7 @@ struct StitchResult {
     HostImage pano;      // 8UC3 (saturate_cast<uchar> of the 16SC3 result, as imwrite does)
     HostImage mask;      // 8UC1
     std::vector<int> indices;          // images kept by the biggest-component pruning
+    std::vector<CameraParams> cameras; // of the kept images, after the optional refinement
     std::vector<int> num_features;
     std::vector<double> confidence;    // n x n
     double t_features = 0, t_matching = 0, t_compositing = 0;
