@@ -13,7 +13,7 @@ def _frame(w, h, yaw=0.0, seed_pitch=0.0):
     return synth.render_frame(synth.make_camera(w, h, 60.0, yaw, seed_pitch))
 
 
-@pytest.mark.parametrize("w,h", [(320, 200), (333, 251)])
+@pytest.mark.parametrize("w,h", [(320, 200), (333, 251), (1300, 72)])   # the last: rows wider than one 2048-output block of the row pass
 def test_scale_space_bit_exact(ctx, oracle_mod, w, h):
     import torch
     import image_stitching_amd as isa
@@ -30,7 +30,7 @@ def test_scale_space_bit_exact(ctx, oracle_mod, w, h):
             assert np.array_equal(f.debug_level(img, octave, layer, dog=True).view(np.uint32), o.dog(octave, layer).view(np.uint32)), (octave, layer)
 
 
-@pytest.mark.parametrize("w,h,yaw", [(480, 270, 0.0), (333, 251, 40.0), (640, 360, -75.0)])
+@pytest.mark.parametrize("w,h,yaw", [(480, 270, 0.0), (333, 251, 40.0), (640, 360, -75.0), (1300, 72, 10.0)])
 def test_keypoints_and_descriptors_bit_exact(ctx, oracle_mod, w, h, yaw):
     import torch
     import image_stitching_amd as isa
