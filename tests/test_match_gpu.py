@@ -148,10 +148,13 @@ def test_knn2_l2_mfma_bit_exact(ctx, oracle_mod):
     import image_stitching_amd as isa
     from image_stitching_amd.stitching import KP_DTYPE
     rng = np.random.default_rng(51)
-    for nq, nt in ((700, 1300), (65, 33), (31, 2), (4096, 4096)):
+    # the last two: 8 and 16 train slices (the XCD-mapped orders of the kernel), ragged last tile, duplicates in different slices
+    for nq, nt in ((700, 1300), (65, 33), (31, 2), (4096, 4096), (70, 9001), (300, 16411)):
         q, t = _sift_like(rng, nq), _sift_like(rng, nt)
         if nt > 40:
             t[7] = q[3]; t[33] = q[3]      # exact duplicates in different lanes / tiles: tie -> smaller index
+            if nt > 9000:
+                t[nt - 5] = q[3]; t[nt // 2 + 1] = q[5]; t[11] = q[5]   # ... and in different slices
         fq = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nq, KP_DTYPE), q)
         ft = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(nt, KP_DTYPE), t)
         idx = np.zeros((nq, 2), np.int32)
