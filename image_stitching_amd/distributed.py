@@ -215,6 +215,10 @@ class StitchJob:
         self.cfg = config or st.StitchConfig()
         if self.cfg.ba_cost_func != "no" and world_size > 1:
             raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
+        if self.cfg.expos_comp_type != "no" or self.cfg.seam_find_type != "no":
+            # refused rather than ignored: the seam-scale step needs every warped image on one rank
+            raise NotImplementedError("the sharded job composes without exposure compensation / seam finding; "
+                                      "use Stitcher.compose (single GPU) for expos_comp_type / seam_find_type")
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
         self.n = len(cameras)

@@ -108,3 +108,16 @@ def test_region_pack_roundtrip_and_int16_wrap():
         outside = torch.ones_like(db, dtype=torch.bool)
         outside[y0:y1, x0:x1] = False
         assert bool((db[outside] == 1).all()) and bool((da[outside.repeat_interleave(3, 1)] == 30000).all())
+
+
+def test_job_refuses_options_it_does_not_run():
+    """Options the sharded job cannot honour are refused at construction, never silently ignored."""
+    from image_stitching_amd.distributed import StitchJob
+    from image_stitching_amd.stitching import StitchConfig
+    from oracle_engine import OracleEngine
+    cams = _cams()
+    for cfg in (StitchConfig(expos_comp_type="gain_blocks"), StitchConfig(seam_find_type="voronoi")):
+        with pytest.raises(NotImplementedError):
+            StitchJob(None, (W, H), cams, engine=OracleEngine((W, H)), config=cfg)
+    with pytest.raises(NotImplementedError):
+        StitchJob(None, (W, H), cams, rank=0, world_size=2, engine=OracleEngine((W, H)), config=StitchConfig(ba_cost_func="reproj"))
