@@ -111,6 +111,8 @@ PROTOTYPES = {
     "mis_match_all_pairs": (_i, [_vp, _P(MisFeatures), _i, _P(MisMatchParams), _P(MisMatchesInfo)]),
     "mis_match_pairs_sharded": (_i, [_vp, _P(MisFeatures), _i, _P(MisMatchParams), _i, _i, _P(MisMatchesInfo)]),
     "mis_matches_free": (_i, [_P(MisMatchesInfo), _i]),
+    "mis_match_sequence": (C.c_longlong, [_vp]),
+    "mis_match_knn_fence": (_i, [_vp, _vp, C.c_longlong, _i]),
     "mis_knn2": (_i, [_vp, _P(MisFeatures), _P(MisFeatures), _vp, _vp]),
     "mis_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _P(_i)]),
     "mis_leave_biggest_component": (_i, [_P(MisMatchesInfo), _i, _f, _vp, _P(_i)]),
@@ -138,6 +140,7 @@ PROTOTYPES = {
     "mis_blender_num_bands": (_i, [_vp]),
     "mis_blender_feed": (_i, [_vp, _P(MisImage), _P(MisImage), MisPoint]),
     "mis_blender_blend": (_i, [_vp, _P(MisImage), _P(MisImage)]),
+    "mis_compose_frames": (_i, [_vp, _P(MisImage), _i, _f, _vp, _vp, _P(MisRect)]),
     "mis_blender_level_info": (_i, [_vp, _i, _P(_i), _P(_i), _P(_vp), _P(_vp)]),
 }
 

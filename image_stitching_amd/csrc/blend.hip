@@ -491,6 +491,34 @@ extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisIma
     return rc != MIS_OK ? rc : (r1 != MIS_OK ? r1 : r2);
 }
 
+// The compositing loop of main() for n frames in one call (image_stitching.cpp:1154-1164 + :1218 per frame): fused warp
+// into recycled device blocks, feed, next frame.  One library call instead of 2 n keeps a host thread that drives the
+// composition (e.g. concurrently with the matcher) out of the interpreter between launches.
+extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "compose before prepare");
+    MIS_CHECK(ctx, frames && Ks && Rs && rois && n >= 0, MIS_E_INVALID, "null argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) {
+        const MisRect& r = rois[i];
+        MIS_CHECK(ctx, r.width > 0 && r.height > 0, MIS_E_INVALID, "frame %d: empty warp roi", i);
+        const size_t ipitch = mis_align_up((size_t)r.width * 6, 256), mpitch = mis_align_up((size_t)r.width, 256);
+        const size_t ibytes = ipitch * r.height, mbytes = mpitch * r.height;
+        void* blk = nullptr; size_t got = 0;
+        int rc = mis_pool_alloc(ctx, ibytes + mbytes, &blk, &got);
+        if (rc != MIS_OK) return rc;
+        MisImage img{blk, r.width, r.height, 3, ipitch, MIS_S16, MIS_MEM_DEVICE};
+        MisImage msk{(uint8_t*)blk + ibytes, r.width, r.height, 1, mpitch, MIS_U8, MIS_MEM_DEVICE};
+        MisPoint tl;
+        rc = mis_warp_spherical_fused(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &img, &msk, &tl);
+        if (rc == MIS_OK) rc = mis_blender_feed(b, &img, &msk, tl);
+        mis_pool_free(ctx, blk, got);   // stream-ordered reuse: the next frame's warp is enqueued behind this feed
+        if (rc != MIS_OK) return rc;
+    }
+    return MIS_OK;
+}
+
 extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) {
     if (!b) return MIS_E_INVALID;
     MisContext* ctx = b->ctx;

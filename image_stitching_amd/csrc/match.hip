@@ -9,6 +9,9 @@
 //   3. homography.hip         batched findHomography(RANSAC) over all pairs, run twice (all matches,
 //                            then inliers only) exactly as BestOf2NearestMatcher::match does.
 #include "common.h"
+#include <thread>
+#include <chrono>
+#include <atomic>
 #include "dev_math.h"
 #include "homography.h"
 #include <algorithm>
@@ -103,6 +106,7 @@ __device__ __forceinline__ void top2_insert(float d, int i, float& d0, int& i0, 
 
 typedef int int16v __attribute__((ext_vector_type(16)));
 constexpr int L2_MAX_SLICES = 16;
+
 
 // A workgroup of 4 waves owns 256 queries (two sets of 32 per wave, their fragments in registers) and walks the train set in
 // tiles of 32 descriptors that are staged ONCE per workgroup in LDS (double buffered, rows padded to 272 bytes so
@@ -455,6 +459,9 @@ struct MatchWorkspace : MisWorkspace {
     HomoBatch b1, b2, b3;
     hipStream_t side = nullptr;
     hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr;
+    // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
+    hipEvent_t ev_knn = nullptr;
+    std::atomic<long long> seq{0}, knn_seq{0};
     MatchWorkspace() { pinned.host = true; }
     ~MatchWorkspace() override {
         dev.release(); pinned.release(); l2.release();
@@ -462,6 +469,7 @@ struct MatchWorkspace : MisWorkspace {
         if (side) hipStreamDestroy(side);
         if (ev_phase0) hipEventDestroy(ev_phase0);
         if (ev_side_done) hipEventDestroy(ev_side_done);
+        if (ev_knn) hipEventDestroy(ev_knn);
     }
 };
 
@@ -484,6 +492,12 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_CHECK(ctx, feats && p && out && n >= 1, MIS_E_INVALID, "null argument");
     MIS_CHECK(ctx, world >= 1 && rank >= 0 && rank < world, MIS_E_INVALID, "bad rank / world size");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
+    // whatever happens below, a thread waiting in mis_match_knn_fence for this call is released when it returns
+    struct SeqGuard {
+        MatchWorkspace* ws; long long seq;
+        ~SeqGuard() { if (ws->knn_seq.load() < seq) ws->knn_seq.store(seq); }
+    } seq_guard{workspace(ctx), 0};
+    seq_guard.seq = ++seq_guard.ws->seq;
     for (int i = 0; i < n * n; i++) init_info(&out[i]);
     // FeaturesMatcher::operator(): all i < j with non-empty keypoint lists, dealt round-robin over ranks
     std::vector<PairDesc> pairs;
@@ -567,6 +581,12 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         }
         MIS_HIP(ctx, hipMemcpyAsync(&l2_bad, L + o_bad, 4, hipMemcpyDeviceToHost, st));
     }
+    // the 2-NN pass fills the device on its own; what follows are latency-bound chains.  Work that wants to share the
+    // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
+    // the 2-NN pass fills the device on its own; what follows are latency-bound chains.  Work that wants to share the
+    // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
+    if (!ws->ev_knn) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_knn, hipEventDisableTiming));
+    MIS_HIP(ctx, hipEventRecord(ws->ev_knn, st));
     hipLaunchKernelGGL(ratio_union_kernel, dim3(np), dim3(1024), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, (const int*)d_idx,
                        (const float*)d_dist, 1.f - p->match_conf, d_matches, d_src, d_dst, d_nm);
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
@@ -608,6 +628,9 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipMemcpyAsync(fin, ws->b1.fin, sizeof(int) * np, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(hm, d_matches, sizeof(MisDMatch) * m_total, hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipMemcpyAsync(hmask, d_mask, m_total, hipMemcpyDeviceToHost, st));
+    // everything of this call is enqueued: a thread waiting in mis_match_knn_fence may start launching now without
+    // competing with this one for the runtime's launch path
+    ws->knn_seq.store(seq_guard.seq);
     MIS_HIP(ctx, hipStreamSynchronize(st));
     MIS_CHECK(ctx, !l2_bad, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style)");
     // assemble MatchesInfo (host): confidence, mirror entry with H^-1 and swapped indices
@@ -651,6 +674,29 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
 }
 
 }  // namespace
+
+// Number of matcher calls this context has started (the next one will be this + 1).
+extern "C" long long mis_match_sequence(MisContext* ctx) {
+    if (!ctx) return -1;
+    return workspace(ctx)->seq.load();
+}
+
+// Makes `stream` (any stream of the device, e.g. another context's) wait for the end of the 2-NN pass of this context's
+// matcher call number `target_seq`, which another host thread is making: blocks the calling thread (at most timeout_ms)
+// until that call has enqueued the pass, then enqueues the wait.  Returns MIS_OK also when the time ran out or the call
+// ended without a 2-NN pass (the stream then simply does not wait).
+extern "C" int mis_match_knn_fence(MisContext* ctx, void* stream, long long target_seq, int timeout_ms) {
+    if (!ctx) return MIS_E_INVALID;
+    MatchWorkspace* ws = (MatchWorkspace*)ctx->match_ws;
+    MIS_CHECK(ctx, ws, MIS_E_STATE, "mis_match_sequence must have been called on this context first");
+    const auto t0 = std::chrono::steady_clock::now();
+    while (ws->knn_seq.load() < target_seq) {
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return MIS_OK;
+        std::this_thread::yield();
+    }
+    if (ws->ev_knn && hipStreamWaitEvent((hipStream_t)stream, ws->ev_knn, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");
+    return MIS_OK;
+}
 
 // diagnostics: RANSAC states of the last matcher call (which = 0: first estimation of every pair, 1: the inlier-only one)
 extern "C" int mis_debug_ransac_states(MisContext* ctx, int which, int* out, int cap) {

@@ -330,6 +330,18 @@ class Blender:
         x, y, w, h = result_roi(corners, sizes)
         self._size = (w, h)
 
+    def compose_frames(self, frames, scale, cameras, rois):
+        """The compositing loop's per-frame body for all frames in one library call (fused warp + feed each;
+        image_stitching.cpp:1154-1164, :1218): the calling thread stays out of the interpreter between launches."""
+        n = len(frames)
+        if n == 0:
+            return
+        arr = (capi.MisImage * n)(*[as_image(f) for f in frames])
+        Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cameras]))
+        Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cameras]))
+        rr = (capi.MisRect * n)(*[capi.MisRect(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in rois])
+        self.ctx.check(self.ctx.lib.mis_compose_frames(self.h, arr, n, float(scale), Ks.ctypes.data_as(C.c_void_p), Rs.ctypes.data_as(C.c_void_p), rr))
+
     def feed(self, img, mask, tl):
         i, m = as_image(img), as_image(mask)
         self.ctx.check(self.ctx.lib.mis_blender_feed(self.h, C.byref(i), C.byref(m), capi.MisPoint(int(tl[0]), int(tl[1]))))

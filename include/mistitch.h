@@ -148,6 +148,12 @@ int mis_match_all_pairs(MisContext* ctx, const MisFeatures* feats, int n, const 
 int mis_match_pairs_sharded(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchParams* p, int rank,
                             int world_size, MisMatchesInfo* out);
 int mis_matches_free(MisMatchesInfo* m, int count);
+/* Ordering aid for a caller that overlaps other device work with a matcher call made by another host thread (the
+ * job's speculative composition): mis_match_sequence = number of matcher calls this context has started;
+ * mis_match_knn_fence(ctx, stream, mis_match_sequence(ctx) + 1 taken BEFORE the other thread calls the matcher, ms)
+ * makes `stream` wait for the end of that call's 2-NN pass (the one phase of the matcher that fills the device). */
+long long mis_match_sequence(MisContext* ctx);
+int mis_match_knn_fence(MisContext* ctx, void* stream, long long target_seq, int timeout_ms);
 /* exact 2-NN (distance, trainIdx) for one direction; results in host memory (stage test hook) */
 int mis_knn2(MisContext* ctx, const MisFeatures* query, const MisFeatures* train, int* idx2_host, float* dist2_host);
 /* cv::findHomography(src, dst, mask, RANSAC, thresh, max_iters, confidence) on host point lists */
@@ -253,6 +259,10 @@ int mis_blender_num_bands(const MisBlender* b);
 int mis_blender_feed(MisBlender* b, const MisImage* img_s16x3, const MisImage* mask_u8, MisPoint tl);
 /* blender->blend(result, result_mask) -- replaces :1225 */
 int mis_blender_blend(MisBlender* b, MisImage* dst_s16x3, MisImage* dst_mask);
+/* The per-frame body of the compositing loop for n frames in one call: fused warp of frames[i] with (Ks + 9 i, Rs + 9 i)
+ * at `scale` into library-owned device blocks of size rois[i] (= mis_warp_roi of the frame), then feed -- replaces
+ * image_stitching.cpp:1154-1164 and :1218 for every image of the loop at :1086.  Same results as the single calls. */
+int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois);
 /* accumulated pyramid level before blend() (host copies, parity tests / multi-GPU reduction hooks) */
 int mis_blender_level_info(const MisBlender* b, int level, int* width, int* height, void** lap_dev, void** weight_dev);
 

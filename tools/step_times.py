@@ -3,6 +3,7 @@ import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_stitching_amd as isa, synth
 from image_stitching_amd.distributed import StitchJob
+if os.environ.get("SWITCH"): sys.setswitchinterval(float(os.environ["SWITCH"]))
 ctx = isa.Context(0)
 wl = sys.argv[2] if len(sys.argv) > 2 else "config3"
 cams = synth.workload(wl)
