@@ -396,11 +396,17 @@ class StitchJob:
 
             fence = self.engine.match_fence_target() if hasattr(self.engine, "match_fence_target") else None
 
+            # a single rank has no exchange between feed and finalise: the collapse of the pyramid is speculated too
+            solo = self.world == 1 and not self.force_collectives
+
             def work():
                 try:
                     if fence is not None:
                         self.engine.compose_after_knn(fence)
                     box["r"] = self._compose_on_side_stream(frames, everyone)
+                    if solo:
+                        with torch.cuda.stream(self.engine.compose_stream):
+                            box["f"] = self.stage_finalize()
                 except BaseException as e:   # re-raised on the caller's thread
                     box["e"] = e
             th = threading.Thread(target=work)
@@ -412,11 +418,14 @@ class StitchJob:
                 th.join()
             if "e" in box:
                 raise box["e"]
-            btype, bands = box["r"] if indices == everyone else self._compose_on_side_stream(frames, indices)
-            self.engine.compose_stream.synchronize()     # the accumulators are complete before any exchange
-            with torch.cuda.stream(self.engine.compose_stream):
-                self.stage_reduce()
-                pano, mask = self.stage_finalize()
+            if indices == everyone and "f" in box:
+                (btype, bands), (pano, mask) = box["r"], box["f"]
+            else:
+                btype, bands = box["r"] if indices == everyone else self._compose_on_side_stream(frames, indices)
+                self.engine.compose_stream.synchronize()     # the accumulators are complete before any exchange
+                with torch.cuda.stream(self.engine.compose_stream):
+                    self.stage_reduce()
+                    pano, mask = self.stage_finalize()
         else:
             pm, conf = self.stage_match(feats)
             indices = self.stage_prune(conf)
