@@ -46,6 +46,7 @@ int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long point
 int homo_batch_debug_states(MisContext* ctx, const HomoBatch* b, int* out, int cap);
 void homo_batch_release(HomoBatch* b);
 // `calls` (device array of b->count entries) must be filled before this is enqueued on ctx->stream.
-// phases: 0 = hypotheses [0, PHASE0) + replay + tails of the problems that finish there; 1 = the rest; 2 = both.
+// phases: 0 = hypotheses [0, PHASE0) + replay + tails of the problems that finish there; 1 = the rest; 2 = both;
+// 3 = like 0 without the tails (left pending), 4 = those pending tails only (any stream, concurrently with a phases = 1 run).
 // `stream` = nullptr: the context's stream.
 int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases = 2, hipStream_t stream = nullptr);

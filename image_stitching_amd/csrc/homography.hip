@@ -35,6 +35,7 @@ struct RansacState {
     int mode;      // 0 skip, 1 exactly 4 points, 2 RANSAC
     int n_sub;     // subsets drawn so far (the sequential getSubset sequence)
     int iter, niters, max_good, done, best_k, result;
+    int tail_pending;   // the loop ended in a scan-only launch: mask / DLT / LM refinement still to run (scan_tail_kernel part 2)
     int draw_k, draw_fail;   // next iteration to draw; getSubset exhausted its 10000 attempts
     long long draw_pos;      // RNG stream position after the last drawn subset
 };
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     if (phase == 0) {
         if (t == 0) {
             st->mode = (!c.active || c.n < 4) ? 0 : (c.n == 4 ? 1 : 2);
-            st->n_sub = 0; st->iter = 0; st->niters = max_iters > 1 ? max_iters : 1; st->max_good = 0; st->done = 0; st->best_k = -1; st->result = 0;
+            st->n_sub = 0; st->iter = 0; st->niters = max_iters > 1 ? max_iters : 1; st->max_good = 0; st->done = 0; st->best_k = -1; st->result = 0; st->tail_pending = 0;
             st->draw_k = 0; st->draw_fail = 0; st->draw_pos = 0;
         }
         if (!c.active || c.n <= 4) return;
@@ -910,9 +911,13 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
     __syncthreads();
 }
 
+// part 0: replay + tail (the finished problems' mask, DLT on the inliers, LM refinement) in one launch;
+// part 1: replay only -- a problem that ends here is marked tail_pending; part 2: the tail of the pending problems whose
+// fin equals `want`.  The split lets the tails of the problems that end in RANSAC phase 0 (latency bound, ~2 ms) run on
+// another stream while phase 1 of the others -- which only needs the replay's verdict -- goes on.
 __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
-                                                       double confidence, float thr, int* fin) {
+                                                       double confidence, float thr, int* fin, int part, int want) {
     __shared__ TailShared S;
     __shared__ int s_done_now;
     __shared__ int wcnt[TB / 64];
@@ -925,6 +930,11 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     float* s1 = scr_all + 4 * c.pt_off;
     float* d1 = s1 + 2 * (size_t)(n > 0 ? n : 0);
     double* rec = rec_all + 10 * c.pt_off;
+    if (part == 2) {
+        if (!st->tail_pending || fin[b] != want) return;   // uniform
+        __syncthreads();                                    // every thread has read the flag before it is cleared
+        if (t == 0) st->tail_pending = 0;
+    } else {
     if (st->done) return;  // finished in an earlier phase (uniform)
     const int mode = st->mode;
     if (t == 0) s_done_now = 0;
@@ -964,6 +974,11 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     }
     __syncthreads();
     if (!s_done_now) return;
+    if (part == 1) {
+        if (t == 0) st->tail_pending = 1;
+        return;
+    }
+    }   // part != 2
     const int result = st->max_good > 0;
     if (t == 0) { res->iters = st->iter; res->ok = result; res->ninl = 0; }
     if (!result) {
@@ -1106,20 +1121,23 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     RansacState* states = (RansacState*)b->state;
     const int p0 = std::min(PHASE0, max_iters);
-    if (phases == 0 || phases == 2) {
+    if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
         hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin);
+                           max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0);
     }
+    if (phases == 4)   // the tails a phases == 3 run left pending (fin == 0)
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin, 2, 0);
     if ((phases == 1 || phases == 2) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
-                           max_iters, max_iters, confidence, thr, b->fin);
+                           max_iters, max_iters, confidence, thr, b->fin, 0, 0);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

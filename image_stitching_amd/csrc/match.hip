@@ -493,6 +493,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_CHECK(ctx, world >= 1 && rank >= 0 && rank < world, MIS_E_INVALID, "bad rank / world size");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     // whatever happens below, a thread waiting in mis_match_knn_fence for this call is released when it returns
+    const auto t_begin = std::chrono::steady_clock::now();
     struct SeqGuard {
         MatchWorkspace* ws; long long seq;
         ~SeqGuard() { if (ws->knn_seq.load() < seq) ws->knn_seq.store(seq); }
@@ -596,16 +597,17 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase0, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }
-    // first estimation, phase 0 (pairs with a clear overlap finish here)
-    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 0, st)) != MIS_OK) return rc;
+    // first estimation, phase 0 up to the replay's verdict (pairs with a clear overlap finish here)
+    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 3, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
-    // side stream: the inlier-only estimation of those pairs ...
+    // side stream: the tails of those pairs (mask, DLT on the inliers, LM: ~2 ms of latency) and their inlier-only estimation ...
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
+    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 4, ws->side)) != MIS_OK) return rc;
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out);
     if ((rc = homo_batch_run(ctx, &ws->b2, p->ransac_thresh, p->max_iters, p->confidence, 2, ws->side)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
-    // ... while the main stream finishes the first estimation of the others and runs their second one
+    // ... while the main stream finishes the first estimation of the others (which only needs the verdict) and runs their second one
     if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 1, st)) != MIS_OK) return rc;
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out);
@@ -631,7 +633,10 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // everything of this call is enqueued: a thread waiting in mis_match_knn_fence may start launching now without
     // competing with this one for the runtime's launch path
     ws->knn_seq.store(seq_guard.seq);
+    const bool trace = getenv("MIS_MATCH_TRACE") != nullptr;
+    const auto tq = std::chrono::steady_clock::now();
     MIS_HIP(ctx, hipStreamSynchronize(st));
+    const auto ts = std::chrono::steady_clock::now();
     MIS_CHECK(ctx, !l2_bad, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style)");
     // assemble MatchesInfo (host): confidence, mirror entry with H^-1 and swapped indices
     for (int k = 0; k < np; k++) {
@@ -669,6 +674,11 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             memcpy(b->inliers_mask, a->inliers_mask, (size_t)nm[k]);
         }
         if (a->has_H) invert3(a->H, b->H);
+    }
+    if (trace) {
+        const auto te = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "match: enqueue %.0f us, device wait %.0f us, host assembly %.0f us\n", us(t_begin, tq), us(tq, ts), us(ts, te));
     }
     return MIS_OK;
 }
