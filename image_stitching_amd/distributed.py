@@ -270,13 +270,20 @@ class StitchJob:
     def stage_prune(self, conf):
         return [int(i) for i in st.leaveBiggestComponentConf(conf.cpu().numpy().reshape(self.n, self.n), self.cfg.conf_thresh)]
 
-    def stage_compose(self, frames, indices):
+    def stage_compose_prepare(self, indices):
+        """blender sizing + prepare for the kept frames (image_stitching.cpp:1138, :1175-1192): needs the cameras only."""
         eng = self.engine
         rois = {i: eng.warp_roi(self.scale, self.cams[i]) for i in indices}
         corners = [(rois[i][0], rois[i][1]) for i in indices]
         sizes = [(rois[i][2], rois[i][3]) for i in indices]
         btype, bands = eng.begin_compose(self.scale, corners, sizes)
         self._compose_indices, self._compose_rois = indices, rois
+        return btype, bands
+
+    def stage_compose(self, frames, indices, prepared=None):
+        eng = self.engine
+        btype, bands = prepared if prepared is not None else self.stage_compose_prepare(indices)
+        rois = self._compose_rois
         mine = [i for i in self.my_frames if i in rois]
         if hasattr(eng, "warp_feed_many"):
             eng.warp_feed_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine])
@@ -374,18 +381,24 @@ class StitchJob:
         return None, None
 
     # -- whole job ---------------------------------------------------------------------------
-    def _compose_on_side_stream(self, frames, indices):
+    def _compose_on_side_stream(self, frames, indices, prepared=None):
         """stage_compose with the engine's compose stream current (allocations and launches belong to it)."""
         eng = self.engine
         with torch.cuda.stream(eng.compose_stream):
-            return self.stage_compose(frames, indices)
+            return self.stage_compose(frames, indices, prepared)
 
     def run(self, frames):
-        feats = self.stage_gather(self.stage_features(frames))
         refine = self.cfg.ba_cost_func != "no"
         if refine and self.world > 1:
             raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         spec = getattr(self.engine, "speculative_compose", False) and not refine   # refined cameras: compose must wait
+        prepared = None
+        if spec:
+            # the blender's prepare (sizing + zeroing ~200 MB of panorama pyramids, ~1.2 ms) depends on the cameras only:
+            # it goes to the compose stream before anything else and runs under the feature stage
+            with torch.cuda.stream(self.engine.compose_stream):
+                prepared = self.stage_compose_prepare(list(range(self.n)))
+        feats = self.stage_gather(self.stage_features(frames))
         if spec:
             # Speculation: almost always every frame survives the pruning, and warp + blend do not depend on the
             # matches otherwise (the cameras are inputs).  Compose for ALL frames on the second stream from a helper
@@ -403,7 +416,7 @@ class StitchJob:
                 try:
                     if fence is not None:
                         self.engine.compose_after_knn(fence)
-                    box["r"] = self._compose_on_side_stream(frames, everyone)
+                    box["r"] = self._compose_on_side_stream(frames, everyone, prepared)
                     if solo:
                         with torch.cuda.stream(self.engine.compose_stream):
                             box["f"] = self.stage_finalize()
