@@ -118,6 +118,100 @@ __global__ __launch_bounds__(256) void pyr_down_f32_kernel(FrameView v, const fl
     dst[(size_t)y * dw + x] = r * (1.f / 256.f);
 }
 
+// ---- level 0 of a feed: both reductions of the padded frame view in one kernel (same 67 x 35 footprint) ----
+// Gaussian level 1 of the image (s16x3) and of the weights (mask / 255, f32) from one staging of the tile.  Tiles whose
+// footprint lies inside the frame (no reflection at all: the bulk of a 4K frame) stage their rows with aligned dword
+// loads (a row is 402 contiguous bytes of 16SC3) instead of three 2-byte loads per pixel, and their weights with dword
+// loads of the mask; the arithmetic of both passes is that of pyr_down_s16x3_kernel / pyr_down_f32_kernel.
+constexpr int PDV_ROW_DW = (PD_SW * 6 + 2 + 3) / 4 + 1;   // dwords that cover a row of 67 pixels from an address rounded down to 4
+constexpr int PDV_MROW_DW = (PD_SW + 3 + 3) / 4 + 1;      // same for the 67 mask bytes
+__global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh) {
+    __shared__ __attribute__((aligned(4))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
+    __shared__ float wt[PD_SH * PD_SW];
+    __shared__ int hbuf[PD_SH * PD_W * 3];
+    __shared__ float hw[PD_SH * PD_W];
+    const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
+    const int sw = v.tw, sh = v.th;
+    const int tx0 = 2 * x0 - 2, ty0 = 2 * y0 - 2;                    // tile coordinates of the footprint's corner
+    const int ix0 = tx0 - v.left, iy0 = ty0 - v.top;                 // image coordinates of the same
+    const bool interior = tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW <= sw && ty0 + PD_SH <= sh && ix0 >= 0 && iy0 >= 0 && ix0 + PD_SW + 12 <= v.w && iy0 + PD_SH <= v.h &&   /* + 12: the dword loads may run past the last needed byte */
+                          (v.istride & 1) == 0 && ((uintptr_t)v.img & 3) == 0 && (v.mstride & 3) == 0 && ((uintptr_t)v.mask & 3) == 0;
+    int toff;   // shorts between the start of an LDS row and its first pixel
+    if (interior) {
+        const size_t e0 = 3 * (size_t)ix0;                           // first short of a row, relative to the row start
+        toff = (int)(e0 & 1);
+        const int16_t* base = v.img + (size_t)iy0 * v.istride + (e0 - toff);
+        // all loads of a thread are issued before the first LDS store (a load -> store loop serialises the round trips)
+        constexpr int NI = (PD_SH * PDV_ROW_DW + 255) / 256, NM = (PD_SH * PDV_MROW_DW + 255) / 256;
+        const int moff = ix0 & 3;
+        const uint8_t* mbase = v.mask + (size_t)iy0 * v.mstride + (ix0 - moff);
+        unsigned ri[NI], rm[NM];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = t + 256 * k, r = i / PDV_ROW_DW, c = i - r * PDV_ROW_DW;
+            ri[k] = i < PD_SH * PDV_ROW_DW ? *reinterpret_cast<const unsigned*>(base + (size_t)r * v.istride + 2 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NM; k++) {
+            const int i = t + 256 * k, r = i / PDV_MROW_DW, c = i - r * PDV_MROW_DW;
+            rm[k] = i < PD_SH * PDV_MROW_DW ? *reinterpret_cast<const unsigned*>(mbase + (size_t)r * v.mstride + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = t + 256 * k;
+            if (i < PD_SH * PDV_ROW_DW) reinterpret_cast<unsigned*>(tile)[i] = ri[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NM; k++) {
+            const int i = t + 256 * k, r = i / PDV_MROW_DW, c = i - r * PDV_MROW_DW;
+            if (i < PD_SH * PDV_MROW_DW) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int x = 4 * c + q - moff;
+                    if (x >= 0 && x < PD_SW) wt[r * PD_SW + x] = (float)((rm[k] >> (8 * q)) & 255u) * (float)(1. / 255.);
+                }
+            }
+        }
+    } else {
+        toff = 0;
+        for (int i = t; i < PD_SH * PD_SW; i += 256) {
+            const int r = i / PD_SW, c = i - r * PD_SW;
+            const int sy = mis_reflect101(ty0 + r, sh), sx = mis_reflect101(tx0 + c, sw);
+            int px[3];
+            view_px(v, sx, sy, px);
+            int16_t* o = tile + (size_t)r * (PDV_ROW_DW * 2) + 3 * c;
+            o[0] = (int16_t)px[0]; o[1] = (int16_t)px[1]; o[2] = (int16_t)px[2];
+            wt[i] = view_w(v, sx, sy);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < PD_SH * PD_W * 3; i += 256) {
+        const int r = i / (PD_W * 3), rem = i - r * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
+        const int16_t* p = tile + (size_t)r * (PDV_ROW_DW * 2) + toff + (2 * x) * 3 + ch;
+        hbuf[i] = p[6] * 6 + (p[3] + p[9]) * 4 + p[0] + p[12];
+    }
+    for (int i = t; i < PD_SH * PD_W; i += 256) {
+        const int r = i / PD_W, x = i - r * PD_W;
+        const float* s = wt + r * PD_SW + 2 * x;
+        hw[i] = ((s[2] * 6.f + (s[1] + s[3]) * 4.f) + s[0]) + s[4];
+    }
+    __syncthreads();
+    for (int i = t; i < PD_H * PD_W * 3; i += 256) {
+        const int y = i / (PD_W * 3), rem = i - y * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
+        if (x0 + x >= dw || y0 + y >= dh) continue;
+        const int* p = hbuf + (2 * y) * (PD_W * 3) + rem;
+        const int acc = p[2 * PD_W * 3] * 6 + (p[PD_W * 3] + p[3 * PD_W * 3]) * 4 + p[0] + p[4 * PD_W * 3];
+        dst[((size_t)(y0 + y) * dw + x0 + x) * 3 + ch] = (int16_t)((acc + 128) >> 8);
+    }
+    for (int i = t; i < PD_H * PD_W; i += 256) {
+        const int y = i / PD_W, x = i - y * PD_W;
+        if (x0 + x >= dw || y0 + y >= dh) continue;
+        const float* p = hw + (2 * y) * PD_W + x;
+        const float r = ((p[2 * PD_W] * 6.f + (p[PD_W] + p[3 * PD_W]) * 4.f) + p[0]) + p[4 * PD_W];
+        wdst[(size_t)(y0 + y) * dw + x0 + x] = r * (1.f / 256.f);
+    }
+}
+
 // pyrUp of a coarse 16SC3 level evaluated at one fine pixel (fine = 2 x coarse exactly):
 // even: r[x-1] + 6 r[x] + r[x+1], odd: 4 (r[x] + r[x+1]); left/top neighbour of sample 0 is sample 1,
 // right/bottom neighbour of the last sample is the last sample; (v + 32) >> 6.
@@ -329,8 +423,7 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
         dim3 g = grid2d(tw[i + 1], th[i + 1]);
         dim3 gp((tw[i + 1] + PD_W - 1) / PD_W, (th[i + 1] + PD_H - 1) / PD_H);
         if (i == 0) {
-            hipLaunchKernelGGL((pyr_down_s16x3_kernel<true>), gp, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], G(1), tw[1], th[1]);
-            hipLaunchKernelGGL((pyr_down_f32_kernel<true>), g, blk, 0, ctx->stream, v, nullptr, tw[0], th[0], W(1), tw[1], th[1]);
+            hipLaunchKernelGGL(pyr_down_view_kernel, gp, blk, 0, ctx->stream, v, G(1), W(1), tw[1], th[1]);
         } else {
             hipLaunchKernelGGL((pyr_down_s16x3_kernel<false>), gp, blk, 0, ctx->stream, v, G(i), tw[i], th[i], G(i + 1), tw[i + 1], th[i + 1]);
             hipLaunchKernelGGL((pyr_down_f32_kernel<false>), g, blk, 0, ctx->stream, v, W(i), tw[i], th[i], W(i + 1), tw[i + 1], th[i + 1]);
