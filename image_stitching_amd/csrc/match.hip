@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
         const uint4* p = reinterpret_cast<const uint4*>(Q.desc + (size_t)q * 32);
         a0 = p[0]; a1 = p[1];
     }
-    int d0 = 1 << 30, d1 = 1 << 30, i0 = -1, i1 = -1;
+    // running top two as keys (distance << 22 | train index): the order of the keys is the (distance, index) order of the
+    // scalar loop ("d < d0" keeps the earlier train on ties), and the update is a min and a median-of-three
+    int k0 = 0x7fffffff, k1 = 0x7fffffff;
     for (int t0 = 0; t0 < T.n; t0 += KNN_TILE) {
         const int nt = min(KNN_TILE, T.n - t0);
         __syncthreads();
@@ -61,13 +63,15 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
                 uint4 b0 = tr[2 * j], b1 = tr[2 * j + 1];
                 int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
                         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = t0 + j; }
-                else if (d < d1) { d1 = d; i1 = t0 + j; }
+                const int key = (d << 22) | (t0 + j);
+                k1 = max(min(k0, k1), min(max(k0, k1), key));   // median of (k0, k1, key): one v_med3_i32
+                k0 = min(k0, key);
             }
         }
     }
     if (active) {
-        idx2[(off + q) * 2] = i0; idx2[(off + q) * 2 + 1] = i1;
+        const int d0 = k0 == 0x7fffffff ? 1 << 30 : k0 >> 22, d1 = k1 == 0x7fffffff ? 1 << 30 : k1 >> 22;
+        idx2[(off + q) * 2] = k0 == 0x7fffffff ? -1 : (k0 & 0x3fffff); idx2[(off + q) * 2 + 1] = k1 == 0x7fffffff ? -1 : (k1 & 0x3fffff);
         dist2[(off + q) * 2] = (float)d0; dist2[(off + q) * 2 + 1] = (float)d1;
     }
 }
@@ -510,6 +514,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         const bool l2_i = feats[i].desc_dtype == MIS_F32 && feats[i].desc_cols >= 1 && feats[i].desc_cols <= 128;
         MIS_CHECK(ctx, feats[i].n == 0 || bin_i || l2_i, MIS_E_UNSUPPORTED,
                   "all-pairs matching supports 32-byte binary descriptors (Hamming) or f32 descriptors of <= 128 columns (L2)");
+        MIS_CHECK(ctx, feats[i].n < (1 << 22), MIS_E_UNSUPPORTED, "more than 4 M keypoints in one image");   // index bits of the 2-NN keys
         if (feats[i].n > 0) { if (l2_i) use_l2 = true; else use_bin = true; }
         fd[i] = FeatDev{(const uint8_t*)feats[i].descriptors, feats[i].keypoints, feats[i].n, feats[i].img_w, feats[i].img_h};
     }
