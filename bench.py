@@ -60,11 +60,19 @@ def main():
     import synth
     from image_stitching_amd import distributed as misdist
 
+    # MIS_BENCH_REHEARSAL=1: the N > 1 code path on a box with ONE GPU (every rank on cuda:0, gloo instead of RCCL) --
+    # a functional rehearsal of this script's multi-rank branch, not a measurement
+    rehearsal = os.environ.get("MIS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
     workload = args.workload or ("config3" if world == 1 else "config4")
     cams = synth.workload(workload)
@@ -149,7 +157,7 @@ def main():
     cpu = None
     if rank == 0:
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
-        if not args.no_cpu_baseline and features == "orb":
+        if not args.no_cpu_baseline and features == "orb" and world == 1:     # the CPU baseline is an N = 1 item
             cpu = cpu_baseline(cams, workload)
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
