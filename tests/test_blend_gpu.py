@@ -112,3 +112,30 @@ def test_multiband_full_size_properties(ctx):
     # inside the overlap the blend is between the two inputs
     ov = o[1000, 2700:3800, 0]
     assert ov.min() >= 70 and ov.max() <= 170
+
+
+def test_warp_then_blend_4k_pair_bit_exact(ctx, oracle_mod):
+    """Two adjacent BASELINE config-3 frames at full size through the fused warp and the multiband blender (the
+    band count the job uses for them) against the oracle: every pyramid level and the final panorama."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    cams = synth.workload("config3")[7:9]
+    frames = [synth.render_frame(c) for c in cams]
+    scale = isa.Stitcher.warped_image_scale(cams)
+    warper = isa.SphericalWarper(ctx, scale)
+    items = []
+    for cam, f in zip(cams, frames):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        tl, img_s, msk = warper.warp_fused(torch.from_numpy(f).cuda(), K, R)
+        oi, otl = oracle_mod.warp_spherical(f, scale, K, R)
+        om, _ = oracle_mod.warp_spherical(np.full(f.shape[:2], 255, np.uint8), scale, K, R, 0, 0)
+        got_i, got_m = img_s.cpu().numpy(), msk.cpu().numpy()
+        assert otl == tl and np.array_equal(got_i, oi.astype(np.int16)) and np.array_equal(got_m, om)
+        items.append((got_i, got_m, tl))
+    cs = [i[2] for i in items]; ss = [(i[1].shape[1], i[1].shape[0]) for i in items]
+    x0 = min(c[0] for c in cs); y0 = min(c[1] for c in cs)
+    x1 = max(c[0] + s[0] for c, s in zip(cs, ss)); y1 = max(c[1] + s[1] for c, s in zip(cs, ss))
+    _, bands, _ = oracle_mod.blend_config(oracle_mod.BLEND_MULTI_BAND, 5.0, x1 - x0, y1 - y0)
+    pano = _run_both(ctx, oracle_mod, oracle_mod.BLEND_MULTI_BAND, items, bands=bands, check_levels=True)
+    assert pano.shape[1] > 3840 and bands >= 6

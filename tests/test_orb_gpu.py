@@ -98,3 +98,14 @@ def test_orb_4k_properties(ctx):
         assert np.all((sel["angle"] >= 0) & (sel["angle"] < 360))
     assert np.all(np.diff(k1["octave"]) >= 0)
     assert k1["x"].min() >= 0 and k1["x"].max() < 3840 and k1["y"].max() < 2160
+
+
+def test_orb_4k_frame_bit_exact(ctx, oracle_mod):
+    """One BASELINE config-3 frame at full size against the oracle (all pyramid levels, keypoints, descriptors)."""
+    import synth
+    import image_stitching_amd as isa
+    cam = synth.workload("config3")[7]
+    frame = synth.render_frame(cam)
+    finder = isa.OrbFeatureFinder(ctx, (3840, 2160))
+    kps, desc = _check_frame(ctx, oracle_mod, finder, oracle_mod.Orb(3840, 2160), frame)
+    assert len(kps) == 4000
