@@ -211,7 +211,7 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) { 
 // The gray tile (+4 halo) is staged with coalesced dword loads issued up front, the scores of the tile
 // (+1 halo) are computed from LDS, and the survivors go to a per-level list (x | y << 16, score) and a
 // per-level histogram: the score map never exists in HBM.
-constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80;
+constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80, HIST_COPIES = 8;
 __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc) {
     __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 8) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75
     __shared__ uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
         surv_xy[(size_t)tile * 512 + j] = lxy[j]; surv_sc[(size_t)tile * 512 + j] = lsc[j];
     }
     __syncthreads();
-    if (lh[t]) atomicAdd(&hist[blockIdx.z * 256 + t], lh[t]);
+    // HIST_COPIES copies of a level's histogram, picked by the tile: the popular bins would otherwise take one atomic from
+    // nearly every tile on a single address (same-address atomics serialise); fast_cut_kernel adds the copies up
+    if (lh[t]) atomicAdd(&hist[((blockIdx.z * HIST_COPIES) + ((blockIdx.x + blockIdx.y) & (HIST_COPIES - 1))) * 256 + t], lh[t]);
 }
 
 // retainBest(2 N_l) on the integer FAST score: cut = the n2-th best score (1 = keep everything), found
@@ -306,7 +308,9 @@ __global__ __launch_bounds__(256) void fast_cut_kernel(Levels L, const int* hist
     const int l = blockIdx.x, t = threadIdx.x;
     const LevelDesc& d = L.d[l];
     // suffix sums of the histogram: suf[v] = number of survivors with score >= v
-    suf[t] = t ? hist[l * 256 + t] : 0;
+    int hsum = 0;
+    for (int c = 0; c < HIST_COPIES; c++) hsum += hist[(l * HIST_COPIES + c) * 256 + t];
+    suf[t] = t ? hsum : 0;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
         int add = t + o < 256 ? suf[t + o] : 0;
@@ -795,7 +799,7 @@ int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* ou
     const Work& W = o->w;
     hipStream_t st = ctx->stream;
     const LevelDesc& d0 = L.d[0];
-    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), st));  // hist, thr, cnt0, cnt1, cnt2
+    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), st));  // hist, thr, cnt0, cnt1, cnt2
     const int aligned = (img.stride % 4 == 0) && ((uintptr_t)img.data % 4 == 0);
     hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h), dim3(256), 0, st, (const uint8_t*)img.data, img.stride, w, h, W.pad + d0.pad_off, d0.pp, aligned);
     for (int l = 1; l < L.n; l++) {
@@ -867,7 +871,7 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
     size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
-    size_t o_hist = carve(sizeof(int) * (256 * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
+    size_t o_hist = carve(sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
     size_t o_sxy = carve(sizeof(uint32_t) * 512 * (size_t)o->surv_total), o_ssc = carve(512 * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
     size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
     size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
@@ -876,7 +880,7 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     uint8_t* m = (uint8_t*)o->mem;
     Work& W = o->w;
     W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
-    W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
+    W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * HIST_COPIES * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
     W.surv_xy = (uint32_t*)(m + o_sxy); W.surv_sc = m + o_ssc; W.tile_cnt = (int*)(m + o_tc);
     W.flags = (int*)(m + o_flags);
     W.cand_xy = (uint32_t*)(m + o_cxy); W.cand_resp = (float*)(m + o_cr); W.fin_xy = (uint32_t*)(m + o_fxy); W.fin_resp = (float*)(m + o_fr);

@@ -373,14 +373,24 @@ __device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd
     float omax = hist[0];
     for (int j = 1; j < n; j++) omax = omax > hist[j] ? omax : hist[j];
     const float mag_thr = omax * SIFT_ORI_PEAK_RATIO;
+    // the lanes that got this far walk the 36 bins in lockstep: peaks of the same bin index are appended with one
+    // global atomic (the counter is a single address; the list order is arbitrary, the keypoints are sorted later)
+    const int lane = threadIdx.x & 63;
     for (int j = 0; j < n; j++) {
         const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
-        if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
+        const bool peak = hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr;
+        const unsigned long long m = __ballot(peak);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(n_kps, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (peak) {
             float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
             bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
             kpt.angle = 360.f - (float)((360.f / n) * bin);
             if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
-            const unsigned slot = atomicAdd(n_kps, 1u);
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
             if (slot < kp_cap) kps[slot] = kpt;
         }
     }
