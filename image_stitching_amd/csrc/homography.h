@@ -47,6 +47,7 @@ int homo_batch_debug_states(MisContext* ctx, const HomoBatch* b, int* out, int c
 void homo_batch_release(HomoBatch* b);
 // `calls` (device array of b->count entries) must be filled before this is enqueued on ctx->stream.
 // phases: 0 = hypotheses [0, PHASE0) + replay + tails of the problems that finish there; 1 = the rest; 2 = both;
-// 3 = like 0 without the tails (left pending), 4 = those pending tails only (any stream, concurrently with a phases = 1 run).
+// 3 / 6 = like 0 / 1 without the tails (left pending), 4 = the pending tails of phase 0 (any stream, concurrently with a phases = 1 run);
+// 10 + 2 w / 11 + 2 w = the pending tails of phase w in two steps: mask + inlier compaction / DLT + LM refinement.
 // `stream` = nullptr: the context's stream.
 int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases = 2, hipStream_t stream = nullptr);

@@ -930,10 +930,11 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     float* s1 = scr_all + 4 * c.pt_off;
     float* d1 = s1 + 2 * (size_t)(n > 0 ? n : 0);
     double* rec = rec_all + 10 * c.pt_off;
-    if (part == 2) {
-        if (!st->tail_pending || fin[b] != want) return;   // uniform
-        __syncthreads();                                    // every thread has read the flag before it is cleared
-        if (t == 0) st->tail_pending = 0;
+    if (part >= 2) {
+        // part 2 runs the whole tail of a pending problem (flag 1 -> 0); parts 3 / 4 split it: mask + compaction (1 -> 2), DLT + LM (2 -> 0)
+        if (st->tail_pending != (part == 4 ? 2 : 1) || fin[b] != want) return;   // uniform
+        __syncthreads();                                    // every thread has read the flag before it changes
+        if (part == 2 && t == 0) st->tail_pending = 0;
     } else {
     if (st->done) return;  // finished in an earlier phase (uniform)
     const int mode = st->mode;
@@ -980,18 +981,20 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     }
     }   // part != 2
     const int result = st->max_good > 0;
-    if (t == 0) { res->iters = st->iter; res->ok = result; res->ninl = 0; }
+    if (part != 4 && t == 0) { res->iters = st->iter; res->ok = result; res->ninl = 0; }
     if (!result) {
         for (int i = t; c.mask && i < n; i += TB) c.mask[i] = 0;
+        if (t == 0) st->tail_pending = 0;
         return;
     }
     // best model -> mask, ordered compaction of the inliers (compressElems)
     if (t == 0) {
         const double* hb = Hc + ((size_t)b * max_iters + st->best_k) * 9;
         for (int i = 0; i < 9; i++) { S.best[i] = hb[i]; S.Hf[i] = (float)hb[i]; }
-        s_base = 0;
+        s_base = part == 4 ? res->ninl : 0;
     }
     __syncthreads();
+    if (part != 4)
     for (int i0 = 0; i0 < n; i0 += TB) {
         int i = i0 + t, f = 0;
         if (i < n) f = is_inlier(S.Hf, c.src[2 * i], c.src[2 * i + 1], c.dst[2 * i], c.dst[2 * i + 1], thr);
@@ -1011,6 +1014,10 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         __syncthreads();
     }
     const int np = s_base;
+    if (part == 3) {   // the inlier set is final here; DLT + LM on it (part 4) only changes H
+        if (t == 0) { res->ninl = np; for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; st->tail_pending = 2; }
+        return;
+    }
     PROF_T0(pt);
     if (np > 0) {
         dlt_coop(S, s1, d1, np, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
 #ifdef MIS_TAIL_PROF
     if (t == 0) atomicMax(&g_tail_prof[7], wall_clock64() - pt);
 #endif
-    if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; }
+    if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; if (part == 4) st->tail_pending = 0; }
 }
 
 // ---------------------------------------------------------------- host side --------------------
@@ -1132,12 +1139,17 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     if (phases == 4)   // the tails a phases == 3 run left pending (fin == 0)
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
                            max_iters, confidence, thr, b->fin, 2, 0);
-    if ((phases == 1 || phases == 2) && max_iters > p0) {
+    if (phases >= 10) {   // 10 + 2 w: mask + compaction, 11 + 2 w: DLT + LM, of the problems a replay-only run left pending with fin == w
+        const int want = (phases - 10) >> 1, part = 3 + ((phases - 10) & 1);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin, part, want);
+    }
+    if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
-                           max_iters, max_iters, confidence, thr, b->fin, 0, 0);
+                           max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

@@ -393,7 +393,7 @@ struct PairOut {
     int pad;
 };
 
-__device__ __forceinline__ double det3(const double* H) {
+__host__ __device__ __forceinline__ double det3(const double* H) {
     return H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
 }
 
@@ -415,13 +415,15 @@ __global__ void first_calls_kernel(const PairDesc* pairs, int np, const int* n_m
 // `want` selects the problems whose first estimation finished in that RANSAC phase (fin1[k]); the others get an
 // inactive call and their PairOut entry is left alone (the launch for the other phase owns it)
 __global__ void second_calls_kernel(int np, const HomoCall* calls1, const HomoResult* res1, const float* scr1, const int* fin1, int want, int thresh2,
-                                    HomoCall* calls2, PairOut* outs) {
+                                    HomoCall* calls2, PairOut* outs, int check_det) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= np) return;
     const HomoCall c1 = calls1[k];
     HomoCall c;
     c.src = nullptr; c.dst = nullptr; c.mask = nullptr; c.pt_off = c1.pt_off; c.n = 0; c.active = 0;
-    if (fin1[k] == want && c1.active && res1[k].ok && !(fabs(det3(res1[k].H)) < DBL_EPSILON)) {
+    // check_det == 0: the refined first H is still being computed on another stream; the host applies the reference's
+    // |det H| >= eps test when it assembles the results and drops a second estimation that was run in vain
+    if (fin1[k] == want && c1.active && res1[k].ok && (!check_det || !(fabs(det3(res1[k].H)) < DBL_EPSILON))) {
         outs[k].passed = 1;
         const int ninl = res1[k].ninl;
         if (ninl >= thresh2) {
@@ -461,8 +463,8 @@ struct MatchWorkspace : MisWorkspace {
     // b1: first estimation of every pair; b2 / b3: the inlier-only estimation of the pairs whose first one finished in
     // RANSAC phase 0 / phase 1.  b2 runs on `side` concurrently with phase 1 of b1 (the chains are latency bound).
     HomoBatch b1, b2, b3;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr;
+    hipStream_t side = nullptr, third = nullptr;
+    hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr, ev_phase1 = nullptr, ev_third_done = nullptr;
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
     std::atomic<long long> seq{0}, knn_seq{0};
@@ -471,6 +473,9 @@ struct MatchWorkspace : MisWorkspace {
         dev.release(); pinned.release(); l2.release();
         homo_batch_release(&b1); homo_batch_release(&b2); homo_batch_release(&b3);
         if (side) hipStreamDestroy(side);
+        if (third) hipStreamDestroy(third);
+        if (ev_phase1) hipEventDestroy(ev_phase1);
+        if (ev_third_done) hipEventDestroy(ev_third_done);
         if (ev_phase0) hipEventDestroy(ev_phase0);
         if (ev_side_done) hipEventDestroy(ev_side_done);
         if (ev_knn) hipEventDestroy(ev_knn);
@@ -598,25 +603,63 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
                        (const float*)d_dst, d_mask, p->num_matches_thresh1, ws->b1.calls, d_out);
     if (!ws->side) {
-        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));   // default priority (an urgent one measured no gain)
+        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));   // default priority
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase0, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }
+    const double rt = p->ransac_thresh, cf = p->confidence;
+    static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 2;
+    if (chains != 3) {
     // first estimation, phase 0 up to the replay's verdict (pairs with a clear overlap finish here)
-    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 3, st)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
     // side stream: the tails of those pairs (mask, DLT on the inliers, LM: ~2 ms of latency) and their inlier-only estimation ...
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
-    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 4, ws->side)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 4, ws->side)) != MIS_OK) return rc;
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
-                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out);
-    if ((rc = homo_batch_run(ctx, &ws->b2, p->ransac_thresh, p->max_iters, p->confidence, 2, ws->side)) != MIS_OK) return rc;
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out, 1);
+    if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
     // ... while the main stream finishes the first estimation of the others (which only needs the verdict) and runs their second one
-    if ((rc = homo_batch_run(ctx, &ws->b1, p->ransac_thresh, p->max_iters, p->confidence, 1, st)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 1, st)) != MIS_OK) return rc;
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
-                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out);
-    if ((rc = homo_batch_run(ctx, &ws->b3, p->ransac_thresh, p->max_iters, p->confidence, 2, st)) != MIS_OK) return rc;
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 1);
+    if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, st)) != MIS_OK) return rc;
+    } else {
+    // MIS_MATCH_CHAINS=3 (opt-in: 0.4 ms faster per 16 x 4K step when every stream has a hardware queue of its own, 2 ms slower when
+    // two of them share one -- the mapping is the runtime's): findHomography returns the RANSAC mask, not one recomputed after
+    // its refinement, so the second estimation starts from the mask while the DLT + LM refinement of the first H runs on a
+    // third stream; the |det H| test of the reference moves to the host assembly below.
+    if (!ws->third) {
+        // its own priority class, i.e. its own hardware queue: at the default priority this stream came to share a queue with
+        // the job's compose stream and the 2 ms refinement kernels stalled the composition (step 13.5 -> 16.6 ms)
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        MIS_HIP(ctx, hipStreamCreateWithPriority(&ws->third, hipStreamNonBlocking, greatest));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase1, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_third_done, hipEventDisableTiming));
+    }
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 10, st)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
+    MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
+    hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out, 0);
+    if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
+    MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase0, 0));
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 11, ws->third)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st)) != MIS_OK) return rc;
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_phase1, st));
+    hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 0);
+    if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, st)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase1, 0));
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 13, ws->third)) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_third_done, ws->third));
+    MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_third_done, 0));
+    }
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_side_done, 0));
     MIS_HIP(ctx, hipGetLastError());
     int* nm = (int*)(Hh + h_nm);
@@ -656,12 +699,17 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             a->inliers_mask = (uint8_t*)malloc((size_t)nm[k] + 1);
             memcpy(a->inliers_mask, hmask + pd.m_off, (size_t)nm[k]);
         }
+        // matchers.cpp: "if (H.empty() || |det H| < eps) return" after the first estimation.  The two-chain flow tests it on
+        // the device before the second estimation; the three-chain flow runs that estimation without waiting for the
+        // refined H, and a degenerate first H drops it here (same expression, same rounding: no FMA contraction)
+        const bool det_ok = !(fabs(det3(r1[k].H)) < DBL_EPSILON);
+        const bool passed = po[k].passed && det_ok, second = po[k].second && det_ok;
         // H of the inlier-only estimation when it ran (it may come back empty), else of the first one
-        const HomoResult& hr = po[k].second ? (fin[k] == 0 ? r2[k] : r3[k]) : r1[k];
+        const HomoResult& hr = second ? (fin[k] == 0 ? r2[k] : r3[k]) : r1[k];
         a->has_H = po[k].ran_ransac ? hr.ok : 0;
         if (a->has_H) memcpy(a->H, hr.H, sizeof(a->H));
-        a->num_inliers = po[k].passed ? r1[k].ninl : 0;
-        if (po[k].passed) {
+        a->num_inliers = passed ? r1[k].ninl : 0;
+        if (passed) {
             // Brown & Lowe confidence; > 3 means near-duplicate images and is zeroed (matchers.cpp)
             double c = a->num_inliers / (8 + 0.3 * nm[k]);
             a->confidence = c > 3. ? 0. : c;

@@ -221,3 +221,45 @@ def test_find_homography_tiny_problems_incl_infeasible(ctx, oracle_mod, n):
     assert np.array_equal(m_g, m_o)
     if ok_g:
         assert np.array_equal(_bits(H_g), _bits(H_o))
+
+
+_CHAINS3_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import synth, image_stitching_amd as isa
+ctx = isa.Context(0)
+cams = synth.workload("config3")[4:10]
+frames = [synth.render_frame_gpu(c) for c in cams]
+feats = isa.OrbFeatureFinder(ctx, (3840, 2160)).detect_batch(frames)
+pm = isa.BestOf2NearestMatcher(ctx, 0.32)(feats)
+out = {}
+for k, m in enumerate(pm):
+    out["c%d" % k] = np.float64(m.confidence); out["n%d" % k] = np.int64(m.num_inliers)
+    out["H%d" % k] = np.asarray(m.H, np.float64) if m.H is not None else np.zeros(0)
+    out["m%d" % k] = np.asarray(m.inliers_mask, np.uint8) if m.inliers_mask is not None else np.zeros(0, np.uint8)
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_three_chain_matcher_flow_gives_identical_results(tmp_path):
+    """MIS_MATCH_CHAINS=3 (second estimation from the RANSAC mask while the first H is still being refined, the |det H| test
+    on the host) against the default flow: six 4K frames, every pair's confidence, inlier count, mask and H bit for bit.
+    The switch is read once per process, hence two child processes (one after the other)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for chains in ("2", "3"):
+        path = str(tmp_path / ("chains%s.npz" % chains))
+        env = dict(os.environ, MIS_MATCH_CHAINS=chains)
+        r = subprocess.run([sys.executable, "-c", _CHAINS3_SCRIPT, root, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(path))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 4 * 36
+    ran = 0
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+        ran += k.startswith("n") and int(a[k]) > 0
+    assert ran >= 10      # adjacent frames do have inliers: the second estimation was exercised
