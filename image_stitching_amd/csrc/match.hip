@@ -608,7 +608,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }
     const double rt = p->ransac_thresh, cf = p->confidence;
-    static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 2;
+    static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 3;   // 2: the two-chain flow below
     if (chains != 3) {
     // first estimation, phase 0 up to the replay's verdict (pairs with a clear overlap finish here)
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
@@ -626,8 +626,8 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 1);
     if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, st)) != MIS_OK) return rc;
     } else {
-    // MIS_MATCH_CHAINS=3 (opt-in: 0.4 ms faster per 16 x 4K step when every stream has a hardware queue of its own, 2 ms slower when
-    // two of them share one -- the mapping is the runtime's): findHomography returns the RANSAC mask, not one recomputed after
+    // Three chains (the default; MIS_MATCH_CHAINS=2 selects the flow above).  0.45 ms faster per 16 x 4K step -- provided the third
+    // stream does not share a hardware queue with the job's compose stream, hence its own priority class: findHomography returns the RANSAC mask, not one recomputed after
     // its refinement, so the second estimation starts from the mask while the DLT + LM refinement of the first H runs on a
     // third stream; the |det H| test of the reference moves to the host assembly below.
     if (!ws->third) {

@@ -934,7 +934,14 @@ extern "C" int mis_orb_destroy(MisOrb* o) {
 }
 
 namespace {
-constexpr int ORB_HELPERS = 3;   // + the finder itself: 4 frames in flight (8 measured: no gain)
+// helper finders next to the finder itself: 3 frames in flight.  The feature stage is bound by device throughput, not by
+// latency, and streams beyond the runtime's hardware queues (4 by default) share them: with 3 helpers the 16 x 4K stage
+// took 3.9 ms, with 2 it takes 3.3 ms (and the job's compose / matcher streams keep a queue each); 4 or 5 helpers cost
+// the whole step 3-4 ms through queue sharing
+#ifndef ORB_HELPERS_N
+#define ORB_HELPERS_N 2
+#endif
+constexpr int ORB_HELPERS = ORB_HELPERS_N;
 
 int ensure_helpers(MisOrb* o) {
     if (!o->helpers.empty() || o->is_helper) return MIS_OK;
