@@ -757,7 +757,7 @@ extern "C" int mis_match_knn_fence(MisContext* ctx, void* stream, long long targ
         if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return MIS_OK;
         std::this_thread::yield();
     }
-    if (ws->ev_knn && hipStreamWaitEvent((hipStream_t)stream, ws->ev_knn, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");
+    if (stream && ws->ev_knn && hipStreamWaitEvent((hipStream_t)stream, ws->ev_knn, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");
     return MIS_OK;
 }
 

@@ -195,7 +195,8 @@ class HipEngine:
         """Queue the compose stream behind the 2-NN pass of matcher call `target_seq` (made by another thread): that
         pass fills the device, the RANSAC chains after it do not -- composing from there on costs the matcher nothing
         (measured: 0.5 ms per 16 x 4K step against starting at once)."""
-        self.ctx.check(self.ctx.lib.mis_match_knn_fence(self.ctx.h, self._compose_stream_handle, target_seq, 50))
+        import os
+        self.ctx.check(self.ctx.lib.mis_match_knn_fence(self.ctx.h, None if os.environ.get('MIS_COMPOSE_GPU_FENCE') == '0' else self._compose_stream_handle, target_seq, 50))
 
     def warp_feed_many(self, frames, cams, rois):
         """warp_feed for a list of frames in one library call (no interpreter work between the launches: the thread that
