@@ -67,78 +67,34 @@ __device__ __forceinline__ float view_w(const FrameView& v, int tx, int ty) {
     return (float)v.mask[(size_t)y * v.mstride + x] * (float)(1. / 255.);
 }
 
-// ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101, s16: (v + 128) >> 8 ----
-// A block produces a 32 x 16 destination tile: the 67 x 35 source footprint is staged in LDS once (the
-// reflect index maps of the padded view are evaluated once per source pixel instead of 25 times per
-// output), then the separable 5-tap filter runs out of LDS (integer, so the pass order is free).
+// ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101 ----
+// s16: integer, (v + 128) >> 8, the pass order is free.  f32: row = s[2x]*6 + (s[2x-1]+s[2x+1])*4 + s[2x-2] + s[2x+2], the
+// same vertically, * 1/256 -- in that order.  A block produces a 32 x 16 destination tile: the 67 x 35 source footprint is
+// staged in LDS once (the reflect index maps are evaluated once per source pixel instead of 25 times per output), then the
+// separable filter runs out of LDS.
 constexpr int PD_W = 32, PD_H = 16, PD_SW = 2 * PD_W + 3, PD_SH = 2 * PD_H + 3;
-template <bool FROM_VIEW>
-__global__ __launch_bounds__(256) void pyr_down_s16x3_kernel(FrameView v, const int16_t* src, int sw, int sh, int16_t* dst, int dw, int dh) {
-    __shared__ int16_t tile[PD_SH * PD_SW * 3];
-    __shared__ int hbuf[PD_SH * PD_W * 3];
-    const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
-    for (int i = t; i < PD_SH * PD_SW; i += 256) {
-        const int r = i / PD_SW, c = i - r * PD_SW;
-        const int sy = mis_reflect101(2 * y0 - 2 + r, sh), sx = mis_reflect101(2 * x0 - 2 + c, sw);
-        int px[3];
-        if (FROM_VIEW) view_px(v, sx, sy, px);
-        else { const int16_t* p = src + ((size_t)sy * sw + sx) * 3; px[0] = p[0]; px[1] = p[1]; px[2] = p[2]; }
-        tile[3 * i] = (int16_t)px[0]; tile[3 * i + 1] = (int16_t)px[1]; tile[3 * i + 2] = (int16_t)px[2];
-    }
-    __syncthreads();
-    for (int i = t; i < PD_SH * PD_W * 3; i += 256) {
-        const int r = i / (PD_W * 3), rem = i - r * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
-        const int16_t* p = tile + (r * PD_SW + 2 * x) * 3 + ch;
-        hbuf[i] = p[6] * 6 + (p[3] + p[9]) * 4 + p[0] + p[12];
-    }
-    __syncthreads();
-    for (int i = t; i < PD_H * PD_W * 3; i += 256) {
-        const int y = i / (PD_W * 3), rem = i - y * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
-        if (x0 + x >= dw || y0 + y >= dh) continue;
-        const int* p = hbuf + (2 * y) * (PD_W * 3) + rem;
-        const int acc = p[2 * PD_W * 3] * 6 + (p[PD_W * 3] + p[3 * PD_W * 3]) * 4 + p[0] + p[4 * PD_W * 3];
-        dst[((size_t)(y0 + y) * dw + x0 + x) * 3 + ch] = (int16_t)((acc + 128) >> 8);
-    }
-}
 
-// ---- pyrDown f32: row = s[2x]*6 + (s[2x-1]+s[2x+1])*4 + s[2x-2] + s[2x+2]; same vertically; * 1/256 ----
-template <bool FROM_VIEW>
-__global__ __launch_bounds__(256) void pyr_down_f32_kernel(FrameView v, const float* src, int sw, int sh, float* dst, int dw, int dh) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    int xi[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) xi[i] = mis_reflect101(2 * x - 2 + i, sw);
-    float hr[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        int sy = mis_reflect101(2 * y - 2 + j, sh);
-        float s[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) s[i] = FROM_VIEW ? view_w(v, xi[i], sy) : src[(size_t)sy * sw + xi[i]];
-        hr[j] = ((s[2] * 6.f + (s[1] + s[3]) * 4.f) + s[0]) + s[4];
-    }
-    float r = ((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4];
-    dst[(size_t)y * dw + x] = r * (1.f / 256.f);
-}
-
-// ---- level 0 of a feed: both reductions of the padded frame view in one kernel (same 67 x 35 footprint) ----
+// ---- one level of a feed: both reductions in one kernel (same 67 x 35 footprint) ----
 // Gaussian level 1 of the image (s16x3) and of the weights (mask / 255, f32) from one staging of the tile.  Tiles whose
 // footprint lies inside the frame (no reflection at all: the bulk of a 4K frame) stage their rows with aligned dword
 // loads (a row is 402 contiguous bytes of 16SC3) instead of three 2-byte loads per pixel, and their weights with dword
-// loads of the mask; the arithmetic of both passes is that of pyr_down_s16x3_kernel / pyr_down_f32_kernel.
+// loads of the mask.
 constexpr int PDV_ROW_DW = (PD_SW * 6 + 2 + 3) / 4 + 1;   // dwords that cover a row of 67 pixels from an address rounded down to 4
 constexpr int PDV_MROW_DW = (PD_SW + 3 + 3) / 4 + 1;      // same for the 67 mask bytes
-__global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh) {
+// FROM_VIEW = false: the same pair of reductions for a level >= 1 (sources: the frame's Gaussian level `src` and weight level
+// `wsrc`, sw x sh, tightly packed), one launch instead of two per level.
+template <bool FROM_VIEW>
+__global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const int16_t* __restrict__ src, const float* __restrict__ wsrc, int psw, int psh,
+                                                            int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh) {
     __shared__ __attribute__((aligned(4))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
     __shared__ float wt[PD_SH * PD_SW];
     __shared__ int hbuf[PD_SH * PD_W * 3];
     __shared__ float hw[PD_SH * PD_W];
     const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
-    const int sw = v.tw, sh = v.th;
+    const int sw = FROM_VIEW ? v.tw : psw, sh = FROM_VIEW ? v.th : psh;
     const int tx0 = 2 * x0 - 2, ty0 = 2 * y0 - 2;                    // tile coordinates of the footprint's corner
     const int ix0 = tx0 - v.left, iy0 = ty0 - v.top;                 // image coordinates of the same
-    const bool interior = tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW <= sw && ty0 + PD_SH <= sh && ix0 >= 0 && iy0 >= 0 && ix0 + PD_SW + 12 <= v.w && iy0 + PD_SH <= v.h &&   /* + 12: the dword loads may run past the last needed byte */
+    const bool interior = FROM_VIEW && tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW <= sw && ty0 + PD_SH <= sh && ix0 >= 0 && iy0 >= 0 && ix0 + PD_SW + 12 <= v.w && iy0 + PD_SH <= v.h &&   /* + 12: the dword loads may run past the last needed byte */
                           (v.istride & 1) == 0 && ((uintptr_t)v.img & 3) == 0 && (v.mstride & 3) == 0 && ((uintptr_t)v.mask & 3) == 0;
     int toff;   // shorts between the start of an LDS row and its first pixel
     if (interior) {
@@ -182,10 +138,11 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, int16_t
             const int r = i / PD_SW, c = i - r * PD_SW;
             const int sy = mis_reflect101(ty0 + r, sh), sx = mis_reflect101(tx0 + c, sw);
             int px[3];
-            view_px(v, sx, sy, px);
+            if (FROM_VIEW) view_px(v, sx, sy, px);
+            else { const int16_t* q = src + ((size_t)sy * sw + sx) * 3; px[0] = q[0]; px[1] = q[1]; px[2] = q[2]; }
             int16_t* o = tile + (size_t)r * (PDV_ROW_DW * 2) + 3 * c;
             o[0] = (int16_t)px[0]; o[1] = (int16_t)px[1]; o[2] = (int16_t)px[2];
-            wt[i] = view_w(v, sx, sy);
+            wt[i] = FROM_VIEW ? view_w(v, sx, sy) : wsrc[(size_t)sy * sw + sx];
         }
     }
     __syncthreads();
@@ -498,13 +455,12 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
     if (first >= nb) first = nb + 1;     // a single level is not worth it
     for (int i = 0; i < nb; i++) {
         if (i >= first) break;           // G(first + 1 ..) are built by feed_tail_build_kernel
-        dim3 g = grid2d(tw[i + 1], th[i + 1]);
         dim3 gp((tw[i + 1] + PD_W - 1) / PD_W, (th[i + 1] + PD_H - 1) / PD_H);
         if (i == 0) {
-            hipLaunchKernelGGL(pyr_down_view_kernel, gp, blk, 0, ctx->stream, v, G(1), W(1), tw[1], th[1]);
+            hipLaunchKernelGGL((pyr_down_view_kernel<true>), gp, blk, 0, ctx->stream, v, nullptr, nullptr, 0, 0, G(1), W(1), tw[1], th[1]);
         } else {
-            hipLaunchKernelGGL((pyr_down_s16x3_kernel<false>), gp, blk, 0, ctx->stream, v, G(i), tw[i], th[i], G(i + 1), tw[i + 1], th[i + 1]);
-            hipLaunchKernelGGL((pyr_down_f32_kernel<false>), g, blk, 0, ctx->stream, v, W(i), tw[i], th[i], W(i + 1), tw[i + 1], th[i + 1]);
+            hipLaunchKernelGGL((pyr_down_view_kernel<false>), gp, blk, 0, ctx->stream, v, (const int16_t*)G(i), (const float*)W(i), tw[i], th[i], G(i + 1), W(i + 1),
+                               tw[i + 1], th[i + 1]);
         }
     }
     int y_tl = tny - R.y, x_tl = tnx - R.x, y_br = bny - R.y, x_br = bnx - R.x;
