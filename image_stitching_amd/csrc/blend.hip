@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void laplace_accumulate_kernel(FrameView v, co
 // the data goes through global memory, which a workgroup sees coherently), feed_tail_accumulate_kernel adds the
 // Laplacians of all those levels to the panorama in one grid.  Arithmetic: that of the per-level kernels.
 struct FeedTail {
-    int first, nb;                                    // levels first .. nb are handled here (first >= 1)
+    int first, nb;                                    // levels first + 1 .. nb are built by feed_tail_build_kernel (first >= 1; first > nb: none)
+    int acc_first;                                    // levels acc_first .. nb are accumulated by feed_tail_accumulate_kernel
     int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1]; // tile size per level
     int16_t* G[MIS_MAX_BANDS + 1];                    // Gaussian levels of the frame (scratch), G[first] already built
     float* W[MIS_MAX_BANDS + 1];
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedTail t) {
     }
 }
 __global__ __launch_bounds__(256) void feed_tail_accumulate_kernel(FeedTail t) {
-    int l = t.first;
+    int l = t.acc_first;
     while (l < t.nb && (int)blockIdx.x >= t.blk_off[l + 1]) l++;
     const int tw = t.tw[l], th = t.th[l];
     const int i = ((int)blockIdx.x - t.blk_off[l]) * 256 + threadIdx.x;
@@ -464,38 +465,31 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
         }
     }
     int y_tl = tny - R.y, x_tl = tnx - R.x, y_br = bny - R.y, x_br = bnx - R.x;
+    // level 0 reads the frame view; every other level goes through one multi-level grid (feed_tail_accumulate_kernel)
     FeedTail ft;
-    ft.first = first; ft.nb = nb;
+    ft.first = first; ft.nb = nb; ft.acc_first = 1;
     for (int i = 0; i <= nb; i++) {
-        if (i >= first) {
+        if (i >= 1) {
             ft.tw[i] = tw[i]; ft.th[i] = th[i]; ft.G[i] = G(i); ft.W[i] = W(i); ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
             ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
             x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
             continue;
         }
-        int rw = x_br - x_tl, rh = y_br - y_tl;  // equals tw[i] x th[i] (tile corners are multiples of 2^nb)
-        dim3 g = grid2d(rw, rh);
-        const int16_t* coarse = i < nb ? G(i + 1) : nullptr;
-        int cw = i < nb ? tw[i + 1] : 0, ch = i < nb ? th[i + 1] : 0;
-        if (i == 0 && nb > 0)
-            hipLaunchKernelGGL((laplace_accumulate_kernel<true, false>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, coarse, cw, ch,
+        const int rw = x_br - x_tl, rh = y_br - y_tl;  // equals tw[0] x th[0] (tile corners are multiples of 2^nb)
+        const dim3 g = grid2d(rw, rh);
+        if (nb > 0)
+            hipLaunchKernelGGL((laplace_accumulate_kernel<true, false>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, (const int16_t*)G(1), tw[1], th[1],
                                b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
-        else if (i == 0)
-            hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, coarse, cw, ch,
-                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
-        else if (i < nb)
-            hipLaunchKernelGGL((laplace_accumulate_kernel<false, false>), g, blk, 0, ctx->stream, v, G(i), W(i), rw, rh, coarse, cw, ch,
-                               b->lap[i], b->wgt[i], b->lw[i], x_tl, y_tl);
         else
-            hipLaunchKernelGGL((laplace_accumulate_kernel<false, true>), g, blk, 0, ctx->stream, v, G(i), W(i), rw, rh, coarse, cw, ch,
-                               b->lap[i], b->wgt[i], b->lw[i], x_tl, y_tl);
+            hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, (const int16_t*)nullptr, 0, 0,
+                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
         x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
     }
-    if (first <= nb) {
+    if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(1), dim3(1024), 0, ctx->stream, ft);
+    if (nb >= 1) {
         int nblk = 0;
-        for (int i = first; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += (ft.tw[i] * ft.th[i] + 255) / 256; }
+        for (int i = 1; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += (ft.tw[i] * ft.th[i] + 255) / 256; }
         ft.blk_off[nb + 1] = nblk;
-        hipLaunchKernelGGL(feed_tail_build_kernel, dim3(1), dim3(1024), 0, ctx->stream, ft);
         hipLaunchKernelGGL(feed_tail_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft);
     }
     MIS_HIP(ctx, hipGetLastError());
