@@ -227,6 +227,52 @@ __global__ __launch_bounds__(256) void laplace_accumulate_kernel(FrameView v, co
     dwgt[o] += w;
 }
 
+// Level 0 of a feed with at least one band: a thread owns a 2 x 2 block of the frame's tile (its size is a multiple of 2^bands).
+// The four pixels share the 3 x 3 coarse neighbourhood of pyrUp, so the block costs 27 coarse loads instead of up to 27 per
+// pixel; the arithmetic per pixel is that of laplace_accumulate_kernel / pyr_up_at (integers, the same sums).
+__global__ __launch_bounds__(256) void laplace_accumulate_view2x2_kernel(FrameView v, int tw, int th, const int16_t* __restrict__ coarse, int cw, int ch,
+                                                                         int16_t* __restrict__ dlap, float* __restrict__ dwgt, int pw, int x_tl, int y_tl) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);   // block index = coarse pixel
+    if (2 * X >= tw || 2 * Y >= th) return;
+    float w[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { w[k] = view_w(v, 2 * X + (k & 1), 2 * Y + (k >> 1)); any |= w[k] != 0.f; }
+    if (!any) return;   // exact no-op contributions
+    const int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
+    const int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
+    const int rows[3] = {ym, Y, yp};
+    int he[3][3], ho[3][3];   // [row][channel]: horizontal sums for an even / odd fine column
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int16_t* p = coarse + (size_t)rows[r] * cw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int a = p[3 * xm + c], b = p[3 * X + c], d = p[3 * xp + c];
+            he[r][c] = a + b * 6 + d;
+            ho[r][c] = (b + d) * 4;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (w[k] == 0.f) continue;
+        const int fx = 2 * X + (k & 1), fy = 2 * Y + (k >> 1);
+        int px[3];
+        view_px(v, fx, fy, px);
+        const size_t o = (size_t)(y_tl + fy) * pw + (x_tl + fx);
+        int16_t* d = dlap + o * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int h0 = (k & 1) ? ho[0][c] : he[0][c], h1 = (k & 1) ? ho[1][c] : he[1][c], h2 = (k & 1) ? ho[2][c] : he[2][c];
+            const int vv = (k >> 1) ? (h1 + h2) * 4 : (h0 + h1 * 6 + h2);
+            const int up = (int16_t)((vv + 32) >> 6);
+            const int lap = sat_s16(px[c] - up);
+            d[c] = (int16_t)(d[c] + (int16_t)((float)lap * w[k]));
+        }
+        dwgt[o] += w[k];
+    }
+}
+
 // ---- the small levels of a feed in two launches ----
 // From some level on a frame's pyramid has a few thousand pixels and every per-level launch costs more in launch-to-launch
 // latency than in work (a 4K frame at 8 bands: 15 launches of ~6 us for levels 4..8).  feed_tail_build_kernel builds all
@@ -478,7 +524,7 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
         const int rw = x_br - x_tl, rh = y_br - y_tl;  // equals tw[0] x th[0] (tile corners are multiples of 2^nb)
         const dim3 g = grid2d(rw, rh);
         if (nb > 0)
-            hipLaunchKernelGGL((laplace_accumulate_kernel<true, false>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, (const int16_t*)G(1), tw[1], th[1],
+            hipLaunchKernelGGL(laplace_accumulate_view2x2_kernel, grid2d((rw + 1) / 2, (rh + 1) / 2), blk, 0, ctx->stream, v, rw, rh, (const int16_t*)G(1), tw[1], th[1],
                                b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
         else
             hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, (const int16_t*)nullptr, 0, 0,
