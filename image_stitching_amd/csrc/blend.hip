@@ -201,6 +201,32 @@ __device__ __forceinline__ void pyr_up_at(const int16_t* c, int cw, int ch, int 
     }
 }
 
+// pyrUp of a coarse level at the 2 x 2 fine block of coarse pixel (X, Y): up[k][c], k = (fy & 1) * 2 + (fx & 1).  The four pixels share
+// the 3 x 3 coarse neighbourhood (27 loads per block instead of up to 27 per pixel); per pixel the sums are those of pyr_up_at.
+__device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int cw, int ch, int X, int Y, int (*up)[3]) {
+    const int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
+    const int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
+    const int rows[3] = {ym, Y, yp};
+    int he[3][3], ho[3][3];   // [row][channel]: horizontal sums for an even / odd fine column
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int16_t* p = c + (size_t)rows[r] * cw * 3;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int a = p[3 * xm + q], b = p[3 * X + q], d = p[3 * xp + q];
+            he[r][q] = a + b * 6 + d;
+            ho[r][q] = (b + d) * 4;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        up[0][q] = (int16_t)((he[0][q] + he[1][q] * 6 + he[2][q] + 32) >> 6);
+        up[1][q] = (int16_t)((ho[0][q] + ho[1][q] * 6 + ho[2][q] + 32) >> 6);
+        up[2][q] = (int16_t)(((he[1][q] + he[2][q]) * 4 + 32) >> 6);
+        up[3][q] = (int16_t)(((ho[1][q] + ho[2][q]) * 4 + 32) >> 6);
+    }
+}
+
 // ---- one pyramid level of a feed: Laplacian = G_i - pyrUp(G_{i+1}) (saturating), then
 // dst += (short)(lap * w), wsum += w over the tile rectangle of the panorama level ----
 template <bool FROM_VIEW, bool LAST>
@@ -239,20 +265,8 @@ __global__ __launch_bounds__(256) void laplace_accumulate_view2x2_kernel(FrameVi
 #pragma unroll
     for (int k = 0; k < 4; k++) { w[k] = view_w(v, 2 * X + (k & 1), 2 * Y + (k >> 1)); any |= w[k] != 0.f; }
     if (!any) return;   // exact no-op contributions
-    const int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
-    const int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
-    const int rows[3] = {ym, Y, yp};
-    int he[3][3], ho[3][3];   // [row][channel]: horizontal sums for an even / odd fine column
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int16_t* p = coarse + (size_t)rows[r] * cw * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int a = p[3 * xm + c], b = p[3 * X + c], d = p[3 * xp + c];
-            he[r][c] = a + b * 6 + d;
-            ho[r][c] = (b + d) * 4;
-        }
-    }
+    int up[4][3];
+    pyr_up_block(coarse, cw, ch, X, Y, up);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (w[k] == 0.f) continue;
@@ -263,10 +277,7 @@ __global__ __launch_bounds__(256) void laplace_accumulate_view2x2_kernel(FrameVi
         int16_t* d = dlap + o * 3;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int h0 = (k & 1) ? ho[0][c] : he[0][c], h1 = (k & 1) ? ho[1][c] : he[1][c], h2 = (k & 1) ? ho[2][c] : he[2][c];
-            const int vv = (k >> 1) ? (h1 + h2) * 4 : (h0 + h1 * 6 + h2);
-            const int up = (int16_t)((vv + 32) >> 6);
-            const int lap = sat_s16(px[c] - up);
+            const int lap = sat_s16(px[c] - up[k][c]);
             d[c] = (int16_t)(d[c] + (int16_t)((float)lap * w[k]));
         }
         dwgt[o] += w[k];
@@ -324,22 +335,44 @@ __global__ __launch_bounds__(256) void feed_tail_accumulate_kernel(FeedTail t) {
     while (l < t.nb && (int)blockIdx.x >= t.blk_off[l + 1]) l++;
     const int tw = t.tw[l], th = t.th[l];
     const int i = ((int)blockIdx.x - t.blk_off[l]) * 256 + threadIdx.x;
+    if (l < t.nb) {
+        // a thread owns a 2 x 2 block (tile sizes below the last level are even): the four pixels share pyrUp's neighbourhood
+        const int cw = t.tw[l + 1], ch = t.th[l + 1];
+        if (i >= cw * ch) return;
+        const int Y = i / cw, X = i - Y * cw;
+        float w[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { w[k] = t.W[l][(size_t)(2 * Y + (k >> 1)) * tw + 2 * X + (k & 1)]; any |= w[k] != 0.f; }
+        if (!any) return;   // exact no-op contributions
+        int up[4][3];
+        pyr_up_block(t.G[l + 1], cw, ch, X, Y, up);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (w[k] == 0.f) continue;
+            const int fx = 2 * X + (k & 1), fy = 2 * Y + (k >> 1);
+            const int16_t* p = t.G[l] + ((size_t)fy * tw + fx) * 3;
+            const size_t o = (size_t)(t.y_tl[l] + fy) * t.pw[l] + (t.x_tl[l] + fx);
+            int16_t* d = t.lap[l] + o * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int lap = sat_s16(p[c] - up[k][c]);
+                d[c] = (int16_t)(d[c] + (int16_t)((float)lap * w[k]));
+            }
+            t.wgt[l][o] += w[k];
+        }
+        return;
+    }
     if (i >= tw * th) return;
     const int y = i / tw, x = i - y * tw;
     const float w = t.W[l][i];
     if (w == 0.f) return;  // exact no-op contribution
     const int16_t* p = t.G[l] + (size_t)i * 3;
-    int c[3] = {p[0], p[1], p[2]};
-    if (l < t.nb) {
-        int up[3];
-        pyr_up_at(t.G[l + 1], t.tw[l + 1], t.th[l + 1], x, y, up);
-        c[0] = sat_s16(c[0] - up[0]); c[1] = sat_s16(c[1] - up[1]); c[2] = sat_s16(c[2] - up[2]);
-    }
     const size_t o = (size_t)(t.y_tl[l] + y) * t.pw[l] + (t.x_tl[l] + x);
     int16_t* d = t.lap[l] + o * 3;
-    d[0] = (int16_t)(d[0] + (int16_t)((float)c[0] * w));
-    d[1] = (int16_t)(d[1] + (int16_t)((float)c[1] * w));
-    d[2] = (int16_t)(d[2] + (int16_t)((float)c[2] * w));
+    d[0] = (int16_t)(d[0] + (int16_t)((float)p[0] * w));
+    d[1] = (int16_t)(d[1] + (int16_t)((float)p[1] * w));
+    d[2] = (int16_t)(d[2] + (int16_t)((float)p[2] * w));
     t.wgt[l][o] += w;
 }
 
@@ -364,6 +397,24 @@ __global__ __launch_bounds__(256) void collapse_kernel(int16_t* fine, const floa
     d[0] = sat_s16(up[0] + (int)(int16_t)((float)d[0] / w));
     d[1] = sat_s16(up[1] + (int)(int16_t)((float)d[1] / w));
     d[2] = sat_s16(up[2] + (int)(int16_t)((float)d[2] / w));
+}
+
+// the same per 2 x 2 block of the fine level (fine = 2 x coarse exactly)
+__global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ fine, const float* __restrict__ fwgt, int fw, int fh, const int16_t* __restrict__ coarse,
+                                                          int cw, int ch) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= cw || Y >= ch) return;
+    int up[4][3];
+    pyr_up_block(coarse, cw, ch, X, Y, up);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t o = (size_t)(2 * Y + (k >> 1)) * fw + 2 * X + (k & 1);
+        const float w = fwgt[o] + WEIGHT_EPS;
+        int16_t* d = fine + o * 3;
+        d[0] = sat_s16(up[k][0] + (int)(int16_t)((float)d[0] / w));
+        d[1] = sat_s16(up[k][1] + (int)(int16_t)((float)d[1] / w));
+        d[2] = sat_s16(up[k][2] + (int)(int16_t)((float)d[2] / w));
+    }
 }
 
 // crop to the un-padded roi, dst_mask = wsum0 > eps (or the or-ed mask), zero outside the mask
@@ -534,7 +585,7 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
     if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(1), dim3(1024), 0, ctx->stream, ft);
     if (nb >= 1) {
         int nblk = 0;
-        for (int i = 1; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += (ft.tw[i] * ft.th[i] + 255) / 256; }
+        for (int i = 1; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
         ft.blk_off[nb + 1] = nblk;
         hipLaunchKernelGGL(feed_tail_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft);
     }
@@ -717,9 +768,14 @@ extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) 
         // every finer level: normalise fused with the collapse step
         size_t n = (size_t)b->lw[nb] * b->lh[nb];
         hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b->lap[nb], b->wgt[nb], n);
-        for (int i = nb; i > 0; i--)
-            hipLaunchKernelGGL(collapse_kernel, grid2d(b->lw[i - 1], b->lh[i - 1]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1],
-                               b->lw[i - 1], b->lh[i - 1], b->lap[i], b->lw[i], b->lh[i]);
+        for (int i = nb; i > 0; i--) {
+            if (b->lw[i - 1] == 2 * b->lw[i] && b->lh[i - 1] == 2 * b->lh[i])   // always, by the padding of prepare(); the per-pixel kernel is the general form
+                hipLaunchKernelGGL(collapse2x2_kernel, grid2d(b->lw[i], b->lh[i]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1], b->lw[i - 1], b->lh[i - 1],
+                                   (const int16_t*)b->lap[i], b->lw[i], b->lh[i]);
+            else
+                hipLaunchKernelGGL(collapse_kernel, grid2d(b->lw[i - 1], b->lh[i - 1]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1],
+                                   b->lw[i - 1], b->lh[i - 1], b->lap[i], b->lw[i], b->lh[i]);
+        }
     }
     hipLaunchKernelGGL(finalize_kernel, grid2d(b->fw, b->fh), dim3(256), 0, ctx->stream, b->lap[0], b->wgt[0], b->dst_mask, b->lw[0], b->fw,
                        b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride);
