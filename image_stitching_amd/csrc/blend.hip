@@ -146,30 +146,45 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
         }
     }
     __syncthreads();
-    for (int i = t; i < PD_SH * PD_W * 3; i += 256) {
-        const int r = i / (PD_W * 3), rem = i - r * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
-        const int16_t* p = tile + (size_t)r * (PDV_ROW_DW * 2) + toff + (2 * x) * 3 + ch;
-        hbuf[i] = p[6] * 6 + (p[3] + p[9]) * 4 + p[0] + p[12];
-    }
-    for (int i = t; i < PD_SH * PD_W; i += 256) {
-        const int r = i / PD_W, x = i - r * PD_W;
-        const float* s = wt + r * PD_SW + 2 * x;
-        hw[i] = ((s[2] * 6.f + (s[1] + s[3]) * 4.f) + s[0]) + s[4];
+    // horizontal pass: one (row, column) of the half-resolution grid per item, all three channels and the weight.  The five
+    // source pixels are 15 contiguous shorts of the LDS row: eight aligned dword reads, halves picked at compile time (toff,
+    // the only run-time part of the alignment, is uniform in the block).
+    static_assert(PD_W == 32, "item -> (row, column) uses shifts");
+    for (int item = t; item < PD_SH * PD_W; item += 256) {
+        const int r = item >> 5, x = item & 31;
+        const unsigned* q = reinterpret_cast<const unsigned*>(tile) + (size_t)r * PDV_ROW_DW + 3 * x;   // shorts 6 x .. 6 x + 15 of the row
+        unsigned wd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) wd[k] = q[k];
+        int px[15];
+        if (toff) {
+#pragma unroll
+            for (int k = 0; k < 15; k++) px[k] = (int)(int16_t)(wd[(k + 1) >> 1] >> (16 * ((k + 1) & 1)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 15; k++) px[k] = (int)(int16_t)(wd[k >> 1] >> (16 * (k & 1)));
+        }
+        int* hb = hbuf + item * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) hb[c] = px[6 + c] * 6 + (px[3 + c] + px[9 + c]) * 4 + px[c] + px[12 + c];
+        const float* sw_ = wt + r * PD_SW + 2 * x;
+        hw[item] = ((sw_[2] * 6.f + (sw_[1] + sw_[3]) * 4.f) + sw_[0]) + sw_[4];
     }
     __syncthreads();
-    for (int i = t; i < PD_H * PD_W * 3; i += 256) {
-        const int y = i / (PD_W * 3), rem = i - y * (PD_W * 3), x = rem / 3, ch = rem - 3 * x;
+    // vertical pass: one output pixel per item
+    for (int item = t; item < PD_H * PD_W; item += 256) {
+        const int y = item >> 5, x = item & 31;
         if (x0 + x >= dw || y0 + y >= dh) continue;
-        const int* p = hbuf + (2 * y) * (PD_W * 3) + rem;
-        const int acc = p[2 * PD_W * 3] * 6 + (p[PD_W * 3] + p[3 * PD_W * 3]) * 4 + p[0] + p[4 * PD_W * 3];
-        dst[((size_t)(y0 + y) * dw + x0 + x) * 3 + ch] = (int16_t)((acc + 128) >> 8);
-    }
-    for (int i = t; i < PD_H * PD_W; i += 256) {
-        const int y = i / PD_W, x = i - y * PD_W;
-        if (x0 + x >= dw || y0 + y >= dh) continue;
-        const float* p = hw + (2 * y) * PD_W + x;
-        const float r = ((p[2 * PD_W] * 6.f + (p[PD_W] + p[3 * PD_W]) * 4.f) + p[0]) + p[4 * PD_W];
-        wdst[(size_t)(y0 + y) * dw + x0 + x] = r * (1.f / 256.f);
+        const int* p = hbuf + (2 * y) * (PD_W * 3) + 3 * x;
+        int16_t* o = dst + ((size_t)(y0 + y) * dw + x0 + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int acc = p[2 * PD_W * 3 + c] * 6 + (p[PD_W * 3 + c] + p[3 * PD_W * 3 + c]) * 4 + p[c] + p[4 * PD_W * 3 + c];
+            o[c] = (int16_t)((acc + 128) >> 8);
+        }
+        const float* pw_ = hw + (2 * y) * PD_W + x;
+        const float rr = ((pw_[2 * PD_W] * 6.f + (pw_[PD_W] + pw_[3 * PD_W]) * 4.f) + pw_[0]) + pw_[4 * PD_W];
+        wdst[(size_t)(y0 + y) * dw + x0 + x] = rr * (1.f / 256.f);
     }
 }
 
