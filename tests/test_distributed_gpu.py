@@ -145,3 +145,21 @@ def test_speculative_compose_equals_sequential(ctx, stray):
     assert spec["pano_size"] == seq["pano_size"]
     assert torch.equal(spec["pano"], seq["pano"]) and torch.equal(spec["mask"], seq["mask"])
     assert torch.equal(spec["confidence"], seq["confidence"])
+
+
+def test_job_equals_the_per_call_stitcher(ctx):
+    """StitchJob (batched entries: mis_orb_detect_batch, mis_compose_frames, speculative composition + collapse on a
+    second stream) against Stitcher (one C call per reference call site, everything on one stream): same panorama,
+    mask, kept indices and pairwise confidences, bit for bit."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd.distributed import StitchJob
+    w, h = 640, 360
+    cams = [synth.make_camera(w, h, 60.0, 12.0 * i - 18.0, 0.5 * ((i % 3) - 1), 0.25 * ((i % 2) - 0.5)) for i in range(5)]
+    dev = [torch.from_numpy(synth.render_frame(c)).cuda() for c in cams]
+    job = StitchJob(ctx, (w, h), cams).run({i: f for i, f in enumerate(dev)})
+    pano, mask, feats, pm, idx = isa.Stitcher(ctx, (w, h), isa.StitchConfig(compose_megapix=-1)).stitch(dev, cams)
+    assert list(idx) == job["indices"] == [0, 1, 2, 3, 4]
+    assert np.array_equal(job["confidence"].cpu().numpy().reshape(-1), np.array([m.confidence for m in pm]))
+    assert torch.equal(job["pano"], pano) and torch.equal(job["mask"], mask)
