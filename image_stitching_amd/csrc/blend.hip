@@ -132,6 +132,35 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
                 }
             }
         }
+    } else if (!FROM_VIEW && tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW + 2 <= sw && ty0 + PD_SH <= sh && (sw & 1) == 0 && ((uintptr_t)src & 3) == 0) {
+        // a level >= 1, footprint inside it: rows are 3 sw shorts apart (sw even: every row starts on the same dword phase)
+        const size_t e0 = 3 * (size_t)tx0;
+        toff = (int)(e0 & 1);
+        const int16_t* base = src + (size_t)ty0 * sw * 3 + (e0 - toff);
+        const float* wbase = wsrc + (size_t)ty0 * sw + tx0;
+        constexpr int NI = (PD_SH * PDV_ROW_DW + 255) / 256, NW = (PD_SH * PD_SW + 255) / 256;
+        unsigned ri[NI];
+        float rw[NW];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = t + 256 * k, r = i / PDV_ROW_DW, c = i - r * PDV_ROW_DW;
+            ri[k] = i < PD_SH * PDV_ROW_DW ? *reinterpret_cast<const unsigned*>(base + (size_t)r * sw * 3 + 2 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const int i = t + 256 * k, r = i / PD_SW, c = i - r * PD_SW;
+            rw[k] = i < PD_SH * PD_SW ? wbase[(size_t)r * sw + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = t + 256 * k;
+            if (i < PD_SH * PDV_ROW_DW) reinterpret_cast<unsigned*>(tile)[i] = ri[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const int i = t + 256 * k;
+            if (i < PD_SH * PD_SW) wt[i] = rw[k];
+        }
     } else {
         toff = 0;
         for (int i = t; i < PD_SH * PD_SW; i += 256) {
