@@ -676,6 +676,15 @@ __global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* 
     desc[(size_t)i * 32 + b] = (uint8_t)val;
 }
 
+// the keypoint counts of a batch and the lanes' overflow flags, gathered into one host-visible (pinned, mapped) array:
+// one kernel instead of one small device-to-host copy per frame at the end of the feature stage
+constexpr int ORB_GATHER_MAX = 96;
+struct GatherPtrs { const int* p[ORB_GATHER_MAX]; };
+__global__ void gather_ints_kernel(GatherPtrs g, int n, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = *g.p[i];
+}
+
 }  // namespace
 
 struct MisOrb {
@@ -689,6 +698,7 @@ struct MisOrb {
     size_t pad_bytes = 0, map_bytes = 0;
     int cand_total = 0, fin_total = 0, tab_total = 0, surv_total = 0, out_cap = 0;
     std::vector<int> tab_host;
+    int* host_counts = nullptr;   // pinned, device-visible: gather_ints_kernel writes the batch's counts / flags here
     // Batches spread their frames over helper finders, each with its own workspace and its own non-blocking stream:
     // the per-frame chain has ~60 launches, most of them small and latency bound, and chains of different frames
     // overlap on the device.  Created on the first batch of more than one frame.
@@ -929,6 +939,7 @@ extern "C" int mis_orb_destroy(MisOrb* o) {
     for (hipEvent_t e : o->helper_done) hipEventDestroy(e);
     if (o->fork_event) hipEventDestroy(o->fork_event);
     if (o->mem) hipFree(o->mem);
+    if (o->host_counts) hipHostFree(o->host_counts);
     delete o;
     return MIS_OK;
 }
@@ -1014,11 +1025,18 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
     // one synchronisation for the whole batch: counts + overflow flags
     std::vector<int> counts(n);
     std::vector<int> lane_flags(lanes.size(), 0);
-    for (int i = 0; i < n; i++)
-        MIS_HIP(ctx, hipMemcpyAsync(&counts[i], feat_count(&out[i], o->out_cap), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    for (size_t k = 0; k < lanes.size(); k++)
-        MIS_HIP(ctx, hipMemcpyAsync(&lane_flags[k], lanes[k]->w.flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int nl = (int)lanes.size();
+    if (!o->host_counts) MIS_HIP(ctx, hipHostMalloc((void**)&o->host_counts, sizeof(int) * ORB_GATHER_MAX, hipHostMallocMapped));
+    for (int i0 = 0; i0 < n + nl; i0 += ORB_GATHER_MAX) {
+        const int m = std::min(ORB_GATHER_MAX, n + nl - i0);
+        GatherPtrs gp;
+        for (int k = 0; k < m; k++) gp.p[k] = i0 + k < n ? feat_count(&out[i0 + k], o->out_cap) : lanes[i0 + k - n]->w.flags;
+        int* dev_view = nullptr;
+        MIS_HIP(ctx, hipHostGetDevicePointer((void**)&dev_view, o->host_counts, 0));
+        hipLaunchKernelGGL(gather_ints_kernel, dim3(1), dim3(ORB_GATHER_MAX), 0, ctx->stream, gp, m, dev_view);
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < m; k++) (i0 + k < n ? counts[i0 + k] : lane_flags[i0 + k - n]) = o->host_counts[k];
+    }
     int flags = 0;
     for (size_t k = 0; k < lanes.size(); k++)
         if (lane_flags[k]) { flags |= lane_flags[k]; hipMemsetAsync(lanes[k]->w.flags, 0, sizeof(int), ctx->stream); }
