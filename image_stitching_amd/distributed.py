@@ -160,8 +160,9 @@ class HipEngine:
     def match(self, feats, rank, world):
         return self.matcher(feats, rank, world)
 
-    def confidence_tensor(self, pm, n):
-        return torch.from_numpy(pm.confidences()).to(self.ctx.device).view(n, n)
+    def confidence_tensor(self, pm, n, on_device=True):
+        t = torch.from_numpy(pm.confidences()).view(n, n)
+        return t.to(self.ctx.device) if on_device else t      # a single rank prunes on the host: no round trip through HBM
 
     def refine_cameras(self, feats, pm, indices, cams):
         return st.refine_cameras(self.ctx, feats, pm, indices, cams, self.cfg)
@@ -264,6 +265,8 @@ class StitchJob:
 
     def stage_match(self, feats):
         pm = self.engine.match(feats, self.rank, self.world)
+        if self.world == 1 and not self.force_collectives and isinstance(self.engine, HipEngine):
+            return pm, self.engine.confidence_tensor(pm, self.n, on_device=False)
         conf = self.engine.confidence_tensor(pm, self.n)
         conf = self.comm.all_reduce_sum(conf)          # every pair is owned by exactly one rank
         return pm, conf

@@ -17,7 +17,7 @@ def test_forced_collective_paths_match_plain_job(ctx):
     plain = StitchJob(ctx, (w, h), cams).run(frames)
     forced = StitchJob(ctx, (w, h), cams, force_collectives=True).run(frames)
     assert forced["indices"] == plain["indices"] == [0, 1, 2, 3]
-    assert torch.equal(forced["confidence"], plain["confidence"])
+    assert torch.equal(forced["confidence"].cpu(), plain["confidence"].cpu())
     for a, b in zip(forced["features"], plain["features"]):
         ka, da = a.download()
         kb, db = b.download()
@@ -59,7 +59,7 @@ def test_sift_job_forced_collectives_match_plain_job(ctx):
     plain = StitchJob(ctx, (w, h), cams, config=cfg).run(frames)
     forced = StitchJob(ctx, (w, h), cams, config=cfg, force_collectives=True).run(frames)
     assert plain["indices"] == forced["indices"] == [0, 1, 2, 3]
-    assert torch.equal(forced["confidence"], plain["confidence"])
+    assert torch.equal(forced["confidence"].cpu(), plain["confidence"].cpu())
     k, d = plain["features"][1].download()
     assert d.dtype == np.float32 and d.shape[1] == 128 and len(k) > 300
     for a, b in zip(forced["features"], plain["features"]):
@@ -144,7 +144,7 @@ def test_speculative_compose_equals_sequential(ctx, stray):
     assert spec["indices"] == seq["indices"] == ([0, 1, 2] if stray else [0, 1, 2, 3])
     assert spec["pano_size"] == seq["pano_size"]
     assert torch.equal(spec["pano"], seq["pano"]) and torch.equal(spec["mask"], seq["mask"])
-    assert torch.equal(spec["confidence"], seq["confidence"])
+    assert torch.equal(spec["confidence"].cpu(), seq["confidence"].cpu())
 
 
 def test_job_equals_the_per_call_stitcher(ctx):
