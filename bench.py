@@ -163,7 +163,7 @@ def main():
     if rank == 0:
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
         if not args.no_cpu_baseline and features == "orb" and world == 1:     # the CPU baseline is an N = 1 item
-            cpu = cpu_baseline(cams, workload)
+            cpu = cpu_baseline(cams, workload, frames)
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -172,7 +172,8 @@ def main():
             "config": {"workload": "%s: %d x %dx%d frames, %s + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"
                                    % (workload, n, W, H, "SIFT (128-D f32, L2 on fp16 MFMA)" if features == "sift" else "ORB 4000"),
                        "frames": n, "frame_size": [W, H], "pairs": n * (n - 1) // 2, "pano_size": list(out["pano_size"]),
-                       "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world)},
+                       "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world),
+                       "warp_roi": "computed inside every timed step (mis_warp_roi_batch: one kernel for all frames, nothing cached)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if single:
@@ -187,46 +188,116 @@ def main():
         dist.destroy_process_group()
 
 
+def _events_ms(stream, fn, reps=1):
+    """HIP events on `stream` (made current so that the events are recorded on it) around reps calls of fn()."""
+    with torch.cuda.stream(stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
 def measure_roofline(ctx, job, frames, cams, launches):
-    """Warp kernel (K10): algorithmic bytes per launch / average launch duration.  The duration is measured with
-    HIP events on the context's stream around `launches` back-to-back launches of the kernel for one frame, all
-    enqueued from inside the library (mis_warp_spherical_fused_timed), so that host launch pacing does not enter."""
+    """algorithmic bytes of K10-K14 / their summed device time, each leg alone on the device and timed with
+    HIP events on the stream its kernels are launched on.
+      warp (K10):      (3 S + 7 P) per frame / average duration of `launches` back-to-back launches of warp_fused_kernel
+                       for one frame, enqueued from inside the library (mis_warp_spherical_fused_timed);
+      feed (K12-K13):  sum over this rank's frames of 7 P_i + 2 (6 + 4) (4/3) P_b,i / the time of their mis_blender_feed
+                       calls (P_b,i = the feed's padded tile, mis_blender_feed_rect);
+      finalise (K14):  44.3 B per padded panorama pixel / the time of mis_blender_blend.
+    The headline object is the aggregate; `parts` carries each leg, the warp kernel alone first."""
+    import ctypes as C
     import image_stitching_amd as isa
-    i = job.my_frames[len(job.my_frames) // 2]
+    from image_stitching_amd import _capi as capi
+    eng = job.engine
+    mine = list(job.my_frames)
+    i = mine[len(mine) // 2]
     cam = cams[i]
     warper = isa.SphericalWarper(ctx, job.scale)
     roi = warper.warpRoi((cam["width"], cam["height"]), cam["K"], cam["R"])
     S = cam["width"] * cam["height"]
     P = roi[2] * roi[3]
-    algo = 3 * S + 6 * P + 1 * P           # SURVEY 8(d): source read once, 16SC3 + mask written once
+    algo_w = 3 * S + 6 * P + 1 * P           # SURVEY 8(d): source read once, 16SC3 + mask written once
     dst, msk = warper.alloc_fused(roi)
     warper.warp_fused_timed(frames[i], cam["K"], cam["R"], roi, dst, msk, launches)        # warm-up
     us = sum(warper.warp_fused_timed(frames[i], cam["K"], cam["R"], roi, dst, msk, launches) for _ in range(3)) / 3.0
-    t = us * 1e-6
-    ach = algo / t / 1e9
+    t_w = us * 1e-6
+    del dst, msk
     # HBM traffic per launch from the PMC passes of profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes): not collectable from inside
-    # this process, so it is read from the committed summary when that belongs to this kernel build.
+    # this process, so it is read from the committed summary when that belongs to this frame size.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_warp_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")) as f:
             pm = json.load(f)
         if pm.get("frame_size") == [cam["width"], cam["height"]]:
             traffic = pm["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "hbm", "kernel": "warp_fused_kernel", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": algo,
-            "avg_launch_us": round(t * 1e6, 2), "launches": launches}
+    parts = {"warp": {"kernel": "warp_fused_kernel", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
+                      "algorithmic_bytes_per_launch": algo_w, "avg_launch_us": round(t_w * 1e6, 2), "launches": launches,
+                      "traffic": traffic}}
+    # ---- feed + finalise legs: this rank's frames through the job's own blender, stage by stage ----
+    cctx, side = eng.cctx, eng.compose_stream
+    with torch.cuda.stream(side):
+        btype, bands = job.stage_compose_prepare(list(range(job.n)))
+    rois = job._compose_rois
+    cw = isa.SphericalWarper(cctx, job.scale)
+    warped = []
+    with torch.cuda.stream(side):
+        for k in mine:
+            tl, img_s, mk = cw.warp_fused(frames[k], cams[k]["K"], cams[k]["R"], rois[k])
+            warped.append((img_s, mk, tl))
+    side.synchronize()
+    algo_f, pb_total = 0, 0
+    for (img_s, mk, tl), k in zip(warped, mine):
+        r = capi.MisRect()
+        cctx.check(cctx.lib.mis_blender_feed_rect(eng.blender.h, rois[k][2], rois[k][3], capi.MisPoint(tl[0], tl[1]), C.byref(r)))
+        pb = r.width * r.height
+        pb_total += pb
+        algo_f += 7 * rois[k][2] * rois[k][3] + (2 * (6 + 4) * 4 * pb) // 3
+
+    def feeds():
+        for img_s, mk, tl in warped:
+            eng.blender.feed(img_s, mk, tl)
+    t_f = _events_ms(side, feeds) * 1e-3
+    px = [0]
+
+    def fin():
+        with torch.cuda.stream(side):
+            pano, mask = eng.blender.blend()
+        px[0] = 1
+    lv = eng.accumulators()
+    p_pano = lv[0][1].shape[0] * lv[0][1].shape[1]
+    algo_b = int(44.3 * p_pano)
+    t_b = _events_ms(side, fin) * 1e-3
+    # a second pass (the first feed pass of a fresh blender also pays allocation of its scratch)
+    with torch.cuda.stream(side):
+        job.stage_compose_prepare(list(range(job.n)))
+    t_f2 = _events_ms(side, feeds) * 1e-3
+    t_b2 = _events_ms(side, fin) * 1e-3
+    t_f, t_b = min(t_f, t_f2), min(t_b, t_b2)
+    nmine = len(mine)
+    parts["feed"] = {"kernels": "feed_* / pyr_down_* / laplace_* (mis_blender_feed)", "achieved": round(algo_f / t_f / 1e9, 1),
+                     "frac": round(algo_f / t_f / 8e12, 4), "algorithmic_bytes": algo_f, "frames": nmine, "num_bands": bands,
+                     "padded_tile_px_per_frame": pb_total // nmine, "us_per_frame": round(t_f / nmine * 1e6, 2)}
+    parts["finalize"] = {"kernels": "normalize / collapse2x2 / finalize (mis_blender_blend)", "achieved": round(algo_b / t_b / 1e9, 1),
+                         "frac": round(algo_b / t_b / 8e12, 4), "algorithmic_bytes": algo_b, "padded_pano_px": p_pano,
+                         "us": round(t_b * 1e6, 2)}
+    # aggregate over this rank's frames: every frame's warp is costed at the measured frame's launch duration scaled by its bytes
+    algo_w_all = sum(3 * S + 7 * rois[k][2] * rois[k][3] for k in mine)
+    t_w_all = t_w * algo_w_all / algo_w
+    total_b, total_t = algo_w_all + algo_f + algo_b, t_w_all + t_f + t_b
+    ach = total_b / total_t / 1e9
+    return {"bound": "hbm", "kernel": "K10-K14 aggregate (warp + blend feed + blend finalise; SURVEY 8(d))", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "algorithmic_bytes": total_b, "device_ms": round(total_t * 1e3, 3), "parts": parts}
 
 
-def cpu_baseline(cams, workload):
-    """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample:
-    two adjacent frames of the same workload through every stage; per-frame and per-pair times are
-    extrapolated to the full job (n frames, n(n-1)/2 pairs, panorama area)."""
-    import oracle
-    import synth
-    n = len(cams)
+def _host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a container's CPU quota (cgroup v2) is the real core count available to the oracle's OpenMP team
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -234,66 +305,39 @@ def cpu_baseline(cams, workload):
             cores = max(1, min(cores, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    cores = int(os.environ.get("OMP_NUM_THREADS", cores))
+    return int(os.environ.get("OMP_NUM_THREADS", cores))
+
+
+def cpu_baseline(cams, workload, frames_dev):
+    """The oracle (CPU restatement, kind "port": scalar C, -O3 -march=x86-64-v3, OpenMP over rows / queries / pairs) timed on
+    this box's host cores on the SAME frames: the full job (every frame, every pair, the whole panorama) on all cores -- no
+    extrapolation -- and, bounded, the job of the 4 middle frames on ONE thread."""
+    import ctypes
+    cores = _host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)   # read by libgomp when the oracle library is first loaded
-    a, b = n // 2 - 1, n // 2
-    sub = [cams[a], cams[b]]
-    fr = [synth.render_frame(c) for c in sub]
-    W, H = sub[0]["width"], sub[0]["height"]
-    t = {}
+    from oracle import job as ojob
+    gomp = ctypes.CDLL("libgomp.so.1")
+    n = len(cams)
+    frames = [frames_dev[i].cpu().numpy() for i in range(n)]
+    gomp.omp_set_num_threads(cores)
     t0 = time.perf_counter()
-    orb = oracle.Orb(W, H)
-    feats = []
-    for f in fr:
-        k, d = orb.run(f)
-        feats.append(dict(img_w=W, img_h=H, xy=np.stack([k["x"], k["y"]], 1), desc=d))
-    t["features"] = (time.perf_counter() - t0) / 2
+    r = ojob.stitch_job(frames, cams)
+    total = time.perf_counter() - t0
+    sp = r["spans_s"]
+    lo = n // 2 - 2
+    sub = list(range(lo, lo + 4)) if n >= 4 else list(range(n))
+    gomp.omp_set_num_threads(1)
     t0 = time.perf_counter()
-    oracle.match_pair(feats[0], feats[1])
-    t["pair_near"] = time.perf_counter() - t0
-    # a pair without overlap costs more (RANSAC never becomes confident and runs all its iterations): time one as well
-    far = cams[(b + n // 2) % n]
-    kf, df = orb.run(synth.render_frame(far))
-    ffar = dict(img_w=W, img_h=H, xy=np.stack([kf["x"], kf["y"]], 1), desc=df)
-    t0 = time.perf_counter()
-    oracle.match_pair(feats[0], ffar)
-    t["pair_far"] = time.perf_counter() - t0
-    scale = float(np.float32(sub[0]["K"][1, 1]))
-    t0 = time.perf_counter()
-    items = []
-    for c, f in zip(sub, fr):
-        K, R = c["K"].astype(np.float32), c["R"].astype(np.float32)
-        img, tl = oracle.warp_spherical(f, scale, K, R)
-        msk, _ = oracle.warp_spherical(np.full((H, W), 255, np.uint8), scale, K, R, oracle.INTER_NEAREST, oracle.BORDER_CONSTANT)
-        items.append((img.astype(np.int16), msk, tl))
-    t["warp"] = (time.perf_counter() - t0) / 2
-    corners = [i[2] for i in items]
-    sizes = [(i[0].shape[1], i[0].shape[0]) for i in items]
-    # band count of the FULL job's panorama (the sample's own panorama is smaller)
-    full_rois = [oracle.warp_roi(scale, W, H, c["K"].astype(np.float32), c["R"].astype(np.float32)) for c in cams]
-    px, py, pw, ph = oracle.lib() and _result_roi(full_rois)
-    _, bands, _ = oracle.blend_config(oracle.BLEND_MULTI_BAND, 5.0, pw, ph)
-    bl = oracle.Blender(oracle.BLEND_MULTI_BAND, bands, 0.0)
-    bl.prepare(corners, sizes)
-    t0 = time.perf_counter()
-    for img, msk, tl in items:
-        bl.feed(img, msk, tl)
-    t["feed"] = (time.perf_counter() - t0) / 2
-    _, _, sw, sh, _, _ = bl.roi()
-    t0 = time.perf_counter()
-    bl.blend()
-    t["finalize_sample"] = time.perf_counter() - t0
-    fin = t["finalize_sample"] * (pw * ph) / float(sw * sh)
-    # pairs whose warped ROIs intersect are costed like the adjacent sample pair, the others like the distant one
-    def overlap(r1, r2):
-        return r1[0] < r2[0] + r2[2] and r2[0] < r1[0] + r1[2] and r1[1] < r2[1] + r2[3] and r2[1] < r1[1] + r1[3]
-    n_near = sum(1 for i in range(n) for j in range(i + 1, n) if overlap(full_rois[i], full_rois[j]))
-    n_far = n * (n - 1) // 2 - n_near
-    total = n * (t["features"] + t["warp"] + t["feed"]) + n_near * t["pair_near"] + n_far * t["pair_far"] + fin
+    r1 = ojob.stitch_job([frames[i] for i in sub], [cams[i] for i in sub])
+    t1 = time.perf_counter() - t0
+    gomp.omp_set_num_threads(cores)
     return {"value": round(n / total, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "frames %d,%d (+ a distant one) of %s through every oracle stage; extrapolated: %d x (features %.2fs + warp %.2fs + feed %.2fs) + "
-                      "%d overlapping pairs x %.3fs + %d other pairs x %.3fs + finalize %.2fs (scaled by panorama area) = %.1fs"
-                      % (a, b, workload, n, t["features"], t["warp"], t["feed"], n_near, t["pair_near"], n_far, t["pair_far"], fin, total)}
+            "sample": "the full %s job (%d frames, %d pairs, %dx%d panorama, %d bands) through every oracle stage on %d threads: features %.2fs + "
+                      "matching %.2fs + compositing (warp + blend) %.2fs = %.2fs"
+                      % (workload, n, n * (n - 1) // 2, r["pano_size"][0], r["pano_size"][1], r["num_bands"], cores, sp["features"], sp["matching"],
+                         sp["compositing"], total),
+            "single_thread": {"value": round(len(sub) / t1, 4), "unit": "frames/s", "cores": 1,
+                              "sample": "frames %d..%d of the same job as a %d-frame job (6 pairs) on one thread: %.2fs" % (sub[0], sub[-1], len(sub), t1)}}
 
 
 def _result_roi(rois):

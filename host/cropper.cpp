@@ -132,13 +132,13 @@ HostImage fillContour(const std::vector<Point>& contour, int width, int height) 
 Rect crop(HostImage& source) {
     if (source.channels != 3 && source.channels != 1) throw std::runtime_error("crop: 8UC3 or 8UC1 image expected");
     const int w = source.width, h = source.height, cn = source.channels;
-    // cvtColor(RGB2GRAY) > 0: Q14 weights R 4899, G 9617, B 1868 on channels 0, 1, 2 (the reference passes a BGR image
+    // cvtColor(RGB2GRAY) > 0: 15-bit weights R 9798, G 19235, B 3735 on channels 0, 1, 2 (the reference passes a BGR image
     // to COLOR_RGB2GRAY; only "> 0" matters afterwards)
     HostImage mask;
     mask.width = w; mask.height = h; mask.channels = 1;
     mask.data.resize((size_t)w * h);
     for (size_t i = 0; i < (size_t)w * h; i++) {
-        int g = cn == 3 ? (source.data[3 * i] * 4899 + source.data[3 * i + 1] * 9617 + source.data[3 * i + 2] * 1868 + (1 << 13)) >> 14 : source.data[i];
+        int g = cn == 3 ? (source.data[3 * i] * 9798 + source.data[3 * i + 1] * 19235 + source.data[3 * i + 2] * 3735 + (1 << 14)) >> 15 : source.data[i];
         mask.data[i] = g > 0 ? 255 : 0;
     }
     std::vector<std::vector<Point>> contours = findExternalContours(mask);

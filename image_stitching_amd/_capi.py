@@ -121,6 +121,8 @@ PROTOTYPES = {
     "mis_wave_correct": (_i, [_vp, _i, _i]),
     "mis_warp_roi": (_i, [_f, _i, _i, _vp, _vp, _P(MisRect)]),
     "mis_warp_spherical": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _i, _i, _P(MisImage), _P(MisPoint)]),
+    "mis_warp_roi_batch": (_i, [_vp, _f, _i, _i, _i, _vp, _vp, _P(MisRect)]),
+    "mis_warp_spherical_fused_roi": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisRect), _P(MisImage), _P(MisImage), _P(MisPoint)]),
     "mis_warp_spherical_fused": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint)]),
     "mis_resize_linear_exact": (_i, [_vp, _P(MisImage), _i, _i, C.c_double, C.c_double, _P(MisImage)]),
     "mis_rotate": (_i, [_vp, _P(MisImage), _i, _P(MisImage)]),
@@ -141,6 +143,7 @@ PROTOTYPES = {
     "mis_blender_feed": (_i, [_vp, _P(MisImage), _P(MisImage), MisPoint]),
     "mis_blender_blend": (_i, [_vp, _P(MisImage), _P(MisImage)]),
     "mis_compose_frames": (_i, [_vp, _P(MisImage), _i, _f, _vp, _vp, _P(MisRect)]),
+    "mis_blender_feed_rect": (_i, [_vp, _i, _i, MisPoint, _P(MisRect)]),
     "mis_blender_level_info": (_i, [_vp, _i, _P(_i), _P(_i), _P(_vp), _P(_vp)]),
 }
 

@@ -128,7 +128,7 @@ def crop(source):
     """crop(cv::Mat& source): -> (cropped image, (x, y, w, h)).  source: (H, W, 3) or (H, W) uint8."""
     source = np.asarray(source)
     if source.ndim == 3:
-        g = (source[..., 0].astype(np.int64) * 4899 + source[..., 1].astype(np.int64) * 9617 + source[..., 2].astype(np.int64) * 1868 + (1 << 13)) >> 14
+        g = (source[..., 0].astype(np.int64) * 9798 + source[..., 1].astype(np.int64) * 19235 + source[..., 2].astype(np.int64) * 3735 + (1 << 14)) >> 15
     else:
         g = source
     mask = np.where(g > 0, 255, 0).astype(np.uint8)

@@ -555,8 +555,9 @@ int ensure_scratch(MisBlender* b, size_t bytes) {
     return MIS_OK;
 }
 
-int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
-    MisContext* ctx = b->ctx;
+// MultiBandBlender::feed's padded tile of a frame at `tl` (w x h): gap 3 * 2^bands, clipped to the padded panorama roi,
+// corners snapped to multiples of 2^bands (relative to the roi), shifted back when the rounding overshoots
+void feed_tile_rect(const MisBlender* b, int w, int h, MisPoint tl, int* otnx, int* otny, int* owidth, int* oheight) {
     const int nb = b->num_bands, q = 1 << nb, gap = 3 * q;
     const MisRect& R = b->roi;
     int brx_roi = R.x + R.width, bry_roi = R.y + R.height;
@@ -569,7 +570,17 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
     height += (q - height % q) % q;
     bnx = tnx + width; bny = tny + height;
     int dy = std::max(bny - bry_roi, 0), dx = std::max(bnx - brx_roi, 0);
-    tnx -= dx; bnx -= dx; tny -= dy; bny -= dy;
+    tnx -= dx; tny -= dy;
+    *otnx = tnx; *otny = tny; *owidth = width; *oheight = height;
+}
+
+int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
+    MisContext* ctx = b->ctx;
+    const int nb = b->num_bands;
+    const MisRect& R = b->roi;
+    int tnx, tny, width, height;
+    feed_tile_rect(b, w, h, tl, &tnx, &tny, &width, &height);
+    const int bnx = tnx + width, bny = tny + height;
     FrameView v;
     v.img = (const int16_t*)dimg.data; v.istride = dimg.stride / 2;
     v.mask = (const uint8_t*)dmask.data; v.mstride = dmask.stride;
@@ -788,7 +799,7 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
         MisImage img{blk, r.width, r.height, 3, ipitch, MIS_S16, MIS_MEM_DEVICE};
         MisImage msk{(uint8_t*)blk + ibytes, r.width, r.height, 1, mpitch, MIS_U8, MIS_MEM_DEVICE};
         MisPoint tl;
-        rc = mis_warp_spherical_fused(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &img, &msk, &tl);
+        rc = mis_warp_spherical_fused_roi(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &r, &img, &msk, &tl);
         if (rc == MIS_OK) rc = mis_blender_feed(b, &img, &msk, tl);
         mis_pool_free(ctx, blk, got);   // stream-ordered reuse: the next frame's warp is enqueued behind this feed
         if (rc != MIS_OK) return rc;
@@ -827,6 +838,13 @@ extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) 
     if ((rc = mis_dev_image_commit(ctx, dst, &dd)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_commit(ctx, dmask, &dm)) != MIS_OK) return rc;
     b->prepared = false;  // the accumulators are consumed (the reference releases them in blend())
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_feed_rect(const MisBlender* b, int width, int height, MisPoint tl, MisRect* tile) {
+    if (!b || !tile || !b->prepared || width < 1 || height < 1) return MIS_E_INVALID;
+    if (b->type != MIS_BLEND_MULTI_BAND) { tile->x = tl.x; tile->y = tl.y; tile->width = width; tile->height = height; return MIS_OK; }
+    feed_tile_rect(b, width, height, tl, &tile->x, &tile->y, &tile->width, &tile->height);
     return MIS_OK;
 }
 

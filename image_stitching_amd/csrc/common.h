@@ -26,6 +26,9 @@ struct MisContext {
     // grow-only scratch for host<->device staging
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // pinned, device-visible host block of mis_warp_roi_batch (jobs in, extremes out)
+    void* roi_pinned = nullptr;
+    size_t roi_pinned_bytes = 0;
 };
 
 int mis_set_error(MisContext* ctx, int code, const char* fmt, ...);
@@ -59,3 +62,4 @@ int mis_dev_image_release(MisContext* ctx, DevImage* d);
 // Prepare an output image (allocate when data == NULL) and, for host outputs, a device twin.
 int mis_dev_image_out(MisContext* ctx, MisImage* img, int width, int height, int channels, int dtype, DevImage* out);
 int mis_dev_image_commit(MisContext* ctx, const MisImage* img, DevImage* d);  // copy back for host outputs, release
+

@@ -61,6 +61,7 @@ extern "C" int mis_context_destroy(MisContext* ctx) {
     delete ctx->match_ws;
     for (auto& b : ctx->pool) hipFree(b.second);
     if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->roi_pinned) hipHostFree(ctx->roi_pinned);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MIS_OK;

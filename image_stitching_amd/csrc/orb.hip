@@ -63,7 +63,7 @@ struct Work {  // device pointers of one MisOrb workspace
 };
 
 // ---------------------------------------------------------------- K1 gray --------------------
-// cvtColor BGR2GRAY, Q14: (B*1868 + G*9617 + R*4899 + 8192) >> 14, written into the padded level 0
+// cvtColor BGR2GRAY, 15-bit coefficients (RGB2Gray<uchar> of OpenCV 4.x: BY15 3735, GY15 19235, RY15 9798, gray_shift 15): (B*3735 + G*19235 + R*9798 + 16384) >> 15, written into the padded level 0
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* dst, int pp, int aligned) {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w) return;
@@ -73,13 +73,13 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t st
         // 12 bytes = 4 BGR pixels in three dwords; the destination is dword aligned (border 32, pitch % 64 == 0)
         const unsigned* sp = reinterpret_cast<const unsigned*>(s);
         const unsigned w0 = sp[0], w1 = sp[1], w2 = sp[2];
-        const unsigned g0 = ((w0 & 255) * 1868 + ((w0 >> 8) & 255) * 9617 + ((w0 >> 16) & 255) * 4899 + (1 << 13)) >> 14;
-        const unsigned g1 = ((w0 >> 24) * 1868 + (w1 & 255) * 9617 + ((w1 >> 8) & 255) * 4899 + (1 << 13)) >> 14;
-        const unsigned g2 = (((w1 >> 16) & 255) * 1868 + (w1 >> 24) * 9617 + (w2 & 255) * 4899 + (1 << 13)) >> 14;
-        const unsigned g3 = (((w2 >> 8) & 255) * 1868 + ((w2 >> 16) & 255) * 9617 + (w2 >> 24) * 4899 + (1 << 13)) >> 14;
+        const unsigned g0 = ((w0 & 255) * 3735 + ((w0 >> 8) & 255) * 19235 + ((w0 >> 16) & 255) * 9798 + (1 << 14)) >> 15;
+        const unsigned g1 = ((w0 >> 24) * 3735 + (w1 & 255) * 19235 + ((w1 >> 8) & 255) * 9798 + (1 << 14)) >> 15;
+        const unsigned g2 = (((w1 >> 16) & 255) * 3735 + (w1 >> 24) * 19235 + (w2 & 255) * 9798 + (1 << 14)) >> 15;
+        const unsigned g3 = (((w2 >> 8) & 255) * 3735 + ((w2 >> 16) & 255) * 19235 + (w2 >> 24) * 9798 + (1 << 14)) >> 15;
         *reinterpret_cast<unsigned*>(o) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
     } else {
-        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)((s[3 * k] * 1868 + s[3 * k + 1] * 9617 + s[3 * k + 2] * 4899 + (1 << 13)) >> 14);
+        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)((s[3 * k] * 3735 + s[3 * k + 1] * 19235 + s[3 * k + 2] * 9798 + (1 << 14)) >> 15);
     }
 }
 

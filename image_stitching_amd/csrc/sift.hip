@@ -4,7 +4,7 @@
 // scale space), imgproc GaussianBlur / resize -- see oracle/mo_sift.h for the restatement choices.
 //
 // Stages (all float arithmetic is IEEE + - * / sqrt in the CPU path's order, no FMA contraction):
-//   gray (Q14) -> 2x bilinear upsample -> Gaussian pyramid (separable blur, nearest 2:1 decimation between
+//   gray (15-bit coefficients) -> 2x bilinear upsample -> Gaussian pyramid (separable blur, nearest 2:1 decimation between
 //   octaves) -> DoG -> 26-neighbour extrema (candidates appended through a counter) -> per candidate: 3-D quadratic
 //   refinement, contrast / edge tests, 36-bin orientation histogram (sequential sums: order matters in float) ->
 //   keypoints -> canonical order of KeyPointsFilter::removeDuplicatedSorted + duplicate removal (a total order, so
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void sift_gray_kernel(const uint8_t* __restric
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
-    gray[(size_t)y * w + x] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+    gray[(size_t)y * w + x] = (uint8_t)((s[0] * 3735 + s[1] * 19235 + s[2] * 9798 + (1 << 14)) >> 15);
 }
 
 // resize(float, 2x, INTER_LINEAR): source coordinate (d + 0.5) * 0.5 - 0.5, taps clamped, horizontal then vertical

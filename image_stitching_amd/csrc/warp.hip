@@ -10,7 +10,6 @@
 #include "common.h"
 #include "dev_math.h"
 #include <algorithm>
-#include <mutex>
 #include <vector>
 
 namespace {
@@ -53,34 +52,18 @@ void projector_set(Projector* p, float scale, const float K[9], const float R[9]
         }
 }
 
-// SphericalProjector::mapForward (warpers_inl.hpp)
-void map_forward(const Projector* p, float x, float y, float* u, float* v) {
-    const float* m = p->r_kinv;
+// SphericalProjector::mapForward (warpers_inl.hpp); the same float operations on the host and on the device
+MIS_HD void map_forward(const float* m, float scale, float x, float y, float* u, float* v) {
     float x_ = (m[0] * x + m[1] * y) + m[2];
     float y_ = (m[3] * x + m[4] * y) + m[5];
     float z_ = (m[6] * x + m[7] * y) + m[8];
-    *u = p->scale * mis_atan2f(x_, z_);
+    *u = scale * mis_atan2f(x_, z_);
     float w = y_ / sqrtf((x_ * x_ + y_ * y_) + z_ * z_);
-    *v = p->scale * (MIS_PI_F - mis_acosf(w == w ? w : 0));
+    *v = scale * (MIS_PI_F - mis_acosf(w == w ? w : 0));
 }
 
-// SphericalWarper::detectResultRoi: border projection + pole tests; 2(W+H) points on the host
-void detect_result_roi(const Projector* p, int sw, int sh, int* tlx, int* tly, int* brx, int* bry) {
-    float tl_uf = FLT_MAX, tl_vf = FLT_MAX, br_uf = -FLT_MAX, br_vf = -FLT_MAX, u, v;
-    auto upd = [&]() {
-        if (u < tl_uf) tl_uf = u;
-        if (v < tl_vf) tl_vf = v;
-        if (u > br_uf) br_uf = u;
-        if (v > br_vf) br_vf = v;
-    };
-    for (int x = 0; x < sw; ++x) {
-        map_forward(p, (float)x, 0, &u, &v); upd();
-        map_forward(p, (float)x, (float)(sh - 1), &u, &v); upd();
-    }
-    for (int y = 0; y < sh; ++y) {
-        map_forward(p, 0, (float)y, &u, &v); upd();
-        map_forward(p, (float)(sw - 1), (float)y, &u, &v); upd();
-    }
+// SphericalWarper::detectResultRoi, second half: the float extremes of the border projection -> integer roi with the pole tests
+void roi_from_extremes(const Projector* p, int sw, int sh, float tl_uf, float tl_vf, float br_uf, float br_vf, int* tlx, int* tly, int* brx, int* bry) {
     tl_uf = (float)(int)tl_uf; tl_vf = (float)(int)tl_vf; br_uf = (float)(int)br_uf; br_vf = (float)(int)br_vf;
     for (int pass = 0; pass < 2; pass++) {
         float x = p->rinv[1], y = pass == 0 ? p->rinv[4] : -p->rinv[4], z = p->rinv[7];
@@ -99,35 +82,68 @@ void detect_result_roi(const Projector* p, int sw, int sh, int* tlx, int* tly, i
     *tlx = (int)tl_uf; *tly = (int)tl_vf; *brx = (int)br_uf; *bry = (int)br_vf;
 }
 
-// detectResultRoi walks 2(W+H) border pixels on the host (~0.1 ms at 4K); the compose loop asks for the
-// same (scale, K, R, size) twice (warpRoi, then warp), so the last few answers are cached.
-struct RoiKey {
-    float scale, K[9], R[9];
-    int w, h;
-};
-struct RoiEntry {
-    RoiKey key;
-    Projector proj;
-    int tlx, tly, brx, bry;
-};
-std::mutex g_roi_mutex;
-std::vector<RoiEntry> g_roi_cache;
+// SphericalWarper::detectResultRoi: border projection + pole tests; 2(W+H) points on the host (single-call entry points;
+// a job's frames go through mis_warp_roi_batch: one small kernel for all of them).  Nothing is cached: every call pays it.
+void detect_result_roi(const Projector* p, int sw, int sh, int* tlx, int* tly, int* brx, int* bry) {
+    float tl_uf = FLT_MAX, tl_vf = FLT_MAX, br_uf = -FLT_MAX, br_vf = -FLT_MAX, u, v;
+    auto upd = [&]() {
+        if (u < tl_uf) tl_uf = u;
+        if (v < tl_vf) tl_vf = v;
+        if (u > br_uf) br_uf = u;
+        if (v > br_vf) br_vf = v;
+    };
+    for (int x = 0; x < sw; ++x) {
+        map_forward(p->r_kinv, p->scale, (float)x, 0, &u, &v); upd();
+        map_forward(p->r_kinv, p->scale, (float)x, (float)(sh - 1), &u, &v); upd();
+    }
+    for (int y = 0; y < sh; ++y) {
+        map_forward(p->r_kinv, p->scale, 0, (float)y, &u, &v); upd();
+        map_forward(p->r_kinv, p->scale, (float)(sw - 1), (float)y, &u, &v); upd();
+    }
+    roi_from_extremes(p, sw, sh, tl_uf, tl_vf, br_uf, br_vf, tlx, tly, brx, bry);
+}
 
 void projector_and_roi(float scale, const float K[9], const float R[9], int w, int h, Projector* p, int* tlx, int* tly, int* brx, int* bry) {
-    RoiKey key;
-    memset(&key, 0, sizeof(key));
-    key.scale = scale; key.w = w; key.h = h;
-    memcpy(key.K, K, sizeof(key.K)); memcpy(key.R, R, sizeof(key.R));
-    {
-        std::lock_guard<std::mutex> lock(g_roi_mutex);
-        for (const RoiEntry& e : g_roi_cache)
-            if (memcmp(&e.key, &key, sizeof(key)) == 0) { *p = e.proj; *tlx = e.tlx; *tly = e.tly; *brx = e.brx; *bry = e.bry; return; }
-    }
     projector_set(p, scale, K, R);
     detect_result_roi(p, w, h, tlx, tly, brx, bry);
-    std::lock_guard<std::mutex> lock(g_roi_mutex);
-    if (g_roi_cache.size() >= 256) g_roi_cache.erase(g_roi_cache.begin());
-    g_roi_cache.push_back(RoiEntry{key, *p, *tlx, *tly, *brx, *bry});
+}
+
+// The border walk of detectResultRoi for a whole job: workgroup f projects the 2(W+H) border pixels of frame f and reduces
+// the four extremes (min / max of finite floats: any order gives the host loop's result).  Jobs and results live in pinned,
+// device-visible host memory: one launch + one stream synchronisation for all frames of a panorama.
+struct RoiJob {
+    float r_kinv[9], scale;
+    int sw, sh;
+    float ext[4];   // out: min u, min v, max u, max v
+};
+__global__ __launch_bounds__(256) void warp_roi_kernel(RoiJob* jobs) {
+    RoiJob* j = jobs + blockIdx.x;
+    __shared__ float red[4][4];
+    float m[9];
+    for (int i = 0; i < 9; i++) m[i] = j->r_kinv[i];
+    const float scale = j->scale;
+    const int sw = j->sw, sh = j->sh;
+    float lo_u = FLT_MAX, lo_v = FLT_MAX, hi_u = -FLT_MAX, hi_v = -FLT_MAX;
+    for (int i = threadIdx.x; i < 2 * (sw + sh); i += 256) {
+        float x, y, u, v;
+        if (i < 2 * sw) { x = (float)(i >> 1); y = (i & 1) ? (float)(sh - 1) : 0.f; }
+        else { const int k = i - 2 * sw; y = (float)(k >> 1); x = (k & 1) ? (float)(sw - 1) : 0.f; }
+        map_forward(m, scale, x, y, &u, &v);
+        lo_u = fminf(lo_u, u); lo_v = fminf(lo_v, v); hi_u = fmaxf(hi_u, u); hi_v = fmaxf(hi_v, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_u = fminf(lo_u, __shfl_xor(lo_u, o)); lo_v = fminf(lo_v, __shfl_xor(lo_v, o));
+        hi_u = fmaxf(hi_u, __shfl_xor(hi_u, o)); hi_v = fmaxf(hi_v, __shfl_xor(hi_v, o));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = lo_u; red[wave][1] = lo_v; red[wave][2] = hi_u; red[wave][3] = hi_v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        j->ext[0] = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+        j->ext[1] = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1]));
+        j->ext[2] = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+        j->ext[3] = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+    }
 }
 
 struct WarpArgs {
@@ -608,7 +624,8 @@ __global__ __launch_bounds__(256) void warp_u8_kernel(WarpArgs a) {
     }
 }
 
-int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9], WarpArgs* a, int* brx, int* bry) {
+// `known`: the roi warpRoi / mis_warp_roi_batch returned for exactly these (scale, K, R, size) -- skips the border walk
+int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9], WarpArgs* a, int* brx, int* bry, const MisRect* known = nullptr) {
     MIS_CHECK(ctx, src && K && R, MIS_E_INVALID, "null argument");
     MIS_CHECK(ctx, src->dtype == MIS_U8 && (src->channels == 1 || src->channels == 3), MIS_E_UNSUPPORTED,
               "warp source must be 8UC1 or 8UC3");
@@ -617,7 +634,12 @@ int setup(MisContext* ctx, const MisImage* src, float scale, const float K[9], c
     MIS_CHECK(ctx, scale > 0.f, MIS_E_INVALID, "scale must be positive");
     Projector p;
     int tlx, tly;
-    projector_and_roi(scale, K, R, src->width, src->height, &p, &tlx, &tly, brx, bry);
+    if (known) {
+        projector_set(&p, scale, K, R);
+        tlx = known->x; tly = known->y; *brx = known->x + known->width - 1; *bry = known->y + known->height - 1;
+    } else {
+        projector_and_roi(scale, K, R, src->width, src->height, &p, &tlx, &tly, brx, bry);
+    }
     for (int i = 0; i < 9; i++) a->m[i] = p.k_rinv[i];
     a->scale = scale; a->tlx = tlx; a->tly = tly;
     a->dw = *brx - tlx + 1; a->dh = *bry - tly + 1;
@@ -686,11 +708,11 @@ extern "C" int mis_warp_spherical(MisContext* ctx, const MisImage* src, float sc
 }
 
 static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
-                           MisImage* dst, MisImage* dmask, MisPoint* tl, int repeats, float* avg_us) {
+                           MisImage* dst, MisImage* dmask, MisPoint* tl, int repeats, float* avg_us, const MisRect* known_roi = nullptr) {
     if (!ctx) return MIS_E_INVALID;
     WarpArgs a;
     int brx, bry, rc;
-    if ((rc = setup(ctx, src, scale, K, R, &a, &brx, &bry)) != MIS_OK) return rc;
+    if ((rc = setup(ctx, src, scale, K, R, &a, &brx, &bry, known_roi)) != MIS_OK) return rc;
     MIS_CHECK(ctx, src->channels == 3, MIS_E_UNSUPPORTED, "fused warp needs an 8UC3 source");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     DevImage din, dout, dm;
@@ -738,6 +760,42 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
 extern "C" int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
                                         MisImage* dst, MisImage* dmask, MisPoint* tl) {
     return warp_fused_impl(ctx, src, scale, K, R, dst, dmask, tl, 1, nullptr);
+}
+
+// the compose loop's form: the roi is the one mis_warp_roi / mis_warp_roi_batch gave for these parameters
+extern "C" int mis_warp_spherical_fused_roi(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9], const MisRect* roi,
+                                            MisImage* dst, MisImage* dmask, MisPoint* tl) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, roi && roi->width > 0 && roi->height > 0, MIS_E_INVALID, "empty roi");
+    return warp_fused_impl(ctx, src, scale, K, R, dst, dmask, tl, 1, nullptr, roi);
+}
+
+extern "C" int mis_warp_roi_batch(MisContext* ctx, float scale, int w, int h, int n, const float* Ks, const float* Rs, MisRect* rois) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, Ks && Rs && rois && n >= 1 && w >= 1 && h >= 1 && scale > 0.f, MIS_E_INVALID, "invalid argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = sizeof(RoiJob) * (size_t)n;
+    if (ctx->roi_pinned_bytes < need) {
+        if (ctx->roi_pinned) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipHostFree(ctx->roi_pinned)); ctx->roi_pinned = nullptr; ctx->roi_pinned_bytes = 0; }
+        MIS_HIP(ctx, hipHostMalloc(&ctx->roi_pinned, need * 2, hipHostMallocMapped));
+        ctx->roi_pinned_bytes = need * 2;
+    }
+    RoiJob* jobs = (RoiJob*)ctx->roi_pinned;
+    std::vector<Projector> proj((size_t)n);
+    for (int i = 0; i < n; i++) {
+        projector_set(&proj[i], scale, Ks + 9 * i, Rs + 9 * i);
+        memcpy(jobs[i].r_kinv, proj[i].r_kinv, sizeof(jobs[i].r_kinv));
+        jobs[i].scale = scale; jobs[i].sw = w; jobs[i].sh = h;
+    }
+    hipLaunchKernelGGL(warp_roi_kernel, dim3(n), dim3(256), 0, ctx->stream, jobs);
+    MIS_HIP(ctx, hipGetLastError());
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) {
+        int tlx, tly, brx, bry;
+        roi_from_extremes(&proj[i], w, h, jobs[i].ext[0], jobs[i].ext[1], jobs[i].ext[2], jobs[i].ext[3], &tlx, &tly, &brx, &bry);
+        rois[i].x = tlx; rois[i].y = tly; rois[i].width = brx + 1 - tlx; rois[i].height = bry + 1 - tly;
+    }
+    return MIS_OK;
 }
 
 extern "C" int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],

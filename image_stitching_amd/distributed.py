@@ -171,6 +171,10 @@ class HipEngine:
     def warp_roi(self, scale, cam):
         return st.warp_roi(scale, self.frame_size, cam["K"], cam["R"])
 
+    def warp_rois(self, scale, cams):
+        """warpRoi of every camera (image_stitching.cpp:1119-1140): one kernel on the compose stream, nothing cached."""
+        return st.warp_rois(self.cctx, scale, self.frame_size, cams)
+
     def begin_compose(self, scale, corners, sizes):
         x, y, pw, ph = st.result_roi(corners, sizes)
         btype, bands, sharp = st.blend_config(self.cfg.blend_type, self.cfg.blend_strength, (pw, ph))
@@ -277,7 +281,12 @@ class StitchJob:
     def stage_compose_prepare(self, indices):
         """blender sizing + prepare for the kept frames (image_stitching.cpp:1138, :1175-1192): needs the cameras only."""
         eng = self.engine
-        rois = {i: eng.warp_roi(self.scale, self.cams[i]) for i in indices}
+        # the reference takes the median focal of the KEPT cameras (image_stitching.cpp:746-748, :884-895)
+        self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])
+        if hasattr(eng, "warp_rois"):
+            rois = dict(zip(indices, eng.warp_rois(self.scale, [self.cams[i] for i in indices])))
+        else:
+            rois = {i: eng.warp_roi(self.scale, self.cams[i]) for i in indices}
         corners = [(rois[i][0], rois[i][1]) for i in indices]
         sizes = [(rois[i][2], rois[i][3]) for i in indices]
         btype, bands = eng.begin_compose(self.scale, corners, sizes)
@@ -397,6 +406,10 @@ class StitchJob:
             raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         spec = getattr(self.engine, "speculative_compose", False) and not refine   # refined cameras: compose must wait
         prepared = None
+        side = getattr(self.engine, "compose_stream", None)
+        if side is not None:
+            # the compose stream is non-blocking: order it behind whatever produced `frames` on the caller's stream
+            side.wait_stream(torch.cuda.current_stream(self.engine.ctx.device))
         if spec:
             # the blender's prepare (sizing + zeroing ~200 MB of panorama pyramids, ~1.2 ms) depends on the cameras only:
             # it goes to the compose stream before anything else and runs under the feature stage

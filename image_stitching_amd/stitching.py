@@ -131,6 +131,18 @@ def warp_roi(scale, src_size, K, R):
     return r.x, r.y, r.width, r.height
 
 
+def warp_rois(ctx, scale, src_size, cameras):
+    """The warpRoi loop of main() (image_stitching.cpp:1119-1140) for all cameras in one library call: the border walks run
+    in one small kernel on the context's stream -> [(x, y, width, height)]."""
+    n = len(cameras)
+    Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cameras]))
+    Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cameras]))
+    rr = (capi.MisRect * n)()
+    ctx.check(ctx.lib.mis_warp_roi_batch(ctx.h, float(scale), int(src_size[0]), int(src_size[1]), n,
+                                         Ks.ctypes.data_as(C.c_void_p), Rs.ctypes.data_as(C.c_void_p), rr))
+    return [(r.x, r.y, r.width, r.height) for r in rr]
+
+
 class SphericalWarper:
     """warper_creator->create(scale) (image_stitching.cpp:973, :1117)."""
 
@@ -163,8 +175,13 @@ class SphericalWarper:
         ka, kp = _mat9(K)
         ra, rp = _mat9(R)
         tl = capi.MisPoint()
-        self.ctx.check(self.ctx.lib.mis_warp_spherical_fused(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(dimg),
-                                                             C.byref(mimg), C.byref(tl)))
+        if roi is not None:      # the roi warpRoi gave for these parameters: the warp does not walk the border again
+            rr = capi.MisRect(int(roi[0]), int(roi[1]), int(roi[2]), int(roi[3]))
+            self.ctx.check(self.ctx.lib.mis_warp_spherical_fused_roi(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(rr),
+                                                                     C.byref(dimg), C.byref(mimg), C.byref(tl)))
+        else:
+            self.ctx.check(self.ctx.lib.mis_warp_spherical_fused(self.ctx.h, C.byref(simg), self.scale, kp, rp, C.byref(dimg),
+                                                                 C.byref(mimg), C.byref(tl)))
         return (tl.x, tl.y)
 
     def warp_fused_timed(self, src_bgr, K, R, roi, dst, msk, repeats):
@@ -847,11 +864,12 @@ class Stitcher:
 
     def compose(self, frames, cameras, indices=None, blender=None):
         """Compositing loop (image_stitching.cpp:1086-1225) with compose_scale = 1."""
-        indices = range(len(frames)) if indices is None else indices
-        scale = self.warped_image_scale(cameras)
+        indices = list(range(len(frames)) if indices is None else indices)
+        # the reference replaces `cameras` by the kept subset (image_stitching.cpp:746-748) before the median focal (:884-895)
+        scale = self.warped_image_scale([cameras[i] for i in indices])
         warper = SphericalWarper(self.ctx, scale)
         w, h = self.frame_size
-        rois = [warper.warpRoi((w, h), cameras[i]["K"], cameras[i]["R"]) for i in indices]
+        rois = warp_rois(self.ctx, scale, (w, h), [cameras[i] for i in indices])
         corners = [(r[0], r[1]) for r in rois]
         sizes = [(r[2], r[3]) for r in rois]
         if blender is None:

@@ -183,6 +183,10 @@ int mis_wave_correct(double* rmats, int n, int kind);
 /* ---------------------------------------------------------------- warp ---------------------- */
 /* warper->warpRoi(sz, K, R) -- replaces image_stitching.cpp:1138 (K, R: 3x3 f32 row-major) */
 int mis_warp_roi(float scale, int src_width, int src_height, const float K[9], const float R[9], MisRect* roi);
+/* the loop `for i: sizes[i], corners[i] = warper->warpRoi(sz, K_i, R_i)` of image_stitching.cpp:1119-1140 in one call:
+ * the 2(W+H) border projections of every frame run in one small kernel (one workgroup per frame) instead of on the host;
+ * Ks, Rs: n x 9 floats.  Same rois as n calls of mis_warp_roi (nothing is cached between calls in either form). */
+int mis_warp_roi_batch(MisContext* ctx, float scale, int src_width, int src_height, int n, const float* Ks, const float* Rs, MisRect* rois);
 /* warper->warp(src, K, R, interp, border, dst) -- replaces image_stitching.cpp:985, :988, :1154, :1159.
  * u8 source with 1 or 3 channels; (INTER_LINEAR, BORDER_REFLECT) or (INTER_NEAREST, BORDER_CONSTANT). */
 int mis_warp_spherical(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9], int interp,
@@ -191,6 +195,10 @@ int mis_warp_spherical(MisContext* ctx, const MisImage* src, float scale, const 
  * (NEAREST, CONSTANT of an all-255 mask) in one pass -- replaces :1154 + :1157-1159 + :1164. */
 int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
                              MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl);
+/* the same with the roi already known (the value mis_warp_roi / mis_warp_roi_batch returned for exactly these scale, K, R and
+ * source size): skips the border walk the reference repeats inside warp() -- the compose loop's form (:1138 then :1154). */
+int mis_warp_spherical_fused_roi(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
+                                 const MisRect* roi, MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl);
 /* measurement aid: the same warp with the main kernel launched `repeats` times back to back on the context's
  * stream between two HIP events; *avg_us = average kernel duration (bench.py's roofline leg: no host gaps). */
 int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
@@ -263,6 +271,9 @@ int mis_blender_blend(MisBlender* b, MisImage* dst_s16x3, MisImage* dst_mask);
  * at `scale` into library-owned device blocks of size rois[i] (= mis_warp_roi of the frame), then feed -- replaces
  * image_stitching.cpp:1154-1164 and :1218 for every image of the loop at :1086.  Same results as the single calls. */
 int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois);
+/* the rectangle of the (padded) panorama a feed of a width x height frame at `tl` touches: MultiBandBlender::feed's tile
+ * (frame + 3 * 2^bands margin, clipped, aligned to 2^bands); P_b of SURVEY 8(d) = tile.width * tile.height */
+int mis_blender_feed_rect(const MisBlender* b, int width, int height, MisPoint tl, MisRect* tile);
 /* accumulated pyramid level before blend() (host copies, parity tests / multi-GPU reduction hooks) */
 int mis_blender_level_info(const MisBlender* b, int level, int* width, int* height, void** lap_dev, void** weight_dev);
 

@@ -540,27 +540,36 @@ static void invert3(const double* H, double* I) {
 
 int mo_match_all_pairs(const MoFeatures* feats, int n, const MoMatchParams* p, MoMatchesInfo* out) {
     for (int i = 0; i < n * n; i++) { memset(&out[i], 0, sizeof(out[i])); out[i].src_img_idx = out[i].dst_img_idx = -1; }
+    /* pairs are independent: they run under one parallel loop, as FeaturesMatcher::operator() runs them under
+     * parallel_for_ (matchers.cpp MatchPairsBody); the 2-NN loops inside a pair then run serially (no nested teams) */
+    int npairs = 0;
+    int* pi = (int*)malloc(sizeof(int) * (size_t)(n * n + 1) * 2);
     for (int i = 0; i < n; i++)
-        for (int j = i + 1; j < n; j++) {
-            if (feats[i].n <= 0 || feats[j].n <= 0) continue;
-            MoMatchesInfo* a = &out[i * n + j];
-            mo_match_pair(&feats[i], &feats[j], p, a);
-            a->src_img_idx = i; a->dst_img_idx = j;
-            MoMatchesInfo* b = &out[j * n + i];
-            *b = *a;
-            b->src_img_idx = j; b->dst_img_idx = i;
-            b->matches = (MoDMatch*)malloc(sizeof(MoDMatch) * (size_t)(a->n_matches + 1));
-            for (int k = 0; k < a->n_matches; k++) {
-                b->matches[k] = a->matches[k];
-                b->matches[k].query_idx = a->matches[k].train_idx;
-                b->matches[k].train_idx = a->matches[k].query_idx;
-            }
-            if (a->inliers_mask) {
-                b->inliers_mask = (uint8_t*)malloc((size_t)(a->n_matches + 1));
-                memcpy(b->inliers_mask, a->inliers_mask, (size_t)a->n_matches);
-            }
-            if (a->has_H) invert3(a->H, b->H);
+        for (int j = i + 1; j < n; j++)
+            if (feats[i].n > 0 && feats[j].n > 0) { pi[2 * npairs] = i; pi[2 * npairs + 1] = j; npairs++; }
+    int k;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (k = 0; k < npairs; k++) {
+        const int i = pi[2 * k], j = pi[2 * k + 1];
+        MoMatchesInfo* a = &out[i * n + j];
+        mo_match_pair(&feats[i], &feats[j], p, a);
+        a->src_img_idx = i; a->dst_img_idx = j;
+        MoMatchesInfo* b = &out[j * n + i];
+        *b = *a;
+        b->src_img_idx = j; b->dst_img_idx = i;
+        b->matches = (MoDMatch*)malloc(sizeof(MoDMatch) * (size_t)(a->n_matches + 1));
+        for (int q = 0; q < a->n_matches; q++) {
+            b->matches[q] = a->matches[q];
+            b->matches[q].query_idx = a->matches[q].train_idx;
+            b->matches[q].train_idx = a->matches[q].query_idx;
         }
+        if (a->inliers_mask) {
+            b->inliers_mask = (uint8_t*)malloc((size_t)(a->n_matches + 1));
+            memcpy(b->inliers_mask, a->inliers_mask, (size_t)a->n_matches);
+        }
+        if (a->has_H) invert3(a->H, b->H);
+    }
+    free(pi);
     return 0;
 }
 

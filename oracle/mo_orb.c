@@ -33,7 +33,8 @@ void mo_orb_default_params(MoOrbParams* p) {
     p->first_level = 0; p->wta_k = 2; p->score_type = 0; p->patch_size = 40; p->fast_threshold = 20;
 }
 
-/* ---- cvtColor BGR2GRAY u8, Q14 coefficients ---- */
+/* ---- cvtColor BGR2GRAY u8 (imgproc color_rgb.simd.hpp RGB2Gray<uchar>): the 15-bit coefficients BY15 3735, GY15 19235,
+ * RY15 9798 with gray_shift 15 of OpenCV 4.x (SURVEY A.1 lists the older Q14 triple as the alternative; recalled, unpinned) ---- */
 void mo_bgr2gray(const uint8_t* bgr, int w, int h, size_t stride, uint8_t* gray, size_t gstride) {
     int y;
 #pragma omp parallel for schedule(static)
@@ -41,7 +42,7 @@ void mo_bgr2gray(const uint8_t* bgr, int w, int h, size_t stride, uint8_t* gray,
         const uint8_t* s = bgr + (size_t)y * stride;
         uint8_t* d = gray + (size_t)y * gstride;
         for (int x = 0; x < w; x++)
-            d[x] = (uint8_t)((s[3 * x] * 1868 + s[3 * x + 1] * 9617 + s[3 * x + 2] * 4899 + (1 << 13)) >> 14);
+            d[x] = (uint8_t)((s[3 * x] * 3735 + s[3 * x + 1] * 19235 + s[3 * x + 2] * 9798 + (1 << 14)) >> 15);
     }
 }
 

@@ -97,7 +97,7 @@ def test_trig_polynomials(oracle_mod):
         assert abs(L.mo_log_d(x) - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))
 
 
-def test_gray_q14_and_gauss_kernel(oracle_mod):
+def test_gray_q15_and_gauss_kernel(oracle_mod):
     o = oracle_mod
     img = np.zeros((1, 4, 3), np.uint8)
     img[0, 0] = (255, 255, 255)
@@ -105,7 +105,7 @@ def test_gray_q14_and_gauss_kernel(oracle_mod):
     img[0, 2] = (0, 255, 0)
     img[0, 3] = (0, 0, 255)
     g = o.bgr2gray(img)[0]
-    assert list(g) == [255, (255 * 1868 + 8192) >> 14, (255 * 9617 + 8192) >> 14, (255 * 4899 + 8192) >> 14]
+    assert list(g) == [255, (255 * 3735 + 16384) >> 15, (255 * 19235 + 16384) >> 15, (255 * 9798 + 16384) >> 15]
     assert o.gauss7_kernel_q8() == [18, 34, 48, 56, 48, 34, 18]
 
 
