@@ -57,14 +57,40 @@ struct FrameView {
     int tw, th;           // padded tile size
 };
 
+// index maps with the common case (at most one fold) branch-free; anything further out takes the general closed form (whose
+// modulo by a run-time length costs ~35 instructions: the border tiles of a 4K feed spent most of their time in it)
+__device__ __forceinline__ int reflect101_near(int p, int len) {
+    if ((unsigned)(p + len - 1) < (unsigned)(3 * len - 2)) { const int a = p < 0 ? -p : p; return a >= len ? 2 * len - 2 - a : a; }
+    return mis_reflect101(p, len);
+}
+__device__ __forceinline__ int reflect_near(int p, int len) {
+    if ((unsigned)(p + len) < (unsigned)(3 * len)) return mis_reflect1(p, len);
+    return mis_reflect(p, len);
+}
+
 __device__ __forceinline__ void view_px(const FrameView& v, int tx, int ty, int* c) {
-    const int16_t* p = v.img + (size_t)mis_reflect(ty - v.top, v.h) * v.istride + 3 * (size_t)mis_reflect(tx - v.left, v.w);
+    const int16_t* p = v.img + (size_t)reflect_near(ty - v.top, v.h) * v.istride + 3 * (size_t)reflect_near(tx - v.left, v.w);
     c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
 }
 __device__ __forceinline__ float view_w(const FrameView& v, int tx, int ty) {
     int x = tx - v.left, y = ty - v.top;
     if ((unsigned)x >= (unsigned)v.w || (unsigned)y >= (unsigned)v.h) return 0.f;
     return (float)v.mask[(size_t)y * v.mstride + x] * (float)(1. / 255.);
+}
+
+// ---- 16SC3 pixel access: one 8-byte load per pixel ----
+// Pixel p of a row is shorts 3p .. 3p+2: with a 4-byte aligned row start they lie inside the 8 bytes at short (3p & ~1),
+// shifted by one short when p is odd.  `ok` = the row start is 4-byte aligned and reading one short past the pixel stays inside
+// the allocation; otherwise three 2-byte loads.
+__device__ __forceinline__ void load_px3(const int16_t* __restrict__ row, int p, bool ok, int* c) {
+    if (ok) {
+        const int e = 3 * p;
+        const uint2 d = *reinterpret_cast<const uint2*>(row + (e & ~1));
+        const unsigned long long q = (((unsigned long long)d.y << 32) | d.x) >> (16 * (e & 1));
+        c[0] = (int)(int16_t)(unsigned short)q; c[1] = (int)(int16_t)(unsigned short)(q >> 16); c[2] = (int)(int16_t)(unsigned short)(q >> 32);
+    } else {
+        c[0] = row[3 * p]; c[1] = row[3 * p + 1]; c[2] = row[3 * p + 2];
+    }
 }
 
 // ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101 ----
@@ -88,8 +114,8 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
                                                             int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh) {
     __shared__ __attribute__((aligned(4))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
     __shared__ float wt[PD_SH * PD_SW];
-    __shared__ int hbuf[PD_SH * PD_W * 3];
-    __shared__ float hw[PD_SH * PD_W];
+    __shared__ int vbuf[PD_H * PDV_ROW_DW];   // vertical sums: 16 rows of packed u16 pairs (fast path) or 8 rows of one int per short
+    unsigned wide_bits = 0;   // bits of the staged shorts outside 0..255 (0 for a converted 8-bit image: the packed 16-bit path is exact)
     const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
     const int sw = FROM_VIEW ? v.tw : psw, sh = FROM_VIEW ? v.th : psh;
     const int tx0 = 2 * x0 - 2, ty0 = 2 * y0 - 2;                    // tile coordinates of the footprint's corner
@@ -119,7 +145,7 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
 #pragma unroll
         for (int k = 0; k < NI; k++) {
             const int i = t + 256 * k;
-            if (i < PD_SH * PDV_ROW_DW) reinterpret_cast<unsigned*>(tile)[i] = ri[k];
+            if (i < PD_SH * PDV_ROW_DW) { reinterpret_cast<unsigned*>(tile)[i] = ri[k]; wide_bits |= ri[k]; }
         }
 #pragma unroll
         for (int k = 0; k < NM; k++) {
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
 #pragma unroll
         for (int k = 0; k < NI; k++) {
             const int i = t + 256 * k;
-            if (i < PD_SH * PDV_ROW_DW) reinterpret_cast<unsigned*>(tile)[i] = ri[k];
+            if (i < PD_SH * PDV_ROW_DW) { reinterpret_cast<unsigned*>(tile)[i] = ri[k]; wide_bits |= ri[k]; }
         }
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -163,57 +189,139 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
         }
     } else {
         toff = 0;
-        for (int i = t; i < PD_SH * PD_SW; i += 256) {
+        for (int i = t; i < PD_SH * (PDV_ROW_DW * 2 - 3 * PD_SW); i += 256) {   // the slack shorts behind the 67 pixels of a row
+            const int r = i / (PDV_ROW_DW * 2 - 3 * PD_SW), c = i - r * (PDV_ROW_DW * 2 - 3 * PD_SW);
+            tile[(size_t)r * (PDV_ROW_DW * 2) + 3 * PD_SW + c] = 0;
+        }
+        // border tiles (40 % of a 4K frame's padded tile): all loads of a thread before its first LDS store, as above
+        constexpr int NG = (PD_SH * PD_SW + 255) / 256;
+        int16_t gp[NG][3];
+        float gw[NG];
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int i = min(t + 256 * k, PD_SH * PD_SW - 1);
             const int r = i / PD_SW, c = i - r * PD_SW;
-            const int sy = mis_reflect101(ty0 + r, sh), sx = mis_reflect101(tx0 + c, sw);
-            int px[3];
-            if (FROM_VIEW) view_px(v, sx, sy, px);
-            else { const int16_t* q = src + ((size_t)sy * sw + sx) * 3; px[0] = q[0]; px[1] = q[1]; px[2] = q[2]; }
-            int16_t* o = tile + (size_t)r * (PDV_ROW_DW * 2) + 3 * c;
-            o[0] = (int16_t)px[0]; o[1] = (int16_t)px[1]; o[2] = (int16_t)px[2];
-            wt[i] = FROM_VIEW ? view_w(v, sx, sy) : wsrc[(size_t)sy * sw + sx];
+            const int sy = reflect101_near(ty0 + r, sh), sx = reflect101_near(tx0 + c, sw);
+            if (FROM_VIEW) {
+                const int iy = sy - v.top, ix = sx - v.left;
+                const int16_t* q = v.img + (size_t)reflect_near(iy, v.h) * v.istride + 3 * (size_t)reflect_near(ix, v.w);
+                gp[k][0] = q[0]; gp[k][1] = q[1]; gp[k][2] = q[2];
+                const bool in = (unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h;
+                gw[k] = in ? (float)v.mask[(size_t)(in ? iy : 0) * v.mstride + (in ? ix : 0)] : -1.f;
+            } else {
+                const int16_t* q = src + ((size_t)sy * sw + sx) * 3;
+                gp[k][0] = q[0]; gp[k][1] = q[1]; gp[k][2] = q[2];
+                gw[k] = wsrc[(size_t)sy * sw + sx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int i = t + 256 * k;
+            if (i < PD_SH * PD_SW) {
+                const int r = i / PD_SW, c = i - r * PD_SW;
+                int16_t* o = tile + (size_t)r * (PDV_ROW_DW * 2) + 3 * c;
+                o[0] = gp[k][0]; o[1] = gp[k][1]; o[2] = gp[k][2];
+                wide_bits |= (unsigned)(unsigned short)gp[k][0] | (unsigned)(unsigned short)gp[k][1] | (unsigned)(unsigned short)gp[k][2];
+                wt[i] = FROM_VIEW ? (gw[k] < 0.f ? 0.f : gw[k] * (float)(1. / 255.)) : gw[k];
+            }
         }
     }
-    __syncthreads();
-    // horizontal pass: one (row, column) of the half-resolution grid per item, all three channels and the weight.  The five
-    // source pixels are 15 contiguous shorts of the LDS row: eight aligned dword reads, halves picked at compile time (toff,
-    // the only run-time part of the alignment, is uniform in the block).
-    static_assert(PD_W == 32, "item -> (row, column) uses shifts");
-    for (int item = t; item < PD_SH * PD_W; item += 256) {
-        const int r = item >> 5, x = item & 31;
-        const unsigned* q = reinterpret_cast<const unsigned*>(tile) + (size_t)r * PDV_ROW_DW + 3 * x;   // shorts 6 x .. 6 x + 15 of the row
-        unsigned wd[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) wd[k] = q[k];
-        int px[15];
+    // every short of the footprint in 0..255 (block-uniform): vertical sums <= 4080 and the full 5 x 5 sums <= 65280 fit 16 bits,
+    // so the image goes through packed 16-bit arithmetic on the raw dwords; any other data takes 32-bit sums
+    const bool small = __syncthreads_or((int)(wide_bits & 0xFF00FF00u)) == 0;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned* tw32 = reinterpret_cast<const unsigned*>(tile);
+    // a thread owns two adjacent outputs (x even) of one row: 7 source pixels = 21 shorts of the row of vertical sums
+    const int j = t >> 4, x = 2 * (t & 15);
+    const int gx = x0 + x, gy = y0 + j;
+    int o[2][3];
+    if (small) {
+        // pass 1 (image, vertical first -- integer sums, the pass order is free): V[j][.] = 6 r[2j+2] + 4 (r[2j+1] + r[2j+3]) + r[2j] + r[2j+4]
+        for (int item = t; item < PD_H * PDV_ROW_DW; item += 256) {
+            const int jj = item / PDV_ROW_DW, d = item - jj * PDV_ROW_DW;
+            const unsigned* q = tw32 + (size_t)(2 * jj) * PDV_ROW_DW + d;
+            const us2 r0 = __builtin_bit_cast(us2, q[0]), r1 = __builtin_bit_cast(us2, q[PDV_ROW_DW]), r2 = __builtin_bit_cast(us2, q[2 * PDV_ROW_DW]),
+                      r3 = __builtin_bit_cast(us2, q[3 * PDV_ROW_DW]), r4 = __builtin_bit_cast(us2, q[4 * PDV_ROW_DW]);
+            const us2 sum = r2 * (unsigned short)6 + (r1 + r3) * (unsigned short)4 + (r0 + r4);
+            vbuf[item] = (int)__builtin_bit_cast(unsigned, sum);
+        }
+        __syncthreads();
+        // pass 2 (horizontal) on the packed sums
+        const unsigned* q = reinterpret_cast<const unsigned*>(vbuf) + (size_t)j * PDV_ROW_DW + 3 * x;   // shorts 6 x .. (+ toff)
+        unsigned D[11];
         if (toff) {
+            unsigned e[12];
 #pragma unroll
-            for (int k = 0; k < 15; k++) px[k] = (int)(int16_t)(wd[(k + 1) >> 1] >> (16 * ((k + 1) & 1)));
+            for (int k = 0; k < 12; k++) e[k] = q[k];
+#pragma unroll
+            for (int k = 0; k < 11; k++) D[k] = __builtin_amdgcn_alignbit(e[k + 1], e[k], 16);
         } else {
 #pragma unroll
-            for (int k = 0; k < 15; k++) px[k] = (int)(int16_t)(wd[k >> 1] >> (16 * (k & 1)));
+            for (int k = 0; k < 11; k++) D[k] = q[k];
         }
-        int* hb = hbuf + item * 3;
+        // pixel P_k = shorts 3k .. 3k+2 of D: even pixels start on a dword ((B,G) = D[3k/2], R = low half of the next), odd pixels
+        // one short later (B = high half of D[(3k-1)/2], (G,R) = the next dword)
 #pragma unroll
-        for (int c = 0; c < 3; c++) hb[c] = px[6 + c] * 6 + (px[3 + c] + px[9 + c]) * 4 + px[c] + px[12 + c];
-        const float* sw_ = wt + r * PD_SW + 2 * x;
-        hw[item] = ((sw_[2] * 6.f + (sw_[1] + sw_[3]) * 4.f) + sw_[0]) + sw_[4];
+        for (int p = 0; p < 2; p++) {
+            const int b = 3 * p;     // dword of pixel 2p
+            const us2 eBG = __builtin_bit_cast(us2, D[b + 3]) * (unsigned short)6 + (__builtin_bit_cast(us2, D[b]) + __builtin_bit_cast(us2, D[b + 6]));
+            const us2 eR = __builtin_bit_cast(us2, D[b + 4]) * (unsigned short)6 + (__builtin_bit_cast(us2, D[b + 1]) + __builtin_bit_cast(us2, D[b + 7]));   // low half
+            const us2 oB = __builtin_bit_cast(us2, D[b + 1]) + __builtin_bit_cast(us2, D[b + 4]);      // high half: B of the odd pixels
+            const us2 oGR = __builtin_bit_cast(us2, D[b + 2]) + __builtin_bit_cast(us2, D[b + 5]);     // (G, R) of the odd pixels
+            const us2 oBG = __builtin_bit_cast(us2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, oGR), __builtin_bit_cast(unsigned, oB), 16));
+            const us2 hBG = ((eBG + oBG * (unsigned short)4) + (unsigned short)128) >> (unsigned short)8;
+            const unsigned hR = (((unsigned)eR.x + 4u * (unsigned)oGR.y) + 128u) >> 8;
+            o[p][0] = hBG.x; o[p][1] = hBG.y; o[p][2] = (int)(hR & 0xffffu);
+        }
+    } else {
+        // any 16SC3 data: 32-bit vertical sums, one int per short; vbuf holds 8 rows of them, so two rounds
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();
+            for (int item = t; item < (PD_H / 2) * PDV_ROW_DW * 2; item += 256) {
+                const int jj = item / (PDV_ROW_DW * 2), c = item - jj * (PDV_ROW_DW * 2);
+                const int16_t* q = tile + (size_t)(2 * (jj + 8 * half)) * (PDV_ROW_DW * 2) + c;
+                vbuf[item] = (int)q[2 * PDV_ROW_DW * 2] * 6 + ((int)q[PDV_ROW_DW * 2] + (int)q[3 * PDV_ROW_DW * 2]) * 4 + (int)q[0] + (int)q[4 * PDV_ROW_DW * 2];
+            }
+            __syncthreads();
+            if ((j >> 3) == half) {
+                const int* q = vbuf + (size_t)(j & 7) * (PDV_ROW_DW * 2) + toff + 6 * x;
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int* sp = q + 6 * p + c;
+                        o[p][c] = (sp[6] * 6 + (sp[3] + sp[9]) * 4 + sp[0] + sp[12] + 128) >> 8;
+                    }
+            }
+        }
     }
-    __syncthreads();
-    // vertical pass: one output pixel per item
-    for (int item = t; item < PD_H * PD_W; item += 256) {
-        const int y = item >> 5, x = item & 31;
-        if (x0 + x >= dw || y0 + y >= dh) continue;
-        const int* p = hbuf + (2 * y) * (PD_W * 3) + 3 * x;
-        int16_t* o = dst + ((size_t)(y0 + y) * dw + x0 + x) * 3;
+    // weights: horizontal sums of the five source rows of the output row, then the vertical sum (f32: the reference's order)
+    float ow[2];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int acc = p[2 * PD_W * 3 + c] * 6 + (p[PD_W * 3 + c] + p[3 * PD_W * 3 + c]) * 4 + p[c] + p[4 * PD_W * 3 + c];
-            o[c] = (int16_t)((acc + 128) >> 8);
+    for (int p = 0; p < 2; p++) {
+        float hr[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const float* sw_ = wt + (2 * j + r) * PD_SW + 2 * (x + p);
+            hr[r] = ((sw_[2] * 6.f + (sw_[1] + sw_[3]) * 4.f) + sw_[0]) + sw_[4];
         }
-        const float* pw_ = hw + (2 * y) * PD_W + x;
-        const float rr = ((pw_[2 * PD_W] * 6.f + (pw_[PD_W] + pw_[3 * PD_W]) * 4.f) + pw_[0]) + pw_[4 * PD_W];
-        wdst[(size_t)(y0 + y) * dw + x0 + x] = rr * (1.f / 256.f);
+        ow[p] = (((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4]) * (1.f / 256.f);
+    }
+    if (gx >= dw || gy >= dh) return;
+    const size_t e = (size_t)gy * dw + gx;
+    int16_t* d = dst + e * 3;
+    if (gx + 1 < dw && (dw & 1) == 0) {      // even level width: the six shorts start on a dword
+        uint3 pk;
+        pk.x = (unsigned)(unsigned short)o[0][0] | ((unsigned)(unsigned short)o[0][1] << 16);
+        pk.y = (unsigned)(unsigned short)o[0][2] | ((unsigned)(unsigned short)o[1][0] << 16);
+        pk.z = (unsigned)(unsigned short)o[1][1] | ((unsigned)(unsigned short)o[1][2] << 16);
+        *reinterpret_cast<uint3*>(d) = pk;
+        *reinterpret_cast<float2*>(wdst + e) = make_float2(ow[0], ow[1]);
+    } else {
+        d[0] = (int16_t)o[0][0]; d[1] = (int16_t)o[0][1]; d[2] = (int16_t)o[0][2];
+        wdst[e] = ow[0];
+        if (gx + 1 < dw) { d[3] = (int16_t)o[1][0]; d[4] = (int16_t)o[1][1]; d[5] = (int16_t)o[1][2]; wdst[e + 1] = ow[1]; }
     }
 }
 
@@ -246,8 +354,8 @@ __device__ __forceinline__ void pyr_up_at(const int16_t* c, int cw, int ch, int 
 }
 
 // pyrUp of a coarse level at the 2 x 2 fine block of coarse pixel (X, Y): up[k][c], k = (fy & 1) * 2 + (fx & 1).  The four pixels share
-// the 3 x 3 coarse neighbourhood (27 loads per block instead of up to 27 per pixel); per pixel the sums are those of pyr_up_at.
-__device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int cw, int ch, int X, int Y, int (*up)[3]) {
+// the 3 x 3 coarse neighbourhood (9 pixel loads per block); per pixel the sums are those of pyr_up_at.  `ok`: see load_px3.
+__device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int cw, int ch, int X, int Y, bool ok, int (*up)[3]) {
     const int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
     const int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
     const int rows[3] = {ym, Y, yp};
@@ -255,11 +363,12 @@ __device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int 
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int16_t* p = c + (size_t)rows[r] * cw * 3;
+        int a[3], b[3], d[3];
+        load_px3(p, xm, ok, a); load_px3(p, X, ok, b); load_px3(p, xp, ok, d);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            const int a = p[3 * xm + q], b = p[3 * X + q], d = p[3 * xp + q];
-            he[r][q] = a + b * 6 + d;
-            ho[r][q] = (b + d) * 4;
+            he[r][q] = a[q] + b[q] * 6 + d[q];
+            ho[r][q] = (b[q] + d[q]) * 4;
         }
     }
 #pragma unroll
@@ -297,46 +406,15 @@ __global__ __launch_bounds__(256) void laplace_accumulate_kernel(FrameView v, co
     dwgt[o] += w;
 }
 
-// Level 0 of a feed with at least one band: a thread owns a 2 x 2 block of the frame's tile (its size is a multiple of 2^bands).
-// The four pixels share the 3 x 3 coarse neighbourhood of pyrUp, so the block costs 27 coarse loads instead of up to 27 per
-// pixel; the arithmetic per pixel is that of laplace_accumulate_kernel / pyr_up_at (integers, the same sums).
-__global__ __launch_bounds__(256) void laplace_accumulate_view2x2_kernel(FrameView v, int tw, int th, const int16_t* __restrict__ coarse, int cw, int ch,
-                                                                         int16_t* __restrict__ dlap, float* __restrict__ dwgt, int pw, int x_tl, int y_tl) {
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);   // block index = coarse pixel
-    if (2 * X >= tw || 2 * Y >= th) return;
-    float w[4];
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { w[k] = view_w(v, 2 * X + (k & 1), 2 * Y + (k >> 1)); any |= w[k] != 0.f; }
-    if (!any) return;   // exact no-op contributions
-    int up[4][3];
-    pyr_up_block(coarse, cw, ch, X, Y, up);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (w[k] == 0.f) continue;
-        const int fx = 2 * X + (k & 1), fy = 2 * Y + (k >> 1);
-        int px[3];
-        view_px(v, fx, fy, px);
-        const size_t o = (size_t)(y_tl + fy) * pw + (x_tl + fx);
-        int16_t* d = dlap + o * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int lap = sat_s16(px[c] - up[k][c]);
-            d[c] = (int16_t)(d[c] + (int16_t)((float)lap * w[k]));
-        }
-        dwgt[o] += w[k];
-    }
-}
-
 // ---- the small levels of a feed in two launches ----
 // From some level on a frame's pyramid has a few thousand pixels and every per-level launch costs more in launch-to-launch
 // latency than in work (a 4K frame at 8 bands: 15 launches of ~6 us for levels 4..8).  feed_tail_build_kernel builds all
 // the remaining Gaussian levels in ONE workgroup (a level depends on the previous one: __syncthreads between them;
-// the data goes through global memory, which a workgroup sees coherently), feed_tail_accumulate_kernel adds the
+// the data goes through global memory, which a workgroup sees coherently), feed_accumulate_kernel adds the
 // Laplacians of all those levels to the panorama in one grid.  Arithmetic: that of the per-level kernels.
 struct FeedTail {
     int first, nb;                                    // levels first + 1 .. nb are built by feed_tail_build_kernel (first >= 1; first > nb: none)
-    int acc_first;                                    // levels acc_first .. nb are accumulated by feed_tail_accumulate_kernel
+    int acc_first;                                    // levels acc_first .. nb are accumulated by feed_accumulate_kernel
     int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1]; // tile size per level
     int16_t* G[MIS_MAX_BANDS + 1];                    // Gaussian levels of the frame (scratch), G[first] already built
     float* W[MIS_MAX_BANDS + 1];
@@ -354,7 +432,7 @@ __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedTail t) {
             const int y = i / dw, x = i - y * dw;
             int xi[5], yi[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) { xi[k] = mis_reflect101(2 * x - 2 + k, sw); yi[k] = mis_reflect101(2 * y - 2 + k, sh); }
+            for (int k = 0; k < 5; k++) { xi[k] = reflect101_near(2 * x - 2 + k, sw); yi[k] = reflect101_near(2 * y - 2 + k, sh); }
             int acc[3] = {0, 0, 0};
             float hr[5];
 #pragma unroll
@@ -374,36 +452,81 @@ __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedTail t) {
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void feed_tail_accumulate_kernel(FeedTail t) {
+// All levels of a feed in one grid (level 0 reads the frame view).  Below the last level a thread owns a 2 x 2 block (tile sizes
+// are even there): the four pixels share pyrUp's 3 x 3 coarse neighbourhood, and a row of the block is 12 contiguous bytes of
+// 16SC3 + 8 of f32 in the panorama pyramids -- read, modified and written as whole dwords (even level widths).  Pixels whose
+// weight is exactly 0 contribute nothing (`x + (short)(v * 0) = x`, `w + 0 = w`): blocks of four zero weights are skipped.
+__global__ __launch_bounds__(256) void feed_accumulate_kernel(FeedTail t, FrameView v, int view_ok) {
     int l = t.acc_first;
     while (l < t.nb && (int)blockIdx.x >= t.blk_off[l + 1]) l++;
     const int tw = t.tw[l], th = t.th[l];
     const int i = ((int)blockIdx.x - t.blk_off[l]) * 256 + threadIdx.x;
     if (l < t.nb) {
-        // a thread owns a 2 x 2 block (tile sizes below the last level are even): the four pixels share pyrUp's neighbourhood
         const int cw = t.tw[l + 1], ch = t.th[l + 1];
         if (i >= cw * ch) return;
         const int Y = i / cw, X = i - Y * cw;
+        const bool view = l == 0;
         float w[4];
-        bool any = false;
+        int px[4][3];
+        // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
+        const int ix0 = 2 * X - v.left, iy0 = 2 * Y - v.top;
+        if (view) {
+            // weights = mask / 255 inside the image, 0 outside (copyMakeBorder CONSTANT)
 #pragma unroll
-        for (int k = 0; k < 4; k++) { w[k] = t.W[l][(size_t)(2 * Y + (k >> 1)) * tw + 2 * X + (k & 1)]; any |= w[k] != 0.f; }
-        if (!any) return;   // exact no-op contributions
-        int up[4][3];
-        pyr_up_block(t.G[l + 1], cw, ch, X, Y, up);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (w[k] == 0.f) continue;
-            const int fx = 2 * X + (k & 1), fy = 2 * Y + (k >> 1);
-            const int16_t* p = t.G[l] + ((size_t)fy * tw + fx) * 3;
-            const size_t o = (size_t)(t.y_tl[l] + fy) * t.pw[l] + (t.x_tl[l] + fx);
-            int16_t* d = t.lap[l] + o * 3;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int lap = sat_s16(p[c] - up[k][c]);
-                d[c] = (int16_t)(d[c] + (int16_t)((float)lap * w[k]));
+            for (int k = 0; k < 4; k++) {
+                const int ix = ix0 + (k & 1), iy = iy0 + (k >> 1);
+                w[k] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)v.mask[(unsigned)iy * (unsigned)v.mstride + (unsigned)ix] * (float)(1. / 255.) : 0.f;
             }
-            t.wgt[l][o] += w[k];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const float2 ww = *reinterpret_cast<const float2*>(t.W[l] + (size_t)(2 * Y + r) * tw + 2 * X);   // tw even, 2 X even
+                w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
+            }
+        }
+        if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) return;   // exact no-op contributions
+        int up[4][3];
+        pyr_up_block(t.G[l + 1], cw, ch, X, Y, (cw & 1) == 0, up);
+        if (view) {
+            // a pixel with a non-zero weight lies inside the image; the others contribute nothing, so their (reflected) values
+            // are never needed: clamp their coordinates instead of reflecting them
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ix = min(max(ix0 + (k & 1), 0), v.w - 1), iy = min(max(iy0 + (k >> 1), 0), v.h - 1);
+                load_px3(v.img + (size_t)iy * v.istride, ix, view_ok && (iy + 1 < v.h || v.istride >= (size_t)3 * v.w + 1), px[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) load_px3(t.G[l] + (size_t)(2 * Y + (k >> 1)) * tw * 3, 2 * X + (k & 1), true, px[k]);
+        }
+        const int pw = t.pw[l];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float w0 = w[2 * r], w1 = w[2 * r + 1];
+            if (w0 == 0.f && w1 == 0.f) continue;
+            const size_t o = (size_t)(t.y_tl[l] + 2 * Y + r) * pw + (t.x_tl[l] + 2 * X);
+            int add[6];
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) add[3 * q + c] = (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * w[2 * r + q]);
+            if ((pw & 1) == 0) {   // x_tl + 2 X is even: the six shorts start on a dword
+                uint3* dp = reinterpret_cast<uint3*>(t.lap[l] + o * 3);
+                uint3 d = *dp;
+                d.x = ((d.x + (unsigned)add[0]) & 0xffffu) | ((d.x + ((unsigned)add[1] << 16)) & 0xffff0000u);
+                d.y = ((d.y + (unsigned)add[2]) & 0xffffu) | ((d.y + ((unsigned)add[3] << 16)) & 0xffff0000u);
+                d.z = ((d.z + (unsigned)add[4]) & 0xffffu) | ((d.z + ((unsigned)add[5] << 16)) & 0xffff0000u);
+                *dp = d;
+                float2* wp = reinterpret_cast<float2*>(t.wgt[l] + o);
+                float2 ws = *wp;
+                ws.x += w0; ws.y += w1;
+                *wp = ws;
+            } else {
+                int16_t* d = t.lap[l] + o * 3;
+#pragma unroll
+                for (int q = 0; q < 6; q++) d[q] = (int16_t)(d[q] + add[q]);
+                t.wgt[l][o] += w0; t.wgt[l][o + 1] += w1;
+            }
         }
         return;
     }
@@ -449,7 +572,7 @@ __global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ 
     const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= cw || Y >= ch) return;
     int up[4][3];
-    pyr_up_block(coarse, cw, ch, X, Y, up);
+    pyr_up_block(coarse, cw, ch, X, Y, (cw & 1) == 0, up);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const size_t o = (size_t)(2 * Y + (k >> 1)) * fw + 2 * X + (k & 1);
@@ -606,6 +729,7 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
     int first = nb + 1;
     for (int i = nb; i >= 2 && (size_t)tw[i] * th[i] <= FEED_TAIL_PIXELS; i--) first = i;
     if (first >= nb) first = nb + 1;     // a single level is not worth it
+    const int view_ok = ((uintptr_t)v.img & 3) == 0 && (v.istride & 1) == 0;   // rows of the frame start on a dword: 8-byte pixel loads
     for (int i = 0; i < nb; i++) {
         if (i >= first) break;           // G(first + 1 ..) are built by feed_tail_build_kernel
         dim3 gp((tw[i + 1] + PD_W - 1) / PD_W, (th[i + 1] + PD_H - 1) / PD_H);
@@ -616,34 +740,26 @@ int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, i
                                tw[i + 1], th[i + 1]);
         }
     }
-    int y_tl = tny - R.y, x_tl = tnx - R.x, y_br = bny - R.y, x_br = bnx - R.x;
-    // level 0 reads the frame view; every other level goes through one multi-level grid (feed_tail_accumulate_kernel)
+    int y_tl = tny - R.y, x_tl = tnx - R.x;
+    if (nb == 0) {
+        hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), grid2d(width, height), blk, 0, ctx->stream, v, nullptr, nullptr, width, height, (const int16_t*)nullptr, 0, 0,
+                           b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
+        MIS_HIP(ctx, hipGetLastError());
+        return MIS_OK;
+    }
+    // every level goes through one multi-level grid (feed_accumulate_kernel; level 0 reads the frame view)
     FeedTail ft;
-    ft.first = first; ft.nb = nb; ft.acc_first = 1;
+    ft.first = first; ft.nb = nb; ft.acc_first = 0;
     for (int i = 0; i <= nb; i++) {
-        if (i >= 1) {
-            ft.tw[i] = tw[i]; ft.th[i] = th[i]; ft.G[i] = G(i); ft.W[i] = W(i); ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
-            ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
-            x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
-            continue;
-        }
-        const int rw = x_br - x_tl, rh = y_br - y_tl;  // equals tw[0] x th[0] (tile corners are multiples of 2^nb)
-        const dim3 g = grid2d(rw, rh);
-        if (nb > 0)
-            hipLaunchKernelGGL(laplace_accumulate_view2x2_kernel, grid2d((rw + 1) / 2, (rh + 1) / 2), blk, 0, ctx->stream, v, rw, rh, (const int16_t*)G(1), tw[1], th[1],
-                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
-        else
-            hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), g, blk, 0, ctx->stream, v, nullptr, nullptr, rw, rh, (const int16_t*)nullptr, 0, 0,
-                               b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
-        x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
+        ft.tw[i] = tw[i]; ft.th[i] = th[i]; ft.G[i] = i ? G(i) : nullptr; ft.W[i] = i ? W(i) : nullptr; ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
+        ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
+        x_tl /= 2; y_tl /= 2;
     }
     if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(1), dim3(1024), 0, ctx->stream, ft);
-    if (nb >= 1) {
-        int nblk = 0;
-        for (int i = 1; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
-        ft.blk_off[nb + 1] = nblk;
-        hipLaunchKernelGGL(feed_tail_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft);
-    }
+    int nblk = 0;
+    for (int i = 0; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
+    ft.blk_off[nb + 1] = nblk;
+    hipLaunchKernelGGL(feed_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft, v, view_ok);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }

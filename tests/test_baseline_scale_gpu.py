@@ -1,0 +1,251 @@
+"""GPU parity at the full sizes of BASELINE.json's configs: the HIP path through the C ABI
+against the CPU oracle on the same frames, bit for bit.
+
+  config 2  2 x 1080p: ORB -> match + RANSAC -> fused warp of both frames                     (test_config2_*)
+  config 3  16 x 4K end to end: features of all 16 frames, all 240 MatchesInfo (default three-chain matcher flow),
+            kept indices, 8-band panorama + mask                                             (test_config3_*)
+  config 4  one adjacent frame pair from each row (pitch -14 / +14 deg) through warp + blend; the 64-frame job's
+            size-independent properties on one GPU                                           (test_config4_*)
+  config 5  one 8K frame through SIFT (keypoints + descriptors complete) and one 24k x 24k L2 2-NN on MFMA
+                                                                                             (test_config5_*)
+Frames are rendered on the GPU and downloaded, so both sides see the same bytes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def _compare_features(feats_gpu, feats_oracle):
+    for g, o in zip(feats_gpu, feats_oracle):
+        gk, gd = g.download()
+        ok = o["kps"]
+        assert len(gk) == len(ok)
+        for name in ("x", "y", "size", "angle", "response"):
+            assert np.array_equal(gk[name].view(np.uint32), ok[name].view(np.uint32)), name
+        assert np.array_equal(gk["octave"], ok["octave"])
+        assert np.array_equal(gd, o["desc"])
+
+
+def _compare_matches_info(g, o):
+    assert g.src_img_idx == o["src_img_idx"] and g.dst_img_idx == o["dst_img_idx"]
+    assert np.array_equal(g.matches, o["matches"].astype(g.matches.dtype))
+    assert np.array_equal(g.inliers_mask, o["inliers_mask"])
+    assert g.num_inliers == o["num_inliers"]
+    assert (g.H is not None) == o["has_H"]
+    if o["has_H"]:
+        assert np.array_equal(_bits(g.H), _bits(o["H"]))
+    assert g.confidence == o["confidence"]
+
+
+def _render(cams):
+    import torch
+    import synth
+    dev = [synth.render_frame_gpu(c) for c in cams]
+    torch.cuda.synchronize()
+    return dev, [f.cpu().numpy() for f in dev]
+
+
+def test_config2_1080p_pair_match_and_warp(ctx, oracle_mod):
+    """BASELINE config 2: the actual 2 x 1080p pair through ORB + 2-NN + RANSAC + warp on the GPU vs the oracle."""
+    import synth
+    import image_stitching_amd as isa
+    from oracle import job as ojob
+    cams = synth.workload("config2")
+    dev, host = _render(cams)
+    ref = ojob.stitch_job(host, cams, keep_warped=True)
+    st = isa.Stitcher(ctx, (1920, 1080), isa.StitchConfig(compose_megapix=-1))
+    feats = st.features(dev)
+    _compare_features(feats, ref["features"])
+    pm = st.match(feats)
+    assert len(pm) == 4
+    for g, o in zip(pm, ref["matches"]):
+        _compare_matches_info(g, o)
+    assert pm[1].num_inliers > 100
+    idx = isa.leaveBiggestComponent(pm, 2, 0.95)
+    assert list(idx) == ref["indices"]
+    scale = isa.Stitcher.warped_image_scale([cams[i] for i in ref["indices"]])
+    assert scale == ref["scale"]
+    warper = isa.SphericalWarper(ctx, scale)
+    for k, i in enumerate(ref["indices"]):
+        tl, img_s, msk = warper.warp_fused(dev[i], cams[i]["K"], cams[i]["R"])
+        oi, om, otl = ref["warped"][k]
+        assert tl == otl and np.array_equal(img_s.cpu().numpy(), oi) and np.array_equal(msk.cpu().numpy(), om)
+    pano, mask = st.compose(dev, cams, ref["indices"])
+    assert np.array_equal(pano.cpu().numpy(), ref["pano"]) and np.array_equal(mask.cpu().numpy(), ref["mask"])
+
+
+def test_config3_end_to_end_bit_exact(ctx, oracle_mod):
+    """BASELINE config 3, the job bench.py times: 16 x 4K frames through StitchJob.run (speculative compose, default
+    three-chain matcher flow) against the oracle's run of the same sequence: every keypoint and descriptor, all 240
+    directed MatchesInfo entries, the kept indices, the 8-band panorama and its mask."""
+    import synth
+    from image_stitching_amd.distributed import StitchJob
+    from oracle import job as ojob
+    cams = synth.workload("config3")
+    dev, host = _render(cams)
+    ref = ojob.stitch_job(host, cams)
+    job = StitchJob(ctx, (3840, 2160), cams)
+    out = job.run({i: f for i, f in enumerate(dev)})
+    assert out["indices"] == ref["indices"] == list(range(16))
+    assert out["num_bands"] == ref["num_bands"] == 8
+    assert tuple(out["pano_size"]) == tuple(ref["pano_size"])
+    _compare_features(out["features"], ref["features"])
+    pm = out["matches"]
+    assert len(pm) == 256
+    for k in range(256):
+        _compare_matches_info(pm[k], ref["matches"][k])
+    assert np.array_equal(np.asarray(out["confidence"]).reshape(16, 16), ref["confidence"])
+    gp, gm = out["pano"].cpu().numpy(), out["mask"].cpu().numpy()
+    assert gp.shape == ref["pano"].shape
+    assert np.array_equal(gm, ref["mask"])
+    assert np.array_equal(gp, ref["pano"])
+    # a second run of the same job (recycled blocks, warm arenas) gives the same panorama
+    out2 = job.run({i: f for i, f in enumerate(dev)})
+    assert np.array_equal(out2["pano"].cpu().numpy(), gp)
+
+
+@pytest.mark.parametrize("first", [15, 47])      # frames 15,16 of row 0 (pitch -14 deg) and 47,48 of row 1 (pitch +14 deg)
+def test_config4_row_pair_warp_blend_bit_exact(ctx, oracle_mod, first):
+    """BASELINE config 4: an adjacent pair of 4K frames from each of the two rows through the fused warp and the multiband
+    blender with the 64-frame job's own scale and band count, against the oracle."""
+    import synth
+    import image_stitching_amd as isa
+    cams_all = synth.workload("config4")
+    scale = isa.Stitcher.warped_image_scale(cams_all)
+    w, h = 3840, 2160
+    rois_all = isa.stitching.warp_rois(ctx, scale, (w, h), cams_all)
+    x0 = min(r[0] for r in rois_all); y0 = min(r[1] for r in rois_all)
+    x1 = max(r[0] + r[2] for r in rois_all); y1 = max(r[1] + r[3] for r in rois_all)
+    _, bands, _ = oracle_mod.blend_config(oracle_mod.BLEND_MULTI_BAND, 5.0, x1 - x0, y1 - y0)
+    assert bands == 8
+    pair = [first, first + 1]
+    cams = [cams_all[i] for i in pair]
+    dev, host = _render(cams)
+    warper = isa.SphericalWarper(ctx, scale)
+    gb, ob = isa.MultiBandBlender(ctx, bands), oracle_mod.Blender(oracle_mod.BLEND_MULTI_BAND, bands, 0.0)
+    items = []
+    for cam, fd, fh, i in zip(cams, dev, host, pair):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        assert tuple(rois_all[i]) == tuple(oracle_mod.warp_roi(scale, w, h, K, R))       # batch roi kernel vs host walk
+        tl, img_s, msk = warper.warp_fused(fd, K, R, rois_all[i])
+        oi, otl = oracle_mod.warp_spherical(fh, scale, K, R)
+        om, _ = oracle_mod.warp_spherical(np.full((h, w), 255, np.uint8), scale, K, R, 0, 0)
+        assert tl == otl and np.array_equal(img_s.cpu().numpy(), oi.astype(np.int16)) and np.array_equal(msk.cpu().numpy(), om)
+        items.append((img_s, msk, tl, oi.astype(np.int16), om))
+    corners = [it[2] for it in items]
+    sizes = [(it[1].shape[1], it[1].shape[0]) for it in items]
+    gb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    for img_s, msk, tl, oi, om in items:
+        gb.feed(img_s, msk, tl)
+        ob.feed(oi, om, tl)
+    for l in range(bands + 1):
+        gl, gw = gb.level(l)
+        ol, ow = ob.level(l)
+        assert np.array_equal(gl, ol), l
+        assert np.array_equal(gw.view(np.uint32), ow.view(np.uint32)), l
+    gp, gm = gb.blend()
+    op, om_ = ob.blend()
+    assert np.array_equal(gp.cpu().numpy(), op) and np.array_equal(gm.cpu().numpy(), om_)
+
+
+def test_config4_job_properties_one_gpu(ctx):
+    """BASELINE config 4 on one GPU (64 x 4K, 2016 pairs): size-independent properties of the whole job -- every frame
+    kept, every pair of the matcher mirrored exactly, adjacent frames of a row connected, panorama covered where any
+    frame's mask is, identical results on a second run."""
+    import torch
+    import synth
+    from image_stitching_amd.distributed import StitchJob
+    cams = synth.workload("config4")
+    dev = {i: synth.render_frame_gpu(c) for i, c in enumerate(cams)}
+    torch.cuda.synchronize()
+    job = StitchJob(ctx, (3840, 2160), cams)
+    out = job.run(dev)
+    n = 64
+    assert out["indices"] == list(range(n)) and out["num_bands"] == 8
+    conf = np.asarray(out["confidence"]).reshape(n, n)
+    assert np.array_equal(conf, conf.T) and np.all(np.diag(conf) == 0)
+    pm = out["matches"]
+    zeroed = 0
+    for i in range(n):
+        if i % 32 != 31:                                    # neighbours in a row overlap by 85 %
+            m = pm[i * n + i + 1]
+            c = m.num_inliers / (8 + 0.3 * len(m.matches))
+            assert c > 0.95, i
+            # BestOf2NearestMatcher: "confidence > 3 -> 0" (the pair looks like the same image twice); happens at 9 deg steps
+            assert conf[i, i + 1] == (0.0 if c > 3 else c), i
+            zeroed += c > 3
+    assert zeroed < 62                                      # and yet the pruning keeps every frame (checked above)
+    for i, j in ((0, 1), (5, 37), (31, 63), (10, 50)):
+        a, b = pm[i * n + j], pm[j * n + i]
+        assert a.num_inliers == b.num_inliers and a.confidence == b.confidence
+        assert np.array_equal(a.matches["query_idx"], b.matches["train_idx"]) and np.array_equal(a.matches["train_idx"], b.matches["query_idx"])
+    feats = out["features"]
+    assert all(len(f) == 4000 for f in feats)
+    pano, mask = out["pano"], out["mask"]
+    pw, ph = out["pano_size"]
+    assert tuple(pano.shape) == (ph, pw, 3) and tuple(mask.shape) == (ph, pw)
+    frac = float((mask > 0).float().mean())
+    assert 0.6 < frac <= 1.0
+    assert int(pano[mask == 0].abs().max()) == 0           # zero outside the mask
+    assert -32 <= int(pano.min()) and int(pano.max()) <= 255 + 32     # Laplacian ringing may leave the u8 range slightly
+    out2 = job.run(dev)
+    assert torch.equal(out2["pano"], pano) and torch.equal(out2["mask"], mask)
+    assert np.array_equal(np.asarray(out2["confidence"]).reshape(n, n), conf)
+
+
+def test_config5_sift_8k_frame_bit_exact(ctx, oracle_mod):
+    """BASELINE config 5: one 7680 x 4320 frame through SIFT on the GPU against the oracle -- keypoints (all fields)
+    and descriptors complete; the scale space is sampled (three Gaussian / DoG images per octave) to bound the
+    downloads."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    cam = synth.workload("config5")[3]
+    fd = synth.render_frame_gpu(cam)
+    torch.cuda.synchronize()
+    fh = fd.cpu().numpy()
+    o = oracle_mod.Sift(7680, 4320)
+    ko, do = o.run(fh)
+    f = isa.SiftFeatureFinder(ctx, (7680, 4320))
+    for octave in range(o.num_octaves()):
+        for layer, dog in ((0, False), (3, False), (2, True)):
+            a = f.debug_level(fd, octave, layer, dog=dog)
+            b = o.dog(octave, layer) if dog else o.gauss(octave, layer)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (octave, layer, dog)
+    kg, dg = f.detect(fd).download()
+    assert len(ko) > 10000 and len(kg) == len(ko)
+    for name in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(kg[name].view(np.uint32), ko[name].view(np.uint32)), name
+    assert np.array_equal(kg["octave"], ko["octave"])
+    assert np.array_equal(dg, do)
+
+
+def test_config5_l2_knn_24k_mfma_bit_exact(ctx, oracle_mod):
+    """BASELINE config 5's matcher core at full size: exact L2 2-NN of 24 576 x 24 576 SIFT-like descriptors (integers
+    0..255, norm ~512) on the fp16 MFMA path against the oracle's scalar loop -- indices and f32 distances."""
+    import ctypes as C
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    rng = np.random.default_rng(2405)
+    n = 24576
+
+    def descs(m):
+        d = rng.gamma(0.6, 1.0, (m, 128))
+        d = d / np.linalg.norm(d, axis=1, keepdims=True) * 512.0
+        return np.clip(np.rint(d), 0, 255).astype(np.float32)
+    q, t = descs(n), descs(n)
+    t[123] = q[77]; t[20000] = q[77]; t[4097] = t[4096]        # exact duplicates: ties -> smaller index
+    fq = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(n, KP_DTYPE), q)
+    ft = isa.ImageFeatures.upload(ctx, (64, 64), np.zeros(n, KP_DTYPE), t)
+    idx = np.zeros((n, 2), np.int32)
+    dist = np.zeros((n, 2), np.float32)
+    ctx.check(ctx.lib.mis_knn2(ctx.h, C.byref(fq.raw), C.byref(ft.raw), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
+    oi, od = oracle_mod.knn2_l2(q, t)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist.view(np.uint32), od.view(np.uint32))
+    assert idx[77, 0] == 123 and dist[77, 0] == 0.0

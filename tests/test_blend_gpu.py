@@ -51,6 +51,18 @@ def test_multiband_bit_exact(ctx, oracle_mod):
     _run_both(ctx, oracle_mod, oracle_mod.BLEND_MULTI_BAND, _frames(rng, 3, 200, 150), bands=4, check_levels=True)
 
 
+def test_multiband_full_s16_range_bit_exact(ctx, oracle_mod):
+    """feed() takes any 16SC3 image: values outside 0..255 leave the packed 16-bit pyrDown path (per tile: one frame is
+    all wide-range, one is 8-bit except for a patch, one has negative values only in a corner)."""
+    rng = np.random.default_rng(27)
+    frames = _frames(rng, 3, 260, 190)
+    a = rng.integers(-32768, 32768, frames[0][0].shape).astype(np.int16)
+    b = frames[1][0].copy(); b[60:90, 100:140] = rng.integers(-3000, 3000, (30, 40, 3)).astype(np.int16)
+    c = frames[2][0].copy(); c[:9, :11] = -7
+    frames = [(a, frames[0][1], frames[0][2]), (b, frames[1][1], frames[1][2]), (c, frames[2][1], frames[2][2])]
+    _run_both(ctx, oracle_mod, oracle_mod.BLEND_MULTI_BAND, frames, bands=5, check_levels=True)
+
+
 def test_multiband_band_crop_and_single_frame(ctx, oracle_mod):
     rng = np.random.default_rng(22)
     # more bands requested than the panorama supports -> prepare() crops them

@@ -7,7 +7,7 @@ for d in dirs:
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             if any(p in r["Kernel_Name"] for p in pats):
-                a = acc[(r["Kernel_Name"][:40], r["Counter_Name"])]
+                a = acc[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:40], r["Counter_Name"])]
                 a[0] += float(r["Counter_Value"]); a[1] += 1
         for (k, c), (s, n) in sorted(acc.items()):
             print("%-40s %-24s avg/dispatch %16.1f  (n=%d)" % (k, c, s / n, n))
