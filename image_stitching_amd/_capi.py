@@ -32,6 +32,10 @@ class MisRect(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
 
 
+class MisLevelRect(C.Structure):
+    _fields_ = [("level", C.c_int), ("x0", C.c_int), ("y0", C.c_int), ("x1", C.c_int), ("y1", C.c_int), ("offset", C.c_ulonglong)]
+
+
 class MisImage(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("channels", C.c_int),
                 ("stride", C.c_size_t), ("dtype", C.c_int), ("mem", C.c_int)]
@@ -143,6 +147,12 @@ PROTOTYPES = {
     "mis_blender_feed": (_i, [_vp, _P(MisImage), _P(MisImage), MisPoint]),
     "mis_blender_blend": (_i, [_vp, _P(MisImage), _P(MisImage)]),
     "mis_compose_frames": (_i, [_vp, _P(MisImage), _i, _f, _vp, _vp, _P(MisRect)]),
+    "mis_blender_blend_columns": (_i, [_vp, _i, _i, _P(MisImage), _P(MisImage)]),
+    "mis_blender_pack_rects": (_i, [_vp, _P(MisLevelRect), _i, _vp, C.c_size_t]),
+    "mis_blender_add_rects": (_i, [_vp, _P(MisLevelRect), _i, _vp, C.c_size_t]),
+    "mis_blender_zero_rects": (_i, [_vp, _P(MisLevelRect), _i]),
+    "mis_features_pack": (_i, [_vp, _P(MisFeatures), _i, _i, _i, _vp, _vp]),
+    "mis_copy_2d": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t]),
     "mis_blender_feed_rect": (_i, [_vp, _i, _i, MisPoint, _P(MisRect)]),
     "mis_blender_level_info": (_i, [_vp, _i, _P(_i), _P(_i), _P(_vp), _P(_vp)]),
 }

@@ -552,25 +552,12 @@ __global__ __launch_bounds__(256) void normalize_kernel(int16_t* lap, const floa
     d[0] = (int16_t)((float)d[0] / w); d[1] = (int16_t)((float)d[1] / w); d[2] = (int16_t)((float)d[2] / w);
 }
 
-// fine level (un-normalised) <- sat(pyrUp(coarse, already final) + normalise(fine))
-__global__ __launch_bounds__(256) void collapse_kernel(int16_t* fine, const float* fwgt, int fw, int fh, const int16_t* coarse, int cw, int ch) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= fw || y >= fh) return;
-    size_t o = (size_t)y * fw + x;
-    float w = fwgt[o] + WEIGHT_EPS;
-    int16_t* d = fine + o * 3;
-    int up[3];
-    pyr_up_at(coarse, cw, ch, x, y, up);
-    d[0] = sat_s16(up[0] + (int)(int16_t)((float)d[0] / w));
-    d[1] = sat_s16(up[1] + (int)(int16_t)((float)d[1] / w));
-    d[2] = sat_s16(up[2] + (int)(int16_t)((float)d[2] / w));
-}
-
-// the same per 2 x 2 block of the fine level (fine = 2 x coarse exactly)
+// fine level (un-normalised) <- sat(pyrUp(coarse, already final) + normalise(fine)), per 2 x 2 block of the fine level (fine = 2 x coarse exactly)
+// (coarse columns cx0 .. cx1 - 1 only: a rank that owns a column strip of the panorama collapses just that strip + halo)
 __global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ fine, const float* __restrict__ fwgt, int fw, int fh, const int16_t* __restrict__ coarse,
-                                                          int cw, int ch) {
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (X >= cw || Y >= ch) return;
+                                                          int cw, int ch, int cx0, int cx1) {
+    const int X = cx0 + blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= cx1 || Y >= ch) return;
     int up[4][3];
     pyr_up_block(coarse, cw, ch, X, Y, (cw & 1) == 0, up);
 #pragma unroll
@@ -585,11 +572,12 @@ __global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ 
 }
 
 // crop to the un-padded roi, dst_mask = wsum0 > eps (or the or-ed mask), zero outside the mask
+// (columns xoff .. xoff + fw - 1 of the panorama -> columns 0 .. fw - 1 of dst)
 __global__ __launch_bounds__(256) void finalize_kernel(const int16_t* lap0, const float* w0, const uint8_t* pmask, int pw, int fw, int fh,
-                                                       int16_t* dst, size_t dstride, uint8_t* dmask, size_t mstride) {
+                                                       int16_t* dst, size_t dstride, uint8_t* dmask, size_t mstride, int xoff) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= fw || y >= fh) return;
-    size_t o = (size_t)y * pw + x;
+    size_t o = (size_t)y * pw + x + xoff;
     unsigned m = pmask ? pmask[o] : (w0[o] > WEIGHT_EPS ? 255u : 0u);
     const int16_t* s = lap0 + o * 3;
     int16_t* d = (int16_t*)((uint8_t*)dst + (size_t)y * dstride) + 3 * (size_t)x;
@@ -923,39 +911,114 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
     return MIS_OK;
 }
 
-extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) {
-    if (!b) return MIS_E_INVALID;
+// blend() restricted to the panorama columns x0 .. x1 - 1 (level 0, relative to the padded roi): normalise + collapse run on
+// that strip plus the halo pyrUp needs (one coarse column either side per level, accumulated: at most two), the result is the
+// strip of the final image.  The whole panorama is the strip 0 .. fw.
+static int blend_columns(MisBlender* b, int x0, int x1, MisImage* dst, MisImage* dmask) {
     MisContext* ctx = b->ctx;
     MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "blend before prepare");
+    x1 = std::min(x1, b->fw);
+    MIS_CHECK(ctx, x0 >= 0 && x0 < x1, MIS_E_INVALID, "empty column range %d..%d (panorama width %d)", x0, x1, b->fw);
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     DevImage dd, dm;
     int rc;
-    if ((rc = mis_dev_image_out(ctx, dst, b->fw, b->fh, 3, MIS_S16, &dd)) != MIS_OK) return rc;
-    if ((rc = mis_dev_image_out(ctx, dmask, b->fw, b->fh, 1, MIS_U8, &dm)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_out(ctx, dst, x1 - x0, b->fh, 3, MIS_S16, &dd)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_out(ctx, dmask, x1 - x0, b->fh, 1, MIS_U8, &dm)) != MIS_OK) return rc;
     MIS_CHECK(ctx, dd.stride % 2 == 0, MIS_E_INVALID, "16SC3 stride must be even");
     const int nb = b->num_bands;
     if (b->type != MIS_BLEND_NO) {
+        // columns needed in final form per level: need[0] = the strip; need[l + 1] = the coarse columns pyrUp reads for need[l]
+        int lo[MIS_MAX_BANDS + 1], hi[MIS_MAX_BANDS + 1];
+        lo[0] = x0; hi[0] = x1;
+        for (int l = 1; l <= nb; l++) { lo[l] = std::max(0, (lo[l - 1] >> 1) - 1); hi[l] = std::min(b->lw[l], ((hi[l - 1] - 1) >> 1) + 2); }
         // coarsest level (or the single level of the feather blender): plain normalise;
         // every finer level: normalise fused with the collapse step
         size_t n = (size_t)b->lw[nb] * b->lh[nb];
         hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b->lap[nb], b->wgt[nb], n);
         for (int i = nb; i > 0; i--) {
-            if (b->lw[i - 1] == 2 * b->lw[i] && b->lh[i - 1] == 2 * b->lh[i])   // always, by the padding of prepare(); the per-pixel kernel is the general form
-                hipLaunchKernelGGL(collapse2x2_kernel, grid2d(b->lw[i], b->lh[i]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1], b->lw[i - 1], b->lh[i - 1],
-                                   (const int16_t*)b->lap[i], b->lw[i], b->lh[i]);
-            else
-                hipLaunchKernelGGL(collapse_kernel, grid2d(b->lw[i - 1], b->lh[i - 1]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1],
-                                   b->lw[i - 1], b->lh[i - 1], b->lap[i], b->lw[i], b->lh[i]);
+            MIS_CHECK(ctx, b->lw[i - 1] == 2 * b->lw[i] && b->lh[i - 1] == 2 * b->lh[i], MIS_E_STATE, "pyramid level %d is not twice level %d", i - 1, i);   // by the padding of prepare()
+            const int cx0 = lo[i - 1] >> 1, cx1 = ((hi[i - 1] - 1) >> 1) + 1;    // coarse columns whose 2 x 2 blocks cover need[i - 1]
+            hipLaunchKernelGGL(collapse2x2_kernel, grid2d(cx1 - cx0, b->lh[i]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1], b->lw[i - 1], b->lh[i - 1],
+                               (const int16_t*)b->lap[i], b->lw[i], b->lh[i], cx0, cx1);
         }
     }
-    hipLaunchKernelGGL(finalize_kernel, grid2d(b->fw, b->fh), dim3(256), 0, ctx->stream, b->lap[0], b->wgt[0], b->dst_mask, b->lw[0], b->fw,
-                       b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride);
+    hipLaunchKernelGGL(finalize_kernel, grid2d(x1 - x0, b->fh), dim3(256), 0, ctx->stream, b->lap[0], b->wgt[0], b->dst_mask, b->lw[0], x1 - x0,
+                       b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride, x0);
     MIS_HIP(ctx, hipGetLastError());
     if ((rc = mis_dev_image_commit(ctx, dst, &dd)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_commit(ctx, dmask, &dm)) != MIS_OK) return rc;
     b->prepared = false;  // the accumulators are consumed (the reference releases them in blend())
     return MIS_OK;
 }
+
+extern "C" int mis_blender_blend(MisBlender* b, MisImage* dst, MisImage* dmask) {
+    if (!b) return MIS_E_INVALID;
+    return blend_columns(b, 0, b->fw, dst, dmask);
+}
+
+extern "C" int mis_blender_blend_columns(MisBlender* b, int x0, int x1, MisImage* dst, MisImage* dmask) {
+    if (!b) return MIS_E_INVALID;
+    return blend_columns(b, x0, x1, dst, dmask);
+}
+
+// ---- multi-GPU blend exchange: rectangles of the accumulator pyramids packed into / added from one byte buffer ----
+// A rectangle (level, x0, y0, x1, y1) occupies, from `offset`: its 16SC3 Laplacian sums row after row (6 bytes per pixel, rounded
+// up to 16), then its f32 weight sums (4 bytes per pixel, rounded up to 16).
+struct RectBatch { int n; MisLevelRect r[MIS_MAX_BANDS + 1]; int16_t* lap[MIS_MAX_BANDS + 1]; float* wgt[MIS_MAX_BANDS + 1]; int pw[MIS_MAX_BANDS + 1]; };
+template <int MODE>   // 0: pack (pyramids -> buffer), 1: add (buffer -> pyramids; 16-bit sums wrap, f32 sums in call order), 2: zero
+__global__ __launch_bounds__(256) void rect_exchange_kernel(RectBatch rb, uint8_t* buf) {
+    const MisLevelRect r = rb.r[blockIdx.z];
+    const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (y >= h) return;
+    int16_t* lap = rb.lap[blockIdx.z] + ((size_t)(r.y0 + y) * rb.pw[blockIdx.z] + r.x0) * 3;
+    float* wgt = rb.wgt[blockIdx.z] + (size_t)(r.y0 + y) * rb.pw[blockIdx.z] + r.x0;
+    int16_t* bl = reinterpret_cast<int16_t*>(buf + r.offset) + (size_t)y * w * 3;
+    float* bw = reinterpret_cast<float*>(buf + r.offset + (((size_t)w * h * 6 + 15) & ~(size_t)15)) + (size_t)y * w;
+    if (x < 3 * w) {
+        if (MODE == 0) bl[x] = lap[x];
+        else if (MODE == 1) lap[x] = (int16_t)(lap[x] + bl[x]);
+        else lap[x] = 0;
+    }
+    if (x < w) {
+        if (MODE == 0) bw[x] = wgt[x];
+        else if (MODE == 1) wgt[x] = wgt[x] + bw[x];
+        else wgt[x] = 0.f;
+    }
+}
+
+static int rect_exchange(MisBlender* b, const MisLevelRect* rects, int n, void* buf, size_t bytes, int mode) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared && b->type != MIS_BLEND_NO, MIS_E_STATE, "no prepared accumulator pyramids");
+    MIS_CHECK(ctx, rects && n >= 0 && (buf || mode == 2), MIS_E_INVALID, "null argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i0 = 0; i0 < n; i0 += MIS_MAX_BANDS + 1) {
+        RectBatch rb;
+        rb.n = std::min(n - i0, MIS_MAX_BANDS + 1);
+        int maxw = 0, maxh = 0;
+        for (int i = 0; i < rb.n; i++) {
+            const MisLevelRect& r = rects[i0 + i];
+            MIS_CHECK(ctx, r.level >= 0 && r.level <= b->num_bands && r.x0 >= 0 && r.y0 >= 0 && r.x0 <= r.x1 && r.y0 <= r.y1 && r.x1 <= b->lw[r.level] && r.y1 <= b->lh[r.level],
+                      MIS_E_INVALID, "rectangle %d outside level %d", i0 + i, r.level);
+            const size_t px = (size_t)(r.x1 - r.x0) * (r.y1 - r.y0);
+            MIS_CHECK(ctx, mode == 2 || r.offset + ((px * 6 + 15) & ~(size_t)15) + ((px * 4 + 15) & ~(size_t)15) <= bytes, MIS_E_INVALID, "rectangle %d overruns the buffer", i0 + i);
+            rb.r[i] = r; rb.lap[i] = b->lap[r.level]; rb.wgt[i] = b->wgt[r.level]; rb.pw[i] = b->lw[r.level];
+            maxw = std::max(maxw, r.x1 - r.x0); maxh = std::max(maxh, r.y1 - r.y0);
+        }
+        if (maxw == 0 || maxh == 0) continue;
+        const dim3 grid((3 * maxw + 255) / 256, maxh, rb.n);
+        if (mode == 0) hipLaunchKernelGGL(rect_exchange_kernel<0>, grid, dim3(256), 0, ctx->stream, rb, (uint8_t*)buf);
+        else if (mode == 1) hipLaunchKernelGGL(rect_exchange_kernel<1>, grid, dim3(256), 0, ctx->stream, rb, (uint8_t*)buf);
+        else hipLaunchKernelGGL(rect_exchange_kernel<2>, grid, dim3(256), 0, ctx->stream, rb, (uint8_t*)buf);
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_pack_rects(MisBlender* b, const MisLevelRect* rects, int n, void* dev_buf, size_t bytes) { return rect_exchange(b, rects, n, dev_buf, bytes, 0); }
+extern "C" int mis_blender_add_rects(MisBlender* b, const MisLevelRect* rects, int n, const void* dev_buf, size_t bytes) { return rect_exchange(b, rects, n, (void*)dev_buf, bytes, 1); }
+extern "C" int mis_blender_zero_rects(MisBlender* b, const MisLevelRect* rects, int n) { return rect_exchange(b, rects, n, nullptr, 0, 2); }
 
 extern "C" int mis_blender_feed_rect(const MisBlender* b, int width, int height, MisPoint tl, MisRect* tile) {
     if (!b || !tile || !b->prepared || width < 1 || height < 1) return MIS_E_INVALID;

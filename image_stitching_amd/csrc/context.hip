@@ -161,3 +161,37 @@ int mis_dev_image_commit(MisContext* ctx, const MisImage* img, DevImage* d) {
     d->data = nullptr; d->owned = false;
     return MIS_OK;
 }
+
+// Feature sets of m frames into two dense device arrays for the descriptor all-gather: frame i's keypoints at
+// kps_dst + i * cap * 24, its descriptors at desc_dst + i * cap * row_bytes, the tails zeroed.  Device-to-device copies on the
+// context's stream; no host round trip.
+extern "C" int mis_features_pack(MisContext* ctx, const MisFeatures* feats, int m, int cap, int row_bytes, void* kps_dst, void* desc_dst) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, feats && m >= 0 && cap >= 1 && row_bytes >= 1 && kps_dst && desc_dst, MIS_E_INVALID, "invalid argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < m; i++) {
+        const int n = feats[i].n;
+        MIS_CHECK(ctx, n >= 0 && n <= cap, MIS_E_INVALID, "frame %d has %d keypoints, capacity %d", i, n, cap);
+        uint8_t* k = (uint8_t*)kps_dst + (size_t)i * cap * sizeof(MisKeyPoint);
+        uint8_t* d = (uint8_t*)desc_dst + (size_t)i * cap * row_bytes;
+        if (n) {
+            MIS_HIP(ctx, hipMemcpyAsync(k, feats[i].keypoints, (size_t)n * sizeof(MisKeyPoint), hipMemcpyDeviceToDevice, ctx->stream));
+            MIS_HIP(ctx, hipMemcpyAsync(d, feats[i].descriptors, (size_t)n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (n < cap) {
+            MIS_HIP(ctx, hipMemsetAsync(k + (size_t)n * sizeof(MisKeyPoint), 0, (size_t)(cap - n) * sizeof(MisKeyPoint), ctx->stream));
+            MIS_HIP(ctx, hipMemsetAsync(d + (size_t)n * row_bytes, 0, (size_t)(cap - n) * row_bytes, ctx->stream));
+        }
+    }
+    return MIS_OK;
+}
+
+// 2-D device-to-device copy on the context's stream (assembling the finished column strips of a panorama)
+extern "C" int mis_copy_2d(MisContext* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, dst && src && width_bytes <= dst_pitch && width_bytes <= src_pitch, MIS_E_INVALID, "invalid argument");
+    if (!width_bytes || !height) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MIS_HIP(ctx, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
+    return MIS_OK;
+}

@@ -8,17 +8,24 @@ spreads the same sequence over N ranks:
   match + RANSAC            pairs dealt round-robin           all-gather of {keypoints, descriptors, counts}
   component pruning         replicated (n <= 64)              all-reduce (sum) of the n x n confidence matrix
   warp + blend accumulate   frames (same blocks)              none
-  blend finalise            rank 0                            region gather of the Laplacian / weight pyramids
+  blend exchange            column strips of the panorama     all-to-all of pyramid rectangles (each rank -> each strip owner)
+  blend finalise            column strips (owner = rank k)    all-gather of the finished strips
 
-Blend exchange.  A rank's frames are a contiguous block of the sweep, so its pyramid contributions are
-confined to one rectangle of the panorama (frame ROIs + the blender's 3 * 2^bands margin, aligned to
-2^bands so the rectangle maps exactly onto every pyramid level).  Instead of an all-reduce of the whole
-pyramid (which would also need int16 -> int32 widening: RCCL has no 16-bit integer type) each rank packs
-only its rectangle of every level into one byte buffer, ONE gather brings the buffers to rank 0 over the
-point-to-point xGMI links in parallel, and rank 0 adds them in rank order.  16SC3 Laplacian sums are
-two's-complement wrap-around additions and therefore exact in any order; the f32 weight sums are added
-in a fixed order (deterministic), differing from the single-GPU feed order in the last bit where >= 3
-frames overlap -- inside the 1-LSB pixel tolerance of the north star.
+Blend exchange (reduce-scatter by panorama column strips, local finalise, all-gather).  Rank k owns the columns
+[c_k, c_k+1) of the padded panorama (boundaries multiples of 2^bands, so a strip maps exactly onto every pyramid level).
+Finalising a strip needs the SUMMED accumulators of that strip plus pyrUp's halo (one coarse column either side per level,
+accumulated: at most two columns) -- `need_l(k)` below.  A rank's frames are a contiguous block of the sweep, so its own
+contributions are confined to one rectangle of the panorama (frame ROIs + the blender's 3 * 2^bands margin): rank r packs, for
+every owner k, the intersection of that rectangle with need_l(k) at every level (mis_blender_pack_rects) and ONE all-to-all
+moves the buffers over the point-to-point xGMI links, every link in parallel, each carrying ~1/N^2 of the pyramid set (an
+all-reduce of the whole 1.4 GB set of config 4 would also need int16 -> int32 widening: RCCL has no 16-bit integer type).
+The owner zeroes its need ranges and adds the N buffers in rank order (its own included: it travels through the same path):
+16SC3 sums are two's-complement wrap-around additions, exact in any order; the f32 weight sums have the fixed association
+((0 + p_0) + p_1) + ... over the per-rank partial sums p_r (each the sum of that rank's frames in feed order), which the CPU
+tests reproduce with the oracle bit for bit, and which differs from the single-GPU feed order in the last bit where >= 3 frames
+of different ranks overlap (inside the 1-LSB pixel tolerance of the north star).  Every rank then runs normalise + collapse +
+crop on its strip only (mis_blender_blend_columns: work per rank ~ 1/N) and the finished strips are all-gathered.  Pack, add,
+zero, the strip finalise, the strip copies and the feature packing are kernels / copies of the library: no torch arithmetic.
 
 The orchestration is engine-agnostic: `HipEngine` (the product) drives libmistitch through the C ABI;
 the CPU tests inject an engine of their own to exercise the sharding / collective logic under gloo.
@@ -71,6 +78,38 @@ class Comm:
             if h is not t:
                 t.copy_(h)
         return t
+
+    def all_to_all_bytes(self, send, recv_sizes):
+        """send: list of world 1-D uint8 tensors (send[k] goes to rank k) -> list of world tensors (recv[r] came from rank r,
+        recv_sizes[r] bytes).  One collective (NCCL / RCCL all_to_all_single with split sizes); isend / irecv pairs under gloo."""
+        if self.world == 1:
+            return [send[0]]
+        import torch.distributed as dist
+        dev = send[0].device
+        hs = [self._h(t).contiguous() for t in send]
+        hdev = hs[0].device
+        recv = [torch.empty(int(n), dtype=torch.uint8, device=hdev) for n in recv_sizes]
+        if self._stage:
+            ops = []
+            for k in range(self.world):
+                if k == self.rank:
+                    recv[k].copy_(hs[k])
+                    continue
+                if hs[k].numel():
+                    ops.append(dist.P2POp(dist.isend, hs[k], k, group=self.group))
+                if recv[k].numel():
+                    ops.append(dist.P2POp(dist.irecv, recv[k], k, group=self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        else:
+            inp, out = torch.cat(hs), torch.empty(int(sum(recv_sizes)), dtype=torch.uint8, device=hdev)
+            dist.all_to_all_single(out, inp, [int(n) for n in recv_sizes], [int(t.numel()) for t in hs], group=self.group)
+            o = 0
+            for k, n in enumerate(recv_sizes):
+                recv[k] = out[o:o + int(n)]
+                o += int(n)
+        return [r.to(dev) for r in recv]
 
     def gather_to_root(self, t):
         """Equal-sized 1-D tensors -> list of world tensors on rank 0 (None elsewhere)."""
@@ -125,17 +164,18 @@ class HipEngine:
 
     def pack_features(self, feats, cap):
         """-> (kps u8 [m, cap*24], desc u8 [m, cap*row_bytes]) device tensors for the all-gather; `cap` = the largest
-        keypoint count of any frame of the job (agreed by the ranks beforehand: SIFT has no fixed budget)."""
+        keypoint count of any frame of the job (agreed by the ranks beforehand: SIFT has no fixed budget).  Device-to-device
+        copies inside the library (mis_features_pack)."""
         m = len(feats)
         dev = self.ctx.device
         rb = self._row_bytes(feats)
-        kps = torch.zeros((m, cap * 24), dtype=torch.uint8, device=dev)
-        desc = torch.zeros((m, cap * rb), dtype=torch.uint8, device=dev)
-        for i, f in enumerate(feats):
-            n = len(f)
-            if n:
-                kps[i, : n * 24] = dev_tensor(f.raw.keypoints, (n * 24,), "|u1", dev)
-                desc[i, : n * rb] = dev_tensor(f.raw.descriptors, (n * rb,), "|u1", dev)
+        kps = torch.empty((m, cap * 24), dtype=torch.uint8, device=dev)
+        desc = torch.empty((m, cap * rb), dtype=torch.uint8, device=dev)
+        if m:
+            arr = (capi.MisFeatures * m)()
+            for k, f in enumerate(feats):
+                C.memmove(C.byref(arr[k]), C.byref(f.raw), C.sizeof(capi.MisFeatures))
+            self.ctx.check(self.ctx.lib.mis_features_pack(self.ctx.h, arr, m, int(cap), int(rb), C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr())))
         return kps, desc
 
     def _row_bytes(self, feats=None):
@@ -225,6 +265,67 @@ class HipEngine:
     def num_bands(self):
         return self.ctx.lib.mis_blender_num_bands(self.blender.h)
 
+    # ---- blend exchange (library kernels on the compose stream) ----
+    def level_sizes(self):
+        out = []
+        for l in range(self.num_bands() + 1):
+            w, h = C.c_int(), C.c_int()
+            self.cctx.check(self.cctx.lib.mis_blender_level_info(self.blender.h, l, C.byref(w), C.byref(h), None, None))
+            out.append((w.value, h.value))
+        return out
+
+    @staticmethod
+    def _rect_array(rects):
+        return (capi.MisLevelRect * max(len(rects), 1))(*[capi.MisLevelRect(*r) for r in rects])
+
+    def pack_rects(self, rects, nbytes):
+        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.ctx.device)
+        if rects:
+            self.cctx.check(self.cctx.lib.mis_blender_pack_rects(self.blender.h, self._rect_array(rects), len(rects), C.c_void_p(buf.data_ptr()), buf.numel()))
+        return buf[:int(nbytes)]
+
+    def add_rects(self, rects, buf):
+        if rects:
+            self.cctx.check(self.cctx.lib.mis_blender_add_rects(self.blender.h, self._rect_array(rects), len(rects), C.c_void_p(buf.data_ptr()), buf.numel()))
+
+    def zero_rects(self, rects):
+        if rects:
+            self.cctx.check(self.cctx.lib.mis_blender_zero_rects(self.blender.h, self._rect_array(rects), len(rects)))
+
+    def finalize_columns(self, x0, x1):
+        """blend() for the panorama columns x0 .. x1 - 1 -> (16SC3 strip, mask strip)."""
+        w, h = self.blender._size
+        x1 = min(x1, w)
+        dst = st._empty_image(self.cctx, h, x1 - x0, 3, torch.int16)
+        msk = st._empty_image(self.cctx, h, x1 - x0, 1, torch.uint8)
+        d, m = st.as_image(dst), st.as_image(msk)
+        self.cctx.check(self.cctx.lib.mis_blender_blend_columns(self.blender.h, int(x0), int(x1), C.byref(d), C.byref(m)))
+        return dst, msk
+
+    def strip_to_bytes(self, img, msk, cap_w):
+        """A finished strip as one flat byte tensor of the common size (strip widths differ by at most 2^bands)."""
+        h, w = msk.shape
+        out = torch.zeros(h * cap_w * 7, dtype=torch.uint8, device=self.ctx.device)
+        lib, cx = self.cctx.lib, self.cctx
+        cx.check(lib.mis_copy_2d(cx.h, C.c_void_p(out.data_ptr()), cap_w * 6, C.c_void_p(img.data_ptr()), img.stride(0) * 2, w * 6, h))
+        cx.check(lib.mis_copy_2d(cx.h, C.c_void_p(out.data_ptr() + h * cap_w * 6), cap_w, C.c_void_p(msk.data_ptr()), msk.stride(0), w, h))
+        return out
+
+    def assemble(self, strips, bounds, cap_w, size):
+        """All ranks' strip byte tensors [world, h * cap_w * 7] -> (panorama 16SC3, mask) device tensors."""
+        w, h = size
+        pano = st._empty_image(self.cctx, h, w, 3, torch.int16)
+        mask = st._empty_image(self.cctx, h, w, 1, torch.uint8)
+        lib, cx = self.cctx.lib, self.cctx
+        for k, (x0, x1) in enumerate(bounds):
+            x1 = min(x1, w)
+            if x1 <= x0:
+                continue
+            base = strips[k].data_ptr()
+            cx.check(lib.mis_copy_2d(cx.h, C.c_void_p(pano.data_ptr() + x0 * 6), pano.stride(0) * 2, C.c_void_p(base), cap_w * 6, (x1 - x0) * 6, h))
+            cx.check(lib.mis_copy_2d(cx.h, C.c_void_p(mask.data_ptr() + x0), mask.stride(0), C.c_void_p(base + h * cap_w * 6), cap_w, x1 - x0, h))
+        return pano, mask
+
     def sync(self):
         torch.cuda.synchronize(self.ctx.device)
 
@@ -305,9 +406,9 @@ class StitchJob:
                 eng.warp_feed(frames[i], self.cams[i], rois[i])
         return btype, bands
 
-    # -- blend exchange: region gather ---------------------------------------------------------
+    # -- blend exchange: column strips ----------------------------------------------------------
     def rank_region(self, r, indices, rois, bands, w0, h0):
-        """Level-0 rectangle (x0, y0, x1, y1) of the panorama that rank r's frames can touch, or None."""
+        """Level-0 rectangle (x0, y0, x1, y1) of the padded panorama that rank r's frames can touch, or None."""
         mine = [i for i in frame_block(self.n, r, self.world) if i in rois]
         if not mine:
             return None
@@ -321,77 +422,88 @@ class StitchJob:
         return x0, y0, x1, y1
 
     @staticmethod
-    def _level_rects(region, levels):
-        """Per level (x0, y0, x1, y1) of a level-0 rectangle, clipped to the level size."""
-        x0, y0, x1, y1 = region
-        out = []
-        for l, (lap, wgt) in enumerate(levels):
-            h, w = wgt.shape
-            out.append((min(x0 >> l, w), min(y0 >> l, h), min(-((-x1) >> l), w), min(-((-y1) >> l), h)))
+    def strip_bounds(w0, bands, world):
+        """Column strips [c_k, c_k+1) of the padded panorama (w0 a multiple of 2^bands), boundaries multiples of 2^bands."""
+        q = 1 << bands
+        nq = w0 // q
+        c = [(k * nq // world) * q for k in range(world)] + [w0]
+        return [(c[k], c[k + 1]) for k in range(world)]
+
+    @staticmethod
+    def need_ranges(strip, level_sizes):
+        """Columns [lo, hi) of every level whose summed accumulators the owner of `strip` needs: the strip itself and, level by
+        level, the coarse columns pyrUp reads for the level below (mis_blender_blend_columns uses the same recurrence)."""
+        lo, hi = strip
+        out = [(lo, hi)]
+        for l in range(1, len(level_sizes)):
+            lo, hi = max(0, (lo >> 1) - 1), min(level_sizes[l][0], ((hi - 1) >> 1) + 2)
+            out.append((lo, hi))
         return out
 
     @staticmethod
-    def _packed_size(rects):
-        return sum(((x1 - x0) * (y1 - y0) * 10 + 31) // 16 * 16 for x0, y0, x1, y1 in rects)   # 6 B lap + 4 B weight, 16 B aligned parts
-
-    @staticmethod
-    def _pack(levels, rects, nbytes):
-        dev = levels[0][0].device
-        buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        o = 0
-        for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects):
+    def exchange_rects(region, need, level_sizes):
+        """Rectangles (level, x0, y0, x1, y1, offset) of `region` (a rank's level-0 rectangle) inside the columns `need`, and
+        the packed size: per level the 16SC3 block then the f32 block, each rounded up to 16 bytes."""
+        rects, off = [], 0
+        if region is None:
+            return rects, 0
+        rx0, ry0, rx1, ry1 = region
+        for l, ((lw, lh), (nlo, nhi)) in enumerate(zip(level_sizes, need)):
+            x0, x1 = max(min(rx0 >> l, lw), nlo), min(min(-((-rx1) >> l), lw), nhi)
+            y0, y1 = min(ry0 >> l, lh), min(-((-ry1) >> l), lh)
+            if x1 <= x0 or y1 <= y0:
+                continue
             m = (x1 - x0) * (y1 - y0)
-            if m:
-                buf[o:o + m * 6] = lap[y0:y1, 3 * x0:3 * x1].contiguous().view(torch.uint8).reshape(-1)
-                ow = o + (m * 6 + 15) // 16 * 16
-                buf[ow:ow + m * 4] = wgt[y0:y1, x0:x1].contiguous().view(torch.uint8).reshape(-1)
-            o += (m * 10 + 31) // 16 * 16
-        return buf
+            rects.append((l, x0, y0, x1, y1, off))
+            off += (m * 6 + 15) // 16 * 16 + (m * 4 + 15) // 16 * 16
+        return rects, off
 
-    @staticmethod
-    def _add_packed(levels, rects, buf):
-        o = 0
-        for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects):
-            m = (x1 - x0) * (y1 - y0)
-            if m:
-                lap[y0:y1, 3 * x0:3 * x1] += buf[o:o + m * 6].view(torch.int16).view(y1 - y0, 3 * (x1 - x0))     # wraps
-                ow = o + (m * 6 + 15) // 16 * 16
-                wgt[y0:y1, x0:x1] += buf[ow:ow + m * 4].view(torch.float32).view(y1 - y0, x1 - x0)
-            o += (m * 10 + 31) // 16 * 16
-
-    def stage_reduce(self):
-        if self.world == 1 and not self.force_collectives:
-            return
-        levels = self.engine.accumulators()
-        bands = len(levels) - 1
-        h0, w0 = levels[0][1].shape
+    def stage_reduce_finalize(self):
+        """Strip exchange + per-strip finalise + assembly -> (pano, mask) on rank 0 (None elsewhere)."""
+        eng = self.engine
+        sizes = eng.level_sizes()
+        bands = len(sizes) - 1
+        w0, h0 = sizes[0]
         indices, rois = self._compose_indices, self._compose_rois
-        regions = [self.rank_region(r, indices, rois, bands, w0, h0) for r in range(self.world)]
-        rects = [self._level_rects(g, levels) if g else None for g in regions]
-        nbytes = max([self._packed_size(rc) for rc in rects[1:] if rc] + [16])
-        if self.force_collectives and self.world == 1:
-            # test mode: move this rank's own rectangle out, zero it, and add it back through the packed path
-            buf = self._pack(levels, rects[0], self._packed_size(rects[0]))
-            for (lap, wgt), (x0, y0, x1, y1) in zip(levels, rects[0]):
-                lap[y0:y1, 3 * x0:3 * x1] = 0
-                wgt[y0:y1, x0:x1] = 0
-            self._add_packed(levels, rects[0], buf)
-            return
-        mine = rects[self.rank]
-        if self.rank != 0 and mine:
-            buf = self._pack(levels, mine, nbytes)
-        else:
-            buf = torch.zeros(nbytes, dtype=torch.uint8, device=levels[0][0].device)
-        bufs = self.comm.gather_to_root(buf)
-        if self.rank == 0:
-            for r in range(1, self.world):
-                if rects[r]:
-                    self._add_packed(levels, rects[r], bufs[r])
+        world = self.world
+        bounds = self.strip_bounds(w0, bands, world)
+        needs = [self.need_ranges(bnd, sizes) for bnd in bounds]
+        regions = [self.rank_region(r, indices, rois, bands, w0, h0) for r in range(world)]
+        plan = [[self.exchange_rects(regions[r], needs[k], sizes) for k in range(world)] for r in range(world)]   # plan[src][dst]
+        me = self.rank
+        send = [eng.pack_rects(*plan[me][k]) for k in range(world)]
+        recv = self.comm.all_to_all_bytes(send, [plan[r][me][1] for r in range(world)])
+        full_h = [(l, lo, 0, hi, sizes[l][1], 0) for l, (lo, hi) in enumerate(needs[me]) if hi > lo]
+        eng.zero_rects(full_h)
+        for r in range(world):                      # fixed association of the f32 sums: rank order
+            eng.add_rects(plan[r][me][0], recv[r])
+        pw, ph = eng.pano_size
+        x0, x1 = bounds[me][0], min(bounds[me][1], pw)
+        cap_w = max(min(b1, pw) - b0 for b0, b1 in bounds)
+        if x1 > x0:
+            img, msk = eng.finalize_columns(x0, x1)
+            mine = eng.strip_to_bytes(img, msk, cap_w)
+        else:                                       # more ranks than 2^bands-wide column groups: this rank owns nothing
+            mine = torch.zeros(ph * cap_w * 7, dtype=torch.uint8, device=send[0].device)
+        strips = self.comm.all_gather(mine)
+        if self.rank != 0:
+            return None, None
+        return eng.assemble(strips, bounds, cap_w, (pw, ph))
 
     def stage_finalize(self):
         if self.rank == 0:
             return self.engine.finalize()
         return None, None
+
+    def stage_exchange_finalize(self):
+        """Single rank: blend().  N ranks (or force_collectives): strip exchange, per-strip finalise, assembly."""
+        if self.world == 1 and not self.force_collectives:
+            return self.stage_finalize()
+        side = getattr(self.engine, "compose_stream", None)
+        if side is None:
+            return self.stage_reduce_finalize()
+        with torch.cuda.stream(side):        # the library's kernels and torch.distributed's collectives meet on this stream
+            return self.stage_reduce_finalize()
 
     # -- whole job ---------------------------------------------------------------------------
     def _compose_on_side_stream(self, frames, indices, prepared=None):
@@ -452,10 +564,8 @@ class StitchJob:
                 (btype, bands), (pano, mask) = box["r"], box["f"]
             else:
                 btype, bands = box["r"] if indices == everyone else self._compose_on_side_stream(frames, indices)
-                self.engine.compose_stream.synchronize()     # the accumulators are complete before any exchange
                 with torch.cuda.stream(self.engine.compose_stream):
-                    self.stage_reduce()
-                    pano, mask = self.stage_finalize()
+                    pano, mask = self.stage_exchange_finalize()
         else:
             pm, conf = self.stage_match(feats)
             indices = self.stage_prune(conf)
@@ -468,8 +578,7 @@ class StitchJob:
                     self.cams[i] = c
                 self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])
             btype, bands = self.stage_compose(frames, indices)
-            self.stage_reduce()
-            pano, mask = self.stage_finalize()
+            pano, mask = self.stage_exchange_finalize()
         self.engine.sync()      # the job's results are complete when run() returns
         return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,
                 "pano_size": self.engine.pano_size, "num_bands": bands}
@@ -498,6 +607,5 @@ class StitchJob:
                 with torch.cuda.stream(side):
                     return fn()
             timed("warp + blend feed", lambda: on_side(lambda: self.stage_compose(frames, idx)))
-            timed("pyramid reduce", lambda: on_side(self.stage_reduce))
-            timed("blend finalise", lambda: on_side(self.stage_finalize))
+            timed("blend exchange + finalise", lambda: on_side(self.stage_exchange_finalize))
         return out

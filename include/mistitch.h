@@ -111,6 +111,11 @@ int mis_features_download(MisContext* ctx, const MisFeatures* f, MisKeyPoint* kp
 int mis_features_upload(MisContext* ctx, int img_w, int img_h, int n, const MisKeyPoint* kps_host,
                         const void* desc_host, int desc_cols, int desc_dtype, MisFeatures* out);
 int mis_features_free(MisContext* ctx, MisFeatures* f);
+/* m feature sets into two dense device arrays (frame i at kps_dst + i * cap * 24 and desc_dst + i * cap * row_bytes, tails
+ * zeroed): the send buffers of the descriptor all-gather of a sharded job; device-to-device, no host copy */
+int mis_features_pack(MisContext* ctx, const MisFeatures* feats, int m, int cap, int row_bytes, void* kps_dst, void* desc_dst);
+/* 2-D device-to-device copy on the context's stream (a rank's finished column strip into the assembled panorama) */
+int mis_copy_2d(MisContext* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height);
 /* stage intermediates of the last mis_orb_detect (host copies, for parity tests):
  * which = 0 gray level (tight w*h), 1 NMS-surviving FAST score map, 2 blurred bordered level */
 int mis_orb_debug_level(MisOrb* orb, int level, int which, uint8_t* host_out, int* width, int* height);
@@ -267,6 +272,20 @@ int mis_blender_num_bands(const MisBlender* b);
 int mis_blender_feed(MisBlender* b, const MisImage* img_s16x3, const MisImage* mask_u8, MisPoint tl);
 /* blender->blend(result, result_mask) -- replaces :1225 */
 int mis_blender_blend(MisBlender* b, MisImage* dst_s16x3, MisImage* dst_mask);
+/* blend() for the panorama columns x0 .. x1 - 1 only (relative to the result roi; x1 is clipped to its width): the same values
+ * as those columns of mis_blender_blend's result, computed from the accumulators of that strip + a halo of two columns per
+ * level.  A rank that owns a column strip of the panorama finalises only that strip. */
+int mis_blender_blend_columns(MisBlender* b, int x0, int x1, MisImage* dst_s16x3, MisImage* dst_mask);
+/* Multi-GPU blend exchange (replaces nothing in the single-process reference: its feed loop :1218 adds every frame into one
+ * pyramid; N ranks add theirs into N pyramids and exchange rectangles).  A rectangle of accumulator level `level`,
+ * columns x0 .. x1 - 1, rows y0 .. y1 - 1, lives in a byte buffer at `offset`: 16SC3 Laplacian sums row by row (6 B per pixel,
+ * the block rounded up to 16 B), then the f32 weight sums (4 B per pixel, rounded up to 16 B).
+ *   pack: accumulators -> buffer;   add: accumulators += buffer (16-bit sums wrap: any order gives the same bits; f32 sums are
+ *   added in call order);   zero: accumulators = 0.   All on the blender's stream, device buffers. */
+typedef struct { int level, x0, y0, x1, y1; unsigned long long offset; } MisLevelRect;
+int mis_blender_pack_rects(MisBlender* b, const MisLevelRect* rects, int n, void* dev_buf, size_t bytes);
+int mis_blender_add_rects(MisBlender* b, const MisLevelRect* rects, int n, const void* dev_buf, size_t bytes);
+int mis_blender_zero_rects(MisBlender* b, const MisLevelRect* rects, int n);
 /* The per-frame body of the compositing loop for n frames in one call: fused warp of frames[i] with (Ks + 9 i, Rs + 9 i)
  * at `scale` into library-owned device blocks of size rois[i] (= mis_warp_roi of the frame), then feed -- replaces
  * image_stitching.cpp:1154-1164 and :1218 for every image of the loop at :1086.  Same results as the single calls. */

@@ -116,6 +116,63 @@ class OracleEngine:
     def finalize(self):
         return self.blender.blend()
 
+    # ---- blend exchange (numpy twins of mis_blender_pack_rects / add_rects / zero_rects / blend_columns) ----
+    def level_sizes(self):
+        return [(w.shape[1], w.shape[0]) for _, w in self.accumulators()]
+
+    def pack_rects(self, rects, nbytes):
+        buf = np.zeros(max(int(nbytes), 16), np.uint8)
+        acc = self.accumulators()
+        for l, x0, y0, x1, y1, off in rects:
+            lap, wgt = acc[l][0].numpy(), acc[l][1].numpy()
+            m = (x1 - x0) * (y1 - y0)
+            buf[off:off + m * 6] = np.ascontiguousarray(lap[y0:y1, 3 * x0:3 * x1]).view(np.uint8).reshape(-1)
+            ow = off + (m * 6 + 15) // 16 * 16
+            buf[ow:ow + m * 4] = np.ascontiguousarray(wgt[y0:y1, x0:x1]).view(np.uint8).reshape(-1)
+        return torch.from_numpy(buf[:int(nbytes)].copy())
+
+    def add_rects(self, rects, buf):
+        b = buf.numpy()
+        acc = self.accumulators()
+        for l, x0, y0, x1, y1, off in rects:
+            lap, wgt = acc[l][0].numpy(), acc[l][1].numpy()
+            m = (x1 - x0) * (y1 - y0)
+            lap[y0:y1, 3 * x0:3 * x1] += b[off:off + m * 6].view(np.int16).reshape(y1 - y0, 3 * (x1 - x0))      # wraps
+            ow = off + (m * 6 + 15) // 16 * 16
+            wgt[y0:y1, x0:x1] += b[ow:ow + m * 4].view(np.float32).reshape(y1 - y0, x1 - x0)
+
+    def zero_rects(self, rects):
+        acc = self.accumulators()
+        for l, x0, y0, x1, y1, _ in rects:
+            acc[l][0].numpy()[y0:y1, 3 * x0:3 * x1] = 0
+            acc[l][1].numpy()[y0:y1, x0:x1] = 0
+
+    def finalize_columns(self, x0, x1):
+        # blend() of the whole pyramid: outside this strip's need ranges the sums are partial and the result is junk, the
+        # strip's own columns only depend on the need ranges
+        pano, mask = self.blender.blend()
+        return pano[:, x0:x1].copy(), mask[:, x0:x1].copy()
+
+    def strip_to_bytes(self, img, msk, cap_w):
+        h, w = msk.shape
+        out = np.zeros(h * cap_w * 7, np.uint8)
+        a = out[:h * cap_w * 6].view(np.int16).reshape(h, cap_w * 3)
+        a[:, :3 * w] = img.reshape(h, 3 * w)
+        out[h * cap_w * 6:].reshape(h, cap_w)[:, :w] = msk
+        return torch.from_numpy(out)
+
+    def assemble(self, strips, bounds, cap_w, size):
+        w, h = size
+        pano, mask = np.zeros((h, w, 3), np.int16), np.zeros((h, w), np.uint8)
+        for k, (x0, x1) in enumerate(bounds):
+            x1 = min(x1, w)
+            if x1 <= x0:
+                continue
+            b = strips[k].numpy()
+            pano[:, x0:x1] = b[:h * cap_w * 6].view(np.int16).reshape(h, cap_w, 3)[:, :x1 - x0]
+            mask[:, x0:x1] = b[h * cap_w * 6:].reshape(h, cap_w)[:, :x1 - x0]
+        return pano, mask
+
     def num_bands(self):
         return self.blender.num_bands
 

@@ -1,7 +1,7 @@
 """world_size-2 gloo runs of the sharded panorama job (image_stitching_amd.distributed.StitchJob) on CPU.
 
-The orchestration (frame blocks, feature all-gather, round-robin pairs, confidence all-reduce, packed
-region gather of the blend pyramids, root finalise) is engine-agnostic; here the oracle-backed engine from
+The orchestration (frame blocks, feature all-gather, round-robin pairs, confidence all-reduce, column-strip
+exchange of the blend pyramids, per-strip finalise, strip all-gather) is engine-agnostic; here the oracle-backed engine from
 tests/oracle_engine.py stands in for the HIP engine so the N > 1 path runs without a GPU."""
 import os
 import socket
@@ -86,28 +86,58 @@ def test_two_rank_job_matches_single_rank(tmp_path):
     assert (d > 0).mean() < 0.02
 
 
-def test_region_pack_roundtrip_and_int16_wrap():
-    """Packed rectangle exchange: pack -> add lands on the same pixels at every level; int16 adds wrap."""
+def test_two_rank_result_is_the_oracle_with_rank_order_sums(tmp_path):
+    """The exchange fixes the association of the f32 weight sums: per-rank partial sums (each rank's frames in feed order)
+    added in rank order from zero.  An oracle run with exactly that association reproduces the 2-rank panorama bit for bit."""
+    import oracle
+    import synth
+    from oracle import job as ojob
+    cams = _cams()
+    frames = [synth.render_frame(c) for c in cams]
+    out_path = str(tmp_path / "rank0.npz")
+    mp.start_processes(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out_path)
+    scale = ojob.warped_image_scale(cams)
+    rois = [oracle.warp_roi(scale, W, H, c["K"].astype(np.float32), c["R"].astype(np.float32)) for c in cams]
+    corners, sizes = [(r[0], r[1]) for r in rois], [(r[2], r[3]) for r in rois]
+    x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + s[0] for c, s in zip(corners, sizes)); y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
+    btype, bands, sharp = oracle.blend_config(oracle.BLEND_MULTI_BAND, 5.0, x1 - x0, y1 - y0)
+    from oracle_engine import OracleEngine
+    engs = []
+    for r in range(2):
+        e = OracleEngine((W, H))
+        e.begin_compose(scale, corners, sizes)
+        for i in (2 * r, 2 * r + 1):
+            e.warp_feed(frames[i], cams[i], rois[i])
+        engs.append(e)
+    a0, a1 = engs[0].accumulators(), engs[1].accumulators()
+    for (l0, w0), (l1, w1) in zip(a0, a1):
+        w0.copy_((torch.zeros_like(w0) + w0) + w1)          # ((0 + p0) + p1)
+        l0.copy_((l0.to(torch.int32) + l1.to(torch.int32)).to(torch.int16))   # wraps
+    pano, mask = engs[0].finalize()
+    assert np.array_equal(got["mask"], mask)
+    assert np.array_equal(got["pano"], pano)
+
+
+def test_strip_plan_covers_what_a_strip_needs():
+    """Strip bounds tile the padded panorama on 2^bands boundaries; the need ranges follow pyrUp's reach; the exchange
+    rectangles of a rank are its region clipped to them, with 16-byte aligned blocks."""
     from image_stitching_amd.distributed import StitchJob
-    g = torch.Generator().manual_seed(5)
-    levels = []
-    w, h = 64, 32
-    for l in range(3):
-        levels.append((torch.randint(-32768, 32767, (h, w * 3), generator=g, dtype=torch.int16), torch.rand((h, w), generator=g)))
-        w, h = w // 2, h // 2
-    region = (8, 4, 40, 28)
-    rects = StitchJob._level_rects(region, levels)
-    assert rects == [(8, 4, 40, 28), (4, 2, 20, 14), (2, 1, 10, 7)]
-    buf = StitchJob._pack(levels, rects, StitchJob._packed_size(rects) + 64)
-    dst = [(torch.full_like(a, 30000), torch.ones_like(b)) for a, b in levels]
-    StitchJob._add_packed(dst, rects, buf)
-    for (a, b), (da, db), (x0, y0, x1, y1) in zip(levels, dst, rects):
-        exp = (a.to(torch.int32) + 30000).to(torch.int16)                  # two's-complement wrap
-        assert torch.equal(da[y0:y1, 3 * x0:3 * x1], exp[y0:y1, 3 * x0:3 * x1])
-        assert torch.equal(db[y0:y1, x0:x1], b[y0:y1, x0:x1] + 1)
-        outside = torch.ones_like(db, dtype=torch.bool)
-        outside[y0:y1, x0:x1] = False
-        assert bool((db[outside] == 1).all()) and bool((da[outside.repeat_interleave(3, 1)] == 30000).all())
+    sizes = [(1024 >> l, 256 >> l) for l in range(5)]            # 4 bands
+    b = StitchJob.strip_bounds(1024, 4, 3)
+    assert b == [(0, 336), (336, 672), (672, 1024)] and all(x % 16 == 0 for bb in b for x in bb)
+    need = StitchJob.need_ranges(b[1], sizes)
+    assert need[0] == (336, 672) and need[1] == (167, 337) and need[2] == (82, 170) and need[4][0] >= 0 and need[4][1] <= 64
+    # the recurrence reproduces what blend_columns collapses: every fine column of need[l] has its three coarse columns in need[l + 1]
+    for l in range(4):
+        lo, hi = need[l]
+        assert need[l + 1][0] <= max(0, (lo >> 1) - 1) and need[l + 1][1] >= min(sizes[l + 1][0], ((hi - 1) >> 1) + 2)
+    rects, nbytes = StitchJob.exchange_rects((320, 16, 720, 240), need, sizes)
+    assert rects[0][:5] == (0, 336, 16, 672, 240) and rects[1][:5] == (1, 167, 8, 337, 120)
+    assert all(r[5] % 16 == 0 for r in rects) and nbytes % 16 == 0
+    assert StitchJob.exchange_rects(None, need, sizes) == ([], 0)
+    assert StitchJob.exchange_rects((0, 0, 320, 64), need, sizes)[0][0][:3] == (4, 19, 0)      # a region left of the strip only meets its coarse halo
 
 
 def test_job_refuses_options_it_does_not_run():

@@ -1,6 +1,7 @@
-"""GPU: the HipEngine side of the sharded job (feature packing for the all-gather, raw-pointer tensor
-views of the blender pyramids, packed region exchange) exercised at world size 1 with the collective code
-paths forced on; the result must equal the plain single-GPU path bit for bit."""
+"""GPU: the HipEngine side of the sharded job (feature packing for the all-gather, raw-pointer tensor views of the blender
+pyramids, the column-strip exchange: pack / zero / add of pyramid rectangles, per-strip finalise, strip assembly) exercised at
+world size 1 with the collective code paths forced on -- the result must equal the plain single-GPU path bit for bit -- and as
+two and three processes on the one GPU of the box."""
 import numpy as np
 import pytest
 
@@ -25,6 +26,52 @@ def test_forced_collective_paths_match_plain_job(ctx):
     for a, b in zip(forced["matches"], plain["matches"]):
         assert np.array_equal(a.matches, b.matches) and np.array_equal(a.inliers_mask, b.inliers_mask)
     assert torch.equal(forced["pano"], plain["pano"]) and torch.equal(forced["mask"], plain["mask"])
+
+
+def test_blend_columns_and_rect_exchange_equal_full_blend(ctx):
+    """mis_blender_blend_columns on 2^bands-aligned column strips (each from freshly fed accumulators, as each rank has its
+    own) reproduces the columns of the full blend; pack -> zero -> add of the need ranges leaves the result unchanged."""
+    import ctypes as C
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd.distributed import HipEngine, StitchJob
+    w, h = 480, 270
+    cams = [synth.make_camera(w, h, 60.0, 13.0 * i - 20.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(4)]
+    frames = [torch.from_numpy(synth.render_frame(c)).cuda() for c in cams]
+    eng = HipEngine(ctx, (w, h))
+    scale = isa.Stitcher.warped_image_scale(cams)
+    rois = eng.warp_rois(scale, cams)
+    corners, sizes = [(r[0], r[1]) for r in rois], [(r[2], r[3]) for r in rois]
+
+    def feed_all():
+        with torch.cuda.stream(eng.compose_stream):
+            eng.begin_compose(scale, corners, sizes)
+            for f, c, r in zip(frames, cams, rois):
+                eng.warp_feed(f, c, r)
+    feed_all()
+    with torch.cuda.stream(eng.compose_stream):
+        full, fmask = eng.finalize()
+    torch.cuda.synchronize()
+    pw, ph = eng.pano_size
+    feed_all()
+    lsz = eng.level_sizes()
+    bands = len(lsz) - 1
+    assert bands >= 3
+    bounds = StitchJob.strip_bounds(lsz[0][0], bands, 3)
+    for k, (x0, x1) in enumerate(bounds):
+        if k:
+            feed_all()
+        need = StitchJob.need_ranges((x0, x1), lsz)
+        rects, nbytes = StitchJob.exchange_rects((0, 0, lsz[0][0], lsz[0][1]), need, lsz)
+        with torch.cuda.stream(eng.compose_stream):
+            buf = eng.pack_rects(rects, nbytes)
+            eng.zero_rects([(l, lo, 0, hi, lsz[l][1], 0) for l, (lo, hi) in enumerate(need)])
+            eng.add_rects(rects, buf)
+            img, msk = eng.finalize_columns(x0, x1)
+        torch.cuda.synchronize()
+        x1c = min(x1, pw)
+        assert torch.equal(img, full[:, x0:x1c]) and torch.equal(msk, fmask[:, x0:x1c]), k
 
 
 def test_accumulator_views_alias_blender_memory(ctx):
@@ -123,6 +170,58 @@ def test_two_ranks_on_one_gpu_match_single_rank(ctx, tmp_path):
     assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
     d = np.abs(got["pano"].astype(np.int32) - ref["pano"].cpu().numpy().astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.02          # f32 weight sums in a different order where >= 3 frames overlap
+
+
+def _gpu_rank6(rank, world, port, out_path):
+    """One rank of a 3-process job over 6 frames on the same GPU (3 strips, halos crossing two owners)."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth
+        import image_stitching_amd as isa
+        from image_stitching_amd.distributed import StitchJob
+        w, h = 480, 270
+        cams = [synth.make_camera(w, h, 60.0, 24.0 * i - 60.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(6)]
+        ctx = isa.Context(0)
+        job = StitchJob(ctx, (w, h), cams, rank=rank, world_size=world, group=dist.group.WORLD)
+        frames = {i: torch.from_numpy(synth.render_frame(cams[i])).cuda() for i in job.my_frames}
+        out = job.run(frames)
+        if rank == 0:
+            np.savez(out_path, pano=out["pano"].cpu().numpy(), mask=out["mask"].cpu().numpy(), indices=np.array(out["indices"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_on_one_gpu_match_single_rank(ctx, tmp_path):
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    import synth
+    from image_stitching_amd.distributed import StitchJob
+    w, h = 480, 270
+    cams = [synth.make_camera(w, h, 60.0, 24.0 * i - 60.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(6)]
+    frames = {i: torch.from_numpy(synth.render_frame(c)).cuda() for i, c in enumerate(cams)}
+    ref = StitchJob(ctx, (w, h), cams).run(frames)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "rank0.npz")
+    mp.start_processes(_gpu_rank6, args=(3, port, out_path), nprocs=3, join=True, start_method="spawn")
+    got = np.load(out_path)
+    assert list(got["indices"]) == ref["indices"]
+    assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
+    d = np.abs(got["pano"].astype(np.int32) - ref["pano"].cpu().numpy().astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
 
 
 @pytest.mark.parametrize("stray", [False, True])
