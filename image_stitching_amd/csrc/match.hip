@@ -88,6 +88,126 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
     }
 }
 
+// ---------------------------------------------------------------- K7 on the matrix cores --------
+// Hamming-256 as an exact int8 GEMM (north star: "MFMA only if descriptor distance is cast as a dense GEMM").  Every bit
+// becomes one int8: trains +64 / -64, queries -64 / +64 (set / clear), so a product is -4096 where the bits agree and +4096
+// where they differ, and the 256-term dot product is 8192 * hamming - 2^20.  With the accumulator preloaded with
+// 2^20 + trainIdx the MFMA chain (8 x v_mfma_i32_32x32x32_i8) delivers the search key 8192 * hamming + trainIdx itself: the
+// running top two of a query are again a min and a median-of-three per candidate, nothing else.  The vector pipe of the scalar
+// kernel above paid 8 xor + 8 bcnt per distance (56 cycles per wave-distance, issue bound at 1.98 ms per 16 x 4K job); here a
+// 32 x 32 tile of distances costs 8 MFMAs (256 matrix-pipe cycles) + 32 vector instructions per lane.  Keys need
+// trainIdx < 8192: larger train sets take the scalar kernel.
+// Layout: accumulator register g of lane (r, h) = query r (B column) x train (g & 3) + 8 (g >> 2) + 4 h (A row) of the tile;
+// a lane's two running keys per query set cover half of the trains, the halves are merged at the end.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int HM_PITCH = 272;          // LDS pitch of an expanded descriptor row (256 B + 16: the 16-byte fragment reads of 32 rows spread over the banks)
+constexpr int HM_ROWPAD = 256;         // expanded blocks are padded with zero rows to a multiple of this
+constexpr int HM_MAX_TRAINS = 8192;
+constexpr int HM_NONE = 0x7f000000;
+
+struct HmFrame { size_t train_off, query_off; };   // byte offsets of a frame's two expanded forms
+
+// one thread per (descriptor, 32-bit word): 32 bits -> 32 bytes of each form; rows >= n are zero (they contribute a dot product of 0)
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const FeatDev* feats, const HmFrame* fr, int8_t* out) {
+    const FeatDev F = feats[blockIdx.y];
+    const int npad = (F.n + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
+    const int item = blockIdx.x * 256 + threadIdx.x, d = item >> 3, w = item & 7;
+    if (d >= npad) return;
+    const bool live = d < F.n;
+    const unsigned x = live ? reinterpret_cast<const unsigned*>(F.desc)[(size_t)d * 8 + w] : 0u;
+    unsigned tq[8], qq[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned s = (((x >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;    // bits 4k .. 4k+3 -> bit 0 of bytes 0 .. 3
+        tq[k] = live ? (0xC0C0C0C0u ^ (s * 0x80u)) : 0u;                                // +64 (set) / -64 (clear)
+        qq[k] = live ? (0x40404040u ^ (s * 0x80u)) : 0u;                                // -64 (set) / +64 (clear)
+    }
+    uint4* to = reinterpret_cast<uint4*>(out + fr[blockIdx.y].train_off + (size_t)d * 256 + 32 * w);
+    uint4* qo = reinterpret_cast<uint4*>(out + fr[blockIdx.y].query_off + (size_t)d * 256 + 32 * w);
+    to[0] = make_uint4(tq[0], tq[1], tq[2], tq[3]); to[1] = make_uint4(tq[4], tq[5], tq[6], tq[7]);
+    qo[0] = make_uint4(qq[0], qq[1], qq[2], qq[3]); qo[1] = make_uint4(qq[4], qq[5], qq[6], qq[7]);
+}
+
+__global__ __launch_bounds__(256) void knn2_hamming_mfma_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
+                                                                float* dist2) {
+    __shared__ __attribute__((aligned(16))) int8_t tr[2][32 * HM_PITCH];
+    const PairDesc pd = pairs[blockIdx.y >> 1];
+    const bool fwd = (blockIdx.y & 1) == 0;
+    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
+    const int nq = feats[qi].n, nt = feats[ti].n;
+    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
+    const int q0 = blockIdx.x * 256;
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int8_t* qx = xp + fr[qi].query_off;
+    const int8_t* tx = xp + fr[ti].train_off;
+    // the wave's 2 x 32 queries as B fragments (step s, lane (r, h): bytes 32 s + 16 h .. + 15 of query r), in registers for the whole pass
+    v4i bq[2][8];
+#pragma unroll
+    for (int set = 0; set < 2; set++)
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++)
+            bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
+    int cbase[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) cbase[g] = (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
+    int k0[2] = {HM_NONE, HM_NONE}, k1[2] = {HM_NONE, HM_NONE};
+    const int ntiles = (nt + 31) / 32;
+    // a tile = 32 expanded trains = 8 KB: two 16-byte pieces per thread, tile t + 1 fetched while tile t is multiplied
+    const int prow = threadIdx.x >> 3, pcol = (threadIdx.x & 7) * 32;
+    {
+        const v4i* g = reinterpret_cast<const v4i*>(tx + (size_t)prow * 256 + pcol);
+        v4i* l = reinterpret_cast<v4i*>(&tr[0][prow * HM_PITCH + pcol]);
+        l[0] = g[0]; l[1] = g[1];
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1, t0 = t * 32;
+        v4i pre0 = {0, 0, 0, 0}, pre1 = {0, 0, 0, 0};
+        if (t + 1 < ntiles) {
+            const v4i* g = reinterpret_cast<const v4i*>(tx + (size_t)(t0 + 32 + prow) * 256 + pcol);
+            pre0 = g[0]; pre1 = g[1];
+        }
+        v4i a[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[buf][r * HM_PITCH + 32 * s8 + 16 * h]);
+        const bool full = t0 + 32 <= nt;    // wave-uniform: only the last tile can hold rows past the train set
+#pragma unroll
+        for (int set = 0; set < 2; set++) {
+            v16i acc;
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[g] = (full || (cbase[g] - (1 << 20)) + t0 < nt) ? cbase[g] + t0 : HM_NONE;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s8], bq[set][s8], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const int key = acc[g];
+                // k0 <= k1 always: the new second best is the median of (k0, k1, key), the new best the minimum
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(k1[set]) : "v"(k0[set]), "v"(k1[set]), "v"(key));
+                k0[set] = min(k0[set], key);
+            }
+        }
+        if (t + 1 < ntiles) {
+            v4i* l = reinterpret_cast<v4i*>(&tr[buf ^ 1][prow * HM_PITCH + pcol]);
+            l[0] = pre0; l[1] = pre1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+        // the other half of the trains sits in lane (r, 1 - h)
+        const int o0 = __shfl_xor(k0[set], 32), o1 = __shfl_xor(k1[set], 32);
+        const int b0 = min(k0[set], o0), b1 = min(max(k0[set], o0), min(k1[set], o1));
+        const int q = q0 + wave * 64 + set * 32 + r;
+        if (h == 0 && q < nq) {
+            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
+            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
+            dist2[(off + q) * 2] = (float)(v0 ? b0 >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? b1 >> 13 : 1 << 30);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K8: exact 2-NN, L2 on MFMA ----
 // SIFT descriptors are integer valued (0..255, stored as f32): they are exact in fp16, every dot
 // product of two 128-D descriptors is an integer < 2^24 and therefore exact in the f32 accumulator of
@@ -571,7 +691,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if ((rc = homo_batch_reserve(ctx, &ws->b3, np, (long long)m_total, p->max_iters)) != MIS_OK) return rc;
     // pinned host mirror of everything that comes back
     Carver hc;
-    const size_t h_in = hc.take(sizeof(FeatDev) * n + sizeof(PairDesc) * np + 512), h_nm = hc.take(sizeof(int) * np), h_out = hc.take(sizeof(PairOut) * np),
+    const size_t h_in = hc.take(sizeof(FeatDev) * n + sizeof(PairDesc) * np + sizeof(HmFrame) * n + 1024), h_nm = hc.take(sizeof(int) * np), h_out = hc.take(sizeof(PairOut) * np),
                  h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total);
     MIS_HIP(ctx, ws->pinned.reserve(hc.off));
     uint8_t* Hh = (uint8_t*)ws->pinned.p;
@@ -581,8 +701,27 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipMemcpyAsync(d_feats, Hh + h_in, sizeof(FeatDev) * n, hipMemcpyHostToDevice, st));
     MIS_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(PairDesc) * np, hipMemcpyHostToDevice, st));
     int l2_bad = 0;
-    if (!use_l2) {
+    static const bool hm_scalar = getenv("MIS_KNN_SCALAR") != nullptr;     // diagnostics: the vector-pipe kernel
+    if (!use_l2 && (maxq > HM_MAX_TRAINS || hm_scalar)) {
         hipLaunchKernelGGL(knn2_hamming_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, d_idx, d_dist);
+    } else if (!use_l2) {
+        // every frame's descriptors once as int8 (train form and query form), then all directed pairs in one MFMA launch
+        std::vector<HmFrame> hf(n);
+        Carver lc;
+        const size_t o_fr = lc.take(sizeof(HmFrame) * n);
+        for (int i = 0; i < n; i++) {
+            const size_t rows = (size_t)(std::max(feats[i].n, 1) + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
+            hf[i].train_off = lc.take(rows * 256); hf[i].query_off = lc.take(rows * 256);
+        }
+        MIS_HIP(ctx, ws->l2.reserve(lc.off));
+        uint8_t* L = (uint8_t*)ws->l2.p;
+        HmFrame* h_fr = (HmFrame*)(Hh + h_in + mis_align_up(sizeof(FeatDev) * n, 256) + mis_align_up(sizeof(PairDesc) * np, 256));
+        memcpy(h_fr, hf.data(), sizeof(HmFrame) * n);
+        MIS_HIP(ctx, hipMemcpyAsync(L + o_fr, h_fr, sizeof(HmFrame) * n, hipMemcpyHostToDevice, st));
+        const int maxpad = (maxq + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
+        hipLaunchKernelGGL(hamming_expand_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
+        hipLaunchKernelGGL(knn2_hamming_mfma_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+                           (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist);
     } else {
         // fp16 copies + squared norms of every image once, then one MFMA distance pass per directed pair
         std::vector<size_t> hoff(n), noff(n);
