@@ -85,7 +85,7 @@ def main():
     W, H = cams[0]["width"], cams[0]["height"]
     ctx = isa.Context(local_rank)
     features = args.features or ("sift" if workload == "config5" else "orb")
-    cfg = isa.StitchConfig(features_type=features)
+    cfg = isa.StitchConfig.hot_path(features_type=features)   # the north-star path: no exposure / seam step (SURVEY rows N1b are "next")
     job = misdist.StitchJob(ctx, (W, H), cams, rank=rank, world_size=world, group=pg, config=cfg)
     # synthetic frames of this rank's shard, rendered straight into HBM
     frames = {i: synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in job.my_frames}

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "mis_compensator_gain_map": (_i, [_vp, _i, _P(C.c_float), _i, _P(_i), _P(_i)]),
     "mis_compensator_apply": (_i, [_vp, _i, _P(MisImage)]),
     "mis_seam_voronoi": (_i, [_vp, _P(MisPoint), _P(MisImage), _i]),
+    "mis_seam_dp": (_i, [_vp, _P(MisPoint), _P(MisImage), _P(MisImage), _i, _i]),
     "mis_warp_spherical_fused_timed": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint), _i, _P(C.c_float)]),
     "mis_blend_config": (_i, [_i, _f, _i, _i, _P(_i), _P(_i), _P(_f)]),
     "mis_result_roi": (_i, [_P(MisPoint), _P(MisSize), _i, _P(MisRect)]),

@@ -138,7 +138,7 @@ class HipEngine:
 
     def __init__(self, ctx, frame_size, config=None):
         self.ctx = ctx
-        self.cfg = config or st.StitchConfig()
+        self.cfg = config or st.StitchConfig.hot_path()
         self.frame_size = frame_size
         # finder per features_type (image_stitching.cpp:543-563): ORB, or SIFT (float descriptors -> the L2 matcher)
         self.finder = st.SiftFeatureFinder(ctx, frame_size) if self.cfg.features_type == "sift" else st.OrbFeatureFinder(ctx, frame_size)
@@ -334,7 +334,7 @@ class StitchJob:
     """The hot-path sequence of main() (image_stitching.cpp:567-1228) for one panorama, sharded."""
 
     def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
-        self.cfg = config or st.StitchConfig()
+        self.cfg = config or st.StitchConfig.hot_path()
         if self.cfg.ba_cost_func != "no" and world_size > 1:
             raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         if self.cfg.expos_comp_type != "no" or self.cfg.seam_find_type != "no":

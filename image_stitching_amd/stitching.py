@@ -301,6 +301,23 @@ class VoronoiSeamFinder:
         return masks
 
 
+class DpSeamFinder:
+    """seam_find_type "dp_color" -- the reference's default (image_stitching.cpp:77, :1056-1057, :1065): DpSeamFinder(COLOR).
+    images: the seam-scale warped 8UC3 images; masks are edited in place."""
+    COLOR = 0
+
+    def __init__(self, ctx, cost_func=0):
+        self.ctx, self.cost_func = ctx, cost_func
+
+    def find(self, images, corners, masks):
+        n = len(masks)
+        cs = (capi.MisPoint * n)(*[capi.MisPoint(int(c[0]), int(c[1])) for c in corners])
+        im = (capi.MisImage * n)(*[as_image(i) for i in images])
+        mk = (capi.MisImage * n)(*[as_image(m) for m in masks])
+        self.ctx.check(self.ctx.lib.mis_seam_dp(self.ctx.h, cs, im, mk, n, int(self.cost_func)))
+        return masks
+
+
 # ------------------------------------------------------------------------------------------------
 # blend: cv::detail::Blender / MultiBandBlender / FeatherBlender (image_stitching.cpp:1173-1225)
 def result_roi(corners, sizes):
@@ -826,12 +843,20 @@ class StitchConfig:
     ba_cost_func: str = "no"          # "no" | "reproj"
     ba_refine_mask: str = "_____"     # the reference's default (image_stitching.cpp:67): rotations only
     wave_correct: str = "horiz"       # "horiz" | "vert" | "no"; applied after the bundle adjustment only
-    # the seam-scale step between warp and blend (image_stitching.cpp:940-1070, :1162-1171).  The reference's defaults are
-    # "gain_blocks" and "dp_color"; DpSeamFinder is not implemented here (asking for it raises), so both default to "no".
-    expos_comp_type: str = "no"       # "no" | "gain_blocks"
+    # the seam-scale step between warp and blend (image_stitching.cpp:940-1070, :1162-1171), the reference's defaults
+    # (:73-77): block gain compensation and the dynamic-programming colour seam finder
+    expos_comp_type: str = "gain_blocks"   # "no" | "gain_blocks"
     expos_comp_block_size: int = 64
     expos_comp_nr_filtering: int = 2
-    seam_find_type: str = "no"        # "no" | "voronoi"
+    seam_find_type: str = "dp_color"       # "no" | "voronoi" | "dp_color"
+
+    @classmethod
+    def hot_path(cls, **kw):
+        """The configuration of the north-star hot path (features -> match -> warp -> blend): no exposure compensation and no
+        seam finder (the steps between warp and blend); everything else as given."""
+        kw.setdefault("expos_comp_type", "no")
+        kw.setdefault("seam_find_type", "no")
+        return cls(**kw)
 
 
 class Stitcher:
@@ -897,9 +922,9 @@ class Stitcher:
         """The seam-scale pass of main() (image_stitching.cpp:604-622 resize, :973-990 warp, :1002-1023 exposure
         compensator feed, :1029-1065 seam finder) -> (compensator | None, masks_warped) or None when both are off."""
         cfg = self.cfg
-        if cfg.seam_find_type not in ("no", "voronoi"):
-            raise NotImplementedError("seam_find_type %r: only 'no' and 'voronoi' are implemented (DpSeamFinder / GraphCut "
-                                      "are outside this library; DESIGN.md section 9)" % (cfg.seam_find_type,))
+        if cfg.seam_find_type not in ("no", "voronoi", "dp_color"):
+            raise NotImplementedError("seam_find_type %r: 'no', 'voronoi' and 'dp_color' are implemented (dp_colorgrad and the "
+                                      "graph-cut finders are outside this library; DESIGN.md section 8)" % (cfg.seam_find_type,))
         if cfg.expos_comp_type not in ("no", "gain_blocks"):
             raise NotImplementedError("expos_comp_type %r: only 'no' and 'gain_blocks' are implemented" % (cfg.expos_comp_type,))
         if cfg.expos_comp_type == "no" and cfg.seam_find_type == "no":
@@ -924,6 +949,8 @@ class Stitcher:
             compensator.feed(corners, images_warped, masks_warped)
         if cfg.seam_find_type == "voronoi":
             VoronoiSeamFinder(self.ctx).find(images_warped, corners, masks_warped)
+        elif cfg.seam_find_type == "dp_color":
+            DpSeamFinder(self.ctx, DpSeamFinder.COLOR).find(images_warped, corners, masks_warped)
         return compensator, masks_warped
 
     def stitch(self, frames, cameras):

@@ -256,6 +256,12 @@ int mis_compensator_apply(MisCompensator* c, int index, MisImage* image);
 /* VoronoiSeamFinder::find (seam_find_type "voronoi", image_stitching.cpp:1031): masks (8UC1) are edited in place.
  * "no" (NoSeamFinder) needs no call.  The reference's default, DpSeamFinder(COLOR) ("dp_color"), is not implemented. */
 int mis_seam_voronoi(MisContext* ctx, const MisPoint* corners, MisImage* masks, int n);
+/* seam_finder = makePtr<detail::DpSeamFinder>(DpSeamFinder::COLOR); seam_finder->find(images_warped_f, corners, masks_warped)
+ * -- replaces image_stitching.cpp:1056-1057, :1065 (the reference's default seam finder, "dp_color").  images: the seam-scale
+ * warped 8UC3 images (converted to float inside, as :992-994 does); masks: 8U, edited in place.  Host logic on copies of the
+ * (~0.1 MP) images; device or host buffers.  cost_func: MIS_SEAM_DP_COLOR (COLOR_GRAD is not built). */
+#define MIS_SEAM_DP_COLOR 0
+int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisImage* images, MisImage* masks, int n, int cost_func);
 
 /* ---------------------------------------------------------------- blend --------------------- */
 /* reference-side blender sizing, image_stitching.cpp:1176-1190: returns the blend type to use in

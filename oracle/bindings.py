@@ -771,3 +771,18 @@ def voronoi_seams(corners, masks):
     mp = (C.c_void_p * n)(*[m.ctypes.data for m in msks])
     lib().mo_voronoi_seams(n, _p(c), _p(s), mp)
     return msks
+
+
+def dp_seams(images, corners, masks):
+    """DpSeamFinder(COLOR)::find (image_stitching.cpp:1056-1065) on 8UC3 seam-scale images; returns the updated masks."""
+    n = len(masks)
+    msks = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
+    imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+    c = np.ascontiguousarray(corners, np.int32).reshape(n, 2)
+    s = np.array([[m.shape[1], m.shape[0]] for m in msks], np.int32)
+    ip = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in msks])
+    L = lib()
+    L.mo_seam_dp_color.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mo_seam_dp_color(n, _p(c), _p(s), ip, mp)
+    return msks

@@ -57,7 +57,7 @@ def test_config2_1080p_pair_match_and_warp(ctx, oracle_mod):
     cams = synth.workload("config2")
     dev, host = _render(cams)
     ref = ojob.stitch_job(host, cams, keep_warped=True)
-    st = isa.Stitcher(ctx, (1920, 1080), isa.StitchConfig(compose_megapix=-1))
+    st = isa.Stitcher(ctx, (1920, 1080), isa.StitchConfig.hot_path(compose_megapix=-1))
     feats = st.features(dev)
     _compare_features(feats, ref["features"])
     pm = st.match(feats)

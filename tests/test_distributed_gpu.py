@@ -102,7 +102,7 @@ def test_sift_job_forced_collectives_match_plain_job(ctx):
     w, h = 480, 270
     cams = [synth.make_camera(w, h, 60.0, 11.0 * i - 16.0, 0.4 * ((i % 3) - 1)) for i in range(4)]
     frames = {i: torch.from_numpy(synth.render_frame(c)).cuda() for i, c in enumerate(cams)}
-    cfg = isa.StitchConfig(features_type="sift")
+    cfg = isa.StitchConfig.hot_path(features_type="sift")
     plain = StitchJob(ctx, (w, h), cams, config=cfg).run(frames)
     forced = StitchJob(ctx, (w, h), cams, config=cfg, force_collectives=True).run(frames)
     assert plain["indices"] == forced["indices"] == [0, 1, 2, 3]
@@ -258,7 +258,7 @@ def test_job_equals_the_per_call_stitcher(ctx):
     cams = [synth.make_camera(w, h, 60.0, 12.0 * i - 18.0, 0.5 * ((i % 3) - 1), 0.25 * ((i % 2) - 0.5)) for i in range(5)]
     dev = [torch.from_numpy(synth.render_frame(c)).cuda() for c in cams]
     job = StitchJob(ctx, (w, h), cams).run({i: f for i, f in enumerate(dev)})
-    pano, mask, feats, pm, idx = isa.Stitcher(ctx, (w, h), isa.StitchConfig(compose_megapix=-1)).stitch(dev, cams)
+    pano, mask, feats, pm, idx = isa.Stitcher(ctx, (w, h), isa.StitchConfig.hot_path(compose_megapix=-1)).stitch(dev, cams)
     assert list(idx) == job["indices"] == [0, 1, 2, 3, 4]
     assert np.array_equal(job["confidence"].cpu().numpy().reshape(-1), np.array([m.confidence for m in pm]))
     assert torch.equal(job["pano"], pano) and torch.equal(job["mask"], mask)

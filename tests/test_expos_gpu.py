@@ -164,6 +164,8 @@ def _oracle_compose(o, frames, cams, cfg, frame_size):
         comp.feed(corners, iw, mw)
     if cfg.seam_find_type == "voronoi":
         mw = o.voronoi_seams(corners, mw)
+    elif cfg.seam_find_type == "dp_color":
+        mw = o.dp_seams(iw, corners, mw)
     items = []
     for k, (f, cam) in enumerate(zip(frames, cams)):
         K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
@@ -184,7 +186,7 @@ def _oracle_compose(o, frames, cams, cfg, frame_size):
     return b.blend()
 
 
-@pytest.mark.parametrize("expos,seam", [("gain_blocks", "voronoi"), ("gain_blocks", "no"), ("no", "voronoi")])
+@pytest.mark.parametrize("expos,seam", [("gain_blocks", "voronoi"), ("gain_blocks", "no"), ("no", "voronoi"), ("gain_blocks", "dp_color"), ("no", "dp_color")])
 def test_stitcher_compose_with_seam_step_matches_oracle(ctx, oracle_mod, expos, seam):
     """Three frames with different exposures through seam-scale warp -> gains -> seams -> compose -> multiband blend."""
     import synth
@@ -199,13 +201,67 @@ def test_stitcher_compose_with_seam_step_matches_oracle(ctx, oracle_mod, expos, 
     want, wmask = _oracle_compose(oracle_mod, frames, cams, cfg, (W, H))
     assert np.array_equal(mask.cpu().numpy(), wmask)
     assert np.array_equal(pano.cpu().numpy(), want)
-    plain, _ = isa.Stitcher(ctx, (W, H), isa.StitchConfig()).compose([torch.from_numpy(f).cuda() for f in frames], cams)
+    plain, _ = isa.Stitcher(ctx, (W, H), isa.StitchConfig.hot_path()).compose([torch.from_numpy(f).cuda() for f in frames], cams)
     assert not np.array_equal(plain.cpu().numpy(), want), "the seam step must change the panorama"
+
+
+def _seam_scene(n, W=960, H=540, step=14.0):
+    import synth
+    cams = [synth.make_camera(W, H, 60.0, step * i, 0.8 * ((i % 3) - 1), -0.5 * ((i % 2) - 0.5)) for i in range(n)]
+    return cams, [synth.render_frame(c) for c in cams]
+
+
+@pytest.mark.parametrize("n,step", [(2, 14.0), (4, 11.0), (5, 23.0)])
+def test_dp_seam_finder_matches_oracle(ctx, oracle_mod, n, step):
+    """DpSeamFinder(COLOR) -- the reference's default seam finder -- on seam-scale warped frames: the library's masks equal the
+    oracle's, every pair resolved (no pixel stays in two masks of a pair that overlapped), nothing outside the input masks."""
+    import image_stitching_amd as isa
+    o = oracle_mod
+    W, H = 960, 540
+    cams, frames = _seam_scene(n, W, H, step)
+    scale = isa.Stitcher.warped_image_scale(cams)
+    seam_scale = min(1.0, float(np.sqrt(0.1e6 / (W * H))))
+    swa = np.float32(seam_scale)
+    warper = isa.SphericalWarper(ctx, np.float32(np.float32(scale) * swa))
+    corners, iw, mw = [], [], []
+    for f, cam in zip(frames, cams):
+        img = isa.resize(ctx, torch.from_numpy(f).cuda(), fx=seam_scale, fy=seam_scale)
+        K = np.array(cam["K"], np.float32).copy()
+        K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
+        R = np.asarray(cam["R"], np.float32)
+        tl, wi = warper.warp(img, K, R, isa.INTER_LINEAR, isa.BORDER_REFLECT)
+        _, wm = warper.warp(torch.full(img.shape[:2], 255, dtype=torch.uint8, device="cuda"), K, R, isa.INTER_NEAREST, isa.BORDER_CONSTANT)
+        corners.append(tl); iw.append(wi); mw.append(wm)
+    before = [m.cpu().numpy().copy() for m in mw]
+    want = o.dp_seams([i.cpu().numpy() for i in iw], corners, before)
+    isa.DpSeamFinder(ctx).find(iw, corners, mw)
+    got = [m.cpu().numpy() for m in mw]
+    changed = 0
+    for g, w_, b in zip(got, want, before):
+        assert np.array_equal(g, w_)
+        assert not np.any((g > 0) & (b == 0))
+        changed += int(np.count_nonzero(g != b))
+    assert changed > 1000                       # overlapping frames: the seams did cut
+    # a pair that overlaps keeps no common pixel
+    for i in range(n):
+        for j in range(i + 1, n):
+            x0, y0 = max(corners[i][0], corners[j][0]), max(corners[i][1], corners[j][1])
+            x1 = min(corners[i][0] + got[i].shape[1], corners[j][0] + got[j].shape[1])
+            y1 = min(corners[i][1] + got[i].shape[0], corners[j][1] + got[j].shape[0])
+            if x0 < x1 and y0 < y1:
+                a = got[i][y0 - corners[i][1]:y1 - corners[i][1], x0 - corners[i][0]:x1 - corners[i][0]]
+                b = got[j][y0 - corners[j][1]:y1 - corners[j][1], x0 - corners[j][0]:x1 - corners[j][0]]
+                assert not np.any((a > 0) & (b > 0)), (i, j)
+    # host buffers take the same path
+    hm = [b.copy() for b in before]
+    isa.DpSeamFinder(ctx).find([i.cpu().numpy() for i in iw], corners, hm)
+    for g, h in zip(got, hm):
+        assert np.array_equal(g, h)
 
 
 def test_unbuilt_seam_finders_are_refused(ctx):
     import image_stitching_amd as isa
-    st = isa.Stitcher(ctx, (64, 64), isa.StitchConfig(seam_find_type="dp_color"))
+    st = isa.Stitcher(ctx, (64, 64), isa.StitchConfig(seam_find_type="gc_color"))
     with pytest.raises(NotImplementedError):
         st.seam_step([], [], [], 100.0)
     st = isa.Stitcher(ctx, (64, 64), isa.StitchConfig(expos_comp_type="channels"))

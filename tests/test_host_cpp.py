@@ -74,7 +74,7 @@ def test_stitch_main_matches_python_pipeline(tmp_path, ctx, oracle_mod):
     hdr, rest = raw.split(b"\n255\n", 1)
     pw, ph = [int(v) for v in hdr.split(b"\n")[1].split()]
     got = np.frombuffer(rest, np.uint8).reshape(ph, pw, 3)[:, :, ::-1]
-    st = isa.Stitcher(ctx, (frames[0].shape[1], frames[0].shape[0]), isa.StitchConfig(compose_megapix=-1))
+    st = isa.Stitcher(ctx, (frames[0].shape[1], frames[0].shape[0]), isa.StitchConfig.hot_path(compose_megapix=-1))
     res, mask, feats, pm, idx = st.stitch([torch.from_numpy(f).cuda() for f in frames], cams)
     assert list(idx) == [0, 1, 2]
     exp = np.clip(res.cpu().numpy(), 0, 255).astype(np.uint8)
@@ -102,10 +102,10 @@ def test_stitch_main_seam_step_and_sift_match_python_pipeline(tmp_path, ctx, ora
     r = subprocess.run([exe, str(tmp_path), "--expos_comp", "gain_blocks", "--seam", "voronoi"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     got = _read_ppm(os.path.join(str(tmp_path), "result.ppm"))
-    st = isa.Stitcher(ctx, size, isa.StitchConfig(compose_megapix=-1, expos_comp_type="gain_blocks", seam_find_type="voronoi"))
+    st = isa.Stitcher(ctx, size, isa.StitchConfig.hot_path(compose_megapix=-1, expos_comp_type="gain_blocks", seam_find_type="voronoi"))
     res, _ = st.compose(dev, cams)
     assert np.array_equal(np.clip(res.cpu().numpy(), 0, 255).astype(np.uint8), got)
-    plain, _ = isa.Stitcher(ctx, size, isa.StitchConfig(compose_megapix=-1)).compose(dev, cams)
+    plain, _ = isa.Stitcher(ctx, size, isa.StitchConfig.hot_path(compose_megapix=-1)).compose(dev, cams)
     assert not np.array_equal(np.clip(plain.cpu().numpy(), 0, 255).astype(np.uint8), got)
     # SIFT features: same panorama (the cameras are inputs), all frames kept, SIFT-sized feature counts in the log
     r = subprocess.run([exe, str(tmp_path), "--features", "sift"], capture_output=True, text=True)

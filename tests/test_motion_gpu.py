@@ -117,7 +117,7 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
         d = dict(c)
         d["R"] = synth.rotation_yxz(*np.radians(rng.normal(0, 0.5, 3))) @ c["R"]
         noisy.append(d)
-    job = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig(ba_cost_func="reproj", ba_refine_mask="xxxxx"))
+    job = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig.hot_path(ba_cost_func="reproj", ba_refine_mask="xxxxx"))
     out = job.run(frames)
     assert out["indices"] == list(range(n))
     # The adjustment minimises the reprojection error of the inlier matches; with focal, aspect and principal point free
@@ -131,7 +131,7 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
     print("reprojection rms (px): noisy %.2f exact %.2f refined %.2f" % (e_noisy, e_exact, e_refined))
     assert e_noisy > 4 * e_exact and e_refined < 1.2 * e_exact + 0.2
     # the reference's default mask "_____" refines the rotations only: intrinsics stay, the error still collapses
-    job2 = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig(ba_cost_func="reproj"))
+    job2 = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))
     job2.run(frames)
     for a, b in zip(job2.cams, noisy):
         assert np.array_equal(a["K"], b["K"])
@@ -140,4 +140,4 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
     assert pw > 2 * w * 0.8 and out["mask"].float().mean() > 100            # a panorama of sensible extent came out
     # the multi-rank path refuses the refinement (matches are sharded)
     with pytest.raises(NotImplementedError):
-        StitchJob(ctx, (w, h), noisy + noisy[:1], rank=0, world_size=2, config=isa.StitchConfig(ba_cost_func="reproj"))
+        StitchJob(ctx, (w, h), noisy + noisy[:1], rank=0, world_size=2, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))

@@ -9,7 +9,7 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "config3"
 cams = synth.workload(wl)
 frames = {i: synth.render_frame_gpu(c) for i, c in enumerate(cams)}
 size = (cams[0]["width"], cams[0]["height"]) if "width" in cams[0] else ((7680, 4320) if wl == "config5" else (3840, 2160))
-job = StitchJob(ctx, size, cams, config=isa.StitchConfig(features_type="sift" if wl == "config5" else "orb"))
+job = StitchJob(ctx, size, cams, config=isa.StitchConfig.hot_path(features_type="sift" if wl == "config5" else "orb"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 ts = []
 for k in range(n):
