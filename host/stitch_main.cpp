@@ -16,7 +16,7 @@
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::cout << "usage: " << argv[0] << " <image directory> [--features orb|sift] [--ba no|reproj] [--ba_refine_mask xxxxx] [--wave_correct horiz|vert|no]\n"
-                     "       [--expos_comp no|gain_blocks] [--seam no|voronoi] [--blend no|feather|multiband] [--conf_thresh f] [--match_conf f]\n"
+                     "       [--expos_comp no|gain_blocks] [--seam no|voronoi|dp_color] [--blend no|feather|multiband] [--conf_thresh f] [--match_conf f]\n"
                      "(the reference sets these as globals, image_stitching.cpp:49-85)\n";
         return -1;
     }

@@ -82,8 +82,8 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
         throw std::runtime_error("bundle adjustment cost function '" + cfg_.ba_cost_func + "' is not implemented (only 'no' and 'reproj')");
     if (cfg_.expos_comp_type != "no" && cfg_.expos_comp_type != "gain_blocks")
         throw std::runtime_error("exposure compensation '" + cfg_.expos_comp_type + "' is not implemented (only 'no' and 'gain_blocks')");
-    if (cfg_.seam_find_type != "no" && cfg_.seam_find_type != "voronoi")
-        throw std::runtime_error("seam finder '" + cfg_.seam_find_type + "' is not implemented (only 'no' and 'voronoi'; DpSeamFinder is outside this library)");
+    if (cfg_.seam_find_type != "no" && cfg_.seam_find_type != "voronoi" && cfg_.seam_find_type != "dp_color")
+        throw std::runtime_error("seam finder '" + cfg_.seam_find_type + "' is not implemented ('no', 'voronoi' and 'dp_color' are)");
     MisOrb* orb = nullptr;
     MisSift* sift = nullptr;
     std::vector<MisFeatures> features(n);
@@ -221,6 +221,8 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
             check(mis_compensator_feed(compensator, seam_corners.data(), images_warped.data(), masks_warped.data(), kept), "mis_compensator_feed");
         }
         if (cfg_.seam_find_type == "voronoi") check(mis_seam_voronoi(ctx_, seam_corners.data(), masks_warped.data(), kept), "mis_seam_voronoi");
+        else if (cfg_.seam_find_type == "dp_color")      // the reference's default (image_stitching.cpp:77, :1056-1065)
+            check(mis_seam_dp(ctx_, seam_corners.data(), images_warped.data(), masks_warped.data(), kept, MIS_SEAM_DP_COLOR), "mis_seam_dp");
         for (auto& im : images_warped) mis_image_free(ctx_, &im);
     }
     for (int k = 0; k < kept; k++) {

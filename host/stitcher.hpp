@@ -28,7 +28,7 @@ struct StitchConfig {
     // seam-scale step (:940-1070, :1162-1171).  The reference's defaults are "gain_blocks" and "dp_color"; DpSeamFinder is
     // not implemented in the library, so both default to "no" here.
     std::string expos_comp_type = "no";    // "no" | "gain_blocks" (64 x 64 blocks, 1 feed, 2 filtering passes)
-    std::string seam_find_type = "no";     // "no" | "voronoi"
+    std::string seam_find_type = "no";     // "no" | "voronoi" | "dp_color" (the reference's default; this driver's default is the hot path)
 };
 
 // cv::detail::CameraParams as main() fills it (focal, aspect, ppx, ppy, R, t)

@@ -2,8 +2,10 @@
 //   (*adjuster)(features, pairwise_matches, cameras) with BundleAdjusterReproj   image_stitching/image_stitching.cpp:681-712
 //   waveCorrect(rmats, WAVE_CORRECT_HORIZ)                                       image_stitching/image_stitching.cpp:718-726
 // The reference runs both on the CPU inside OpenCV (stitching/src/motion_estimators.cpp, calib3d CvLevMarq, core
-// JacobiSVD / Jacobi eigen, calib3d Rodrigues); restated here from the published algorithms, f64 throughout, plain
-// sequential arithmetic.  PARITY UNPINNED (OpenCV absent offline): the checks are behavioural (tests/test_motion_gpu.py).
+// JacobiSVD / Jacobi eigen, calib3d Rodrigues); restated here from the published algorithms with the reference's precisions: the
+// cameras' rotations are CV_32F (image_stitching.cpp:626-634), the solver state is CV_64F, the refined rotations leave as CV_32F
+// and wave correction runs in CV_32F.  PARITY UNPINNED (OpenCV absent offline); bit-exact against the oracle's independent
+// restatement (oracle/mo_motion.c, tests/test_motion_gpu.py).
 // No kernels: the data is a few thousand inlier correspondences and 7 parameters per camera.
 #include "common.h"
 #include <algorithm>
@@ -27,34 +29,47 @@ struct Mat {
     double operator()(int i, int j) const { return v[(size_t)i * c + j]; }
 };
 
-void mul3(const double* a, const double* b, double* o) {   // o = a * b (3x3)
-    double t[9];
+// 3x3 product: the written-out sums of OpenCV's small-matrix path, in the matrix type
+template <typename T>
+void mul3(const T* a, const T* b, T* o) {   // o = a * b (3x3)
+    T t[9];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) t[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
     memcpy(o, t, sizeof(t));
 }
-void transpose3(const double* a, double* o) { double t[9] = {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; memcpy(o, t, sizeof(t)); }
-double det3(const double* a) { return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]); }
-bool inv3(const double* a, double* o) {
+// determinant / inverse: cofactors in double for either matrix type, the result stored in the matrix type (cv::determinant / cv::invert, 3x3)
+template <typename T>
+double det3(const T* a) {
+    return a[0] * ((double)a[4] * a[8] - (double)a[5] * a[7]) - a[1] * ((double)a[3] * a[8] - (double)a[5] * a[6]) + a[2] * ((double)a[3] * a[7] - (double)a[4] * a[6]);
+}
+template <typename T>
+bool inv3(const T* a, T* o) {
     double d = det3(a);
     if (d == 0) return false;
     d = 1. / d;
-    double t[9] = {(a[4] * a[8] - a[5] * a[7]) * d, (a[2] * a[7] - a[1] * a[8]) * d, (a[1] * a[5] - a[2] * a[4]) * d,
-                   (a[5] * a[6] - a[3] * a[8]) * d, (a[0] * a[8] - a[2] * a[6]) * d, (a[2] * a[3] - a[0] * a[5]) * d,
-                   (a[3] * a[7] - a[4] * a[6]) * d, (a[1] * a[6] - a[0] * a[7]) * d, (a[0] * a[4] - a[1] * a[3]) * d};
-    memcpy(o, t, sizeof(t));
+    const double t[9] = {((double)a[4] * a[8] - (double)a[5] * a[7]) * d, ((double)a[2] * a[7] - (double)a[1] * a[8]) * d, ((double)a[1] * a[5] - (double)a[2] * a[4]) * d,
+                         ((double)a[5] * a[6] - (double)a[3] * a[8]) * d, ((double)a[0] * a[8] - (double)a[2] * a[6]) * d, ((double)a[2] * a[3] - (double)a[0] * a[5]) * d,
+                         ((double)a[3] * a[7] - (double)a[4] * a[6]) * d, ((double)a[1] * a[6] - (double)a[0] * a[7]) * d, ((double)a[0] * a[4] - (double)a[1] * a[3]) * d};
+    for (int i = 0; i < 9; i++) o[i] = (T)t[i];
     return true;
 }
 
-// core/src/lapack.cpp JacobiSVDImpl_<double>: one-sided Jacobi on the rows of At (n rows of length m); W = singular
-// values (descending), rows of At become the left vectors scaled to unit length, Vt the right vectors.
-void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int m, int n) {
-    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+template <typename T> struct SvdTraits;
+template <> struct SvdTraits<double> { static double eps() { return DBL_EPSILON * 10; } static double minval() { return DBL_MIN; } };
+template <> struct SvdTraits<float> { static float eps() { return FLT_EPSILON * 2; } static double minval() { return FLT_MIN; } };
+
+// core/src/lapack.cpp JacobiSVDImpl_<T>: one-sided Jacobi on the rows of At (n rows of length m); W = singular
+// values (descending), rows of At become the left vectors scaled to unit length, Vt the right vectors.  The squared norms and
+// the rotation angle are computed in double for either T, the rotations themselves in T.
+template <typename T>
+void jacobi_svd(T* At, int astep, T* Wout, T* Vt, int vstep, int m, int n) {
+    const T eps = SvdTraits<T>::eps();
+    const double minval = SvdTraits<T>::minval();
     std::vector<double> W(n);
     const int max_iter = std::max(m, 30);
     for (int i = 0; i < n; i++) {
         double sd = 0;
-        for (int k = 0; k < m; k++) { double t = At[i * astep + k]; sd += t * t; }
+        for (int k = 0; k < m; k++) { const T t = At[i * astep + k]; sd += (double)t * t; }
         W[i] = sd;
         for (int k = 0; k < n; k++) Vt[i * vstep + k] = 0;
         Vt[i * vstep + i] = 1;
@@ -63,31 +78,32 @@ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int 
         bool changed = false;
         for (int i = 0; i < n - 1; i++)
             for (int j = i + 1; j < n; j++) {
-                double *Ai = At + i * astep, *Aj = At + j * astep;
+                T *Ai = At + i * astep, *Aj = At + j * astep;
                 double a = W[i], p = 0, b = W[j];
-                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
-                if (std::abs(p) <= eps * std::sqrt(a * b)) continue;
+                for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta), c, s;
+                const double beta = a - b, gamma = hypot((double)p, beta);
+                T c, s;
                 if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = std::sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (T)std::sqrt(delta / gamma);
+                    c = (T)(p / (gamma * s * 2));
                 } else {
-                    c = std::sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
+                    c = (T)std::sqrt((gamma + beta) / (gamma * 2));
+                    s = (T)(p / (gamma * c * 2));
                 }
                 a = b = 0;
                 for (int k = 0; k < m; k++) {
-                    double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+                    const T t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
                     Ai[k] = t0; Aj[k] = t1;
-                    a += t0 * t0; b += t1 * t1;
+                    a += (double)t0 * t0; b += (double)t1 * t1;
                 }
                 W[i] = a; W[j] = b;
                 changed = true;
-                double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
+                T *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
                 for (int k = 0; k < n; k++) {
-                    double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k];
+                    const T t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k];
                     Vi[k] = t0; Vj[k] = t1;
                 }
             }
@@ -95,7 +111,7 @@ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int 
     }
     for (int i = 0; i < n; i++) {
         double sd = 0;
-        for (int k = 0; k < m; k++) { double t = At[i * astep + k]; sd += t * t; }
+        for (int k = 0; k < m; k++) { const T t = At[i * astep + k]; sd += (double)t * t; }
         W[i] = std::sqrt(sd);
     }
     for (int i = 0; i < n - 1; i++) {
@@ -108,8 +124,8 @@ void jacobi_svd(double* At, int astep, double* Wout, double* Vt, int vstep, int 
         }
     }
     for (int i = 0; i < n; i++) {
-        Wout[i] = W[i];
-        const double s = W[i] > minval ? 1 / W[i] : 0.;   // (degenerate directions: zeroed; the random completion of
+        Wout[i] = (T)W[i];
+        const T s = (T)(W[i] > minval ? 1 / W[i] : 0.);   // (degenerate directions: zeroed; the random completion of
         for (int k = 0; k < m; k++) At[i * astep + k] *= s;   //  OpenCV only matters for full bases, not for solve)
     }
 }
@@ -138,8 +154,9 @@ bool solve_svd(const Mat& A, const std::vector<double>& b, std::vector<double>& 
 }
 
 // 3x3 SVD through the same routine: R = U diag(w) Vt  (u, vt as 3x3 row-major)
-void svd3(const double* R, double* u, double* w, double* vt) {
-    double At[9], Vt[9];
+template <typename T>
+void svd3(const T* R, T* u, T* w, T* vt) {
+    T At[9], Vt[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i * 3 + j] = R[j * 3 + i];
     jacobi_svd(At, 3, w, Vt, 3, 3, 3);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { u[j * 3 + i] = At[i * 3 + j]; vt[i * 3 + j] = Vt[i * 3 + j]; }
@@ -156,13 +173,16 @@ void rodrigues_to_mat(const double* r, double* R) {
     const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * rx[k];
 }
-// matrix -> rotation vector (R is first projected on SO(3) by the caller)
-void rodrigues_to_vec(const double* R, double* r) {
+// matrix -> rotation vector (cvRodrigues2 projects the matrix on SO(3) through its SVD first)
+void rodrigues_to_vec(const double* Rin, double* r) {
+    double U[9], W[3], Vt[9], R[9];
+    svd3(Rin, U, W, Vt);
+    mul3(U, Vt, R);
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
     const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1. ? 1. : (c < -1. ? -1. : c);
-    const double theta = std::acos(c);
+    double theta = std::acos(c);
     if (s < 1e-5) {
         if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
         double t;
@@ -170,11 +190,12 @@ void rodrigues_to_vec(const double* R, double* r) {
         t = (R[4] + 1) * 0.5; ry = std::sqrt(std::max(t, 0.)) * (R[1] < 0 ? -1. : 1.);
         t = (R[8] + 1) * 0.5; rz = std::sqrt(std::max(t, 0.)) * (R[2] < 0 ? -1. : 1.);
         if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
-        const double k = theta / std::sqrt(rx * rx + ry * ry + rz * rz);
-        r[0] = rx * k; r[1] = ry * k; r[2] = rz * k;
+        theta /= std::sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
         return;
     }
-    const double vth = 1 / (2 * s) * theta;
+    double vth = 1 / (2 * s);
+    vth *= theta;
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
@@ -196,7 +217,18 @@ struct LevMarq {
         solve_svd(A, JtErr, d);
         for (int i = 0; i < nparams; i++) param[i] = prevParam[i] - d[i];
     }
-    static double norm2(const std::vector<double>& a) { double s = 0; for (double v : a) s += v * v; return std::sqrt(s); }
+    // normL2Sqr<double, double>: groups of four, as the unrolled loop of core's stat code adds them
+    static double l2sqr(const double* a, const double* b, int n) {
+        double s = 0;
+        int i = 0;
+        for (; i <= n - 4; i += 4) {
+            const double v0 = a[i] - (b ? b[i] : 0.), v1 = a[i + 1] - (b ? b[i + 1] : 0.), v2 = a[i + 2] - (b ? b[i + 2] : 0.), v3 = a[i + 3] - (b ? b[i + 3] : 0.);
+            s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+        }
+        for (; i < n; i++) { const double v = a[i] - (b ? b[i] : 0.); s += v * v; }
+        return s;
+    }
+    static double norm2(const std::vector<double>& a) { return std::sqrt(l2sqr(a.data(), nullptr, (int)a.size())); }
     // returns proceed; want_J / want_err tell the caller what to compute for `param`
     bool update(bool& want_J, bool& want_err) {
         want_J = want_err = false;
@@ -231,12 +263,8 @@ struct LevMarq {
             }
         }
         lambdaLg10 = std::max(lambdaLg10 - 1, -16);
-        double change = 0;
-        {
-            double num = 0, den = 0;
-            for (int i = 0; i < nparams; i++) { num += (param[i] - prevParam[i]) * (param[i] - prevParam[i]); den += prevParam[i] * prevParam[i]; }
-            change = std::sqrt(num) / (std::sqrt(den) + DBL_EPSILON);   // cvNorm(param, prevParam, CV_RELATIVE_L2)
-        }
+        // cvNorm(param, prevParam, CV_RELATIVE_L2)
+        const double change = std::sqrt(l2sqr(param.data(), prevParam.data(), nparams)) / (std::sqrt(l2sqr(prevParam.data(), nullptr, nparams)) + DBL_EPSILON);
         if (++iters >= max_iter || change < epsilon) { state = DONE; return true; }
         prevErrNorm = errNorm;
         std::fill(J.v.begin(), J.v.end(), 0.);
@@ -336,32 +364,59 @@ void max_spanning_tree_centers(int n, const MisMatchesInfo* pm, std::vector<int>
     for (int i = 0; i < n; i++) if (max_dists[i] == mn) centers.push_back(i);
 }
 
-// symmetric 3x3 eigen decomposition (cv::eigen = Jacobi): eigenvalues descending, eigenvectors as rows
-void eigen3(const double* Ain, double* evals, double* evecs) {
-    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    memcpy(A, Ain, sizeof(A));
-    for (int sweep = 0; sweep < 60; sweep++) {
-        int p = 0, q = 1;
-        double mx = std::fabs(A[1]);
-        if (std::fabs(A[2]) > mx) { mx = std::fabs(A[2]); p = 0; q = 2; }
-        if (std::fabs(A[5]) > mx) { mx = std::fabs(A[5]); p = 1; q = 2; }
-        if (mx <= DBL_EPSILON) break;
-        const double app = A[p * 3 + p], aqq = A[q * 3 + q], apq = A[p * 3 + q];
-        const double y = (aqq - app) * 0.5;
-        double t = std::fabs(y) + hypot(apq, y), s = hypot(apq, t), c = t / s;
-        s = apq / s; t = (apq / t) * apq;
-        if (y < 0) { s = -s; t = -t; }
-        A[p * 3 + q] = A[q * 3 + p] = 0;
-        A[p * 3 + p] -= t; A[q * 3 + q] += t;
-        const int r = 3 - p - q;
-        const double arp = A[r * 3 + p], arq = A[r * 3 + q];
-        A[r * 3 + p] = A[p * 3 + r] = arp * c - arq * s;
-        A[r * 3 + q] = A[q * 3 + r] = arp * s + arq * c;
-        for (int k = 0; k < 3; k++) { const double vp = V[p * 3 + k], vq = V[q * 3 + k]; V[p * 3 + k] = vp * c - vq * s; V[q * 3 + k] = vp * s + vq * c; }
+inline float hypot_cv(float a, float b) {   // cv::hypot(float, float)
+    a = std::fabs(a); b = std::fabs(b);
+    if (a > b) { b /= a; return a * std::sqrt(1 + b * b); }
+    if (b > 0) { a /= b; return b * std::sqrt(1 + a * a); }
+    return 0;
+}
+
+// cv::eigen of a symmetric n x n CV_32F matrix (core/src/lapack.cpp JacobiImpl_<float>): cyclic pivoting on the largest
+// off-diagonal element of the upper triangle (row / column maxima kept in indR / indC), eigenvalues descending, eigenvectors as rows
+void jacobi_eigen_f32(float* A, int n, float* W, float* V) {
+    const float eps = FLT_EPSILON;
+    std::vector<int> indR(n), indC(n);
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) V[i * n + j] = 0; V[i * n + i] = 1; }
+    auto row_max = [&](int k) { int m = k + 1; float mv = std::fabs(A[n * k + m]); for (int i = k + 2; i < n; i++) { const float val = std::fabs(A[n * k + i]); if (mv < val) mv = val, m = i; } return m; };
+    auto col_max = [&](int k) { int m = 0; float mv = std::fabs(A[k]); for (int i = 1; i < k; i++) { const float val = std::fabs(A[n * i + k]); if (mv < val) mv = val, m = i; } return m; };
+    for (int k = 0; k < n; k++) {
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) indR[k] = row_max(k);
+        if (k > 0) indC[k] = col_max(k);
     }
-    int idx[3] = {0, 1, 2};
-    std::sort(idx, idx + 3, [&](int a, int b) { return A[a * 3 + a] > A[b * 3 + b]; });
-    for (int i = 0; i < 3; i++) { evals[i] = A[idx[i] * 3 + idx[i]]; for (int k = 0; k < 3; k++) evecs[i * 3 + k] = V[idx[i] * 3 + k]; }
+    if (n > 1)
+        for (int iters = 0; iters < n * n * 30; iters++) {
+            int k = 0;
+            float mv = std::fabs(A[indR[0]]);
+            for (int i = 1; i < n - 1; i++) { const float val = std::fabs(A[n * i + indR[i]]); if (mv < val) mv = val, k = i; }
+            int l = indR[k];
+            for (int i = 1; i < n; i++) { const float val = std::fabs(A[n * indC[i] + i]); if (mv < val) mv = val, k = indC[i], l = i; }
+            const float p = A[n * k + l];
+            if (std::fabs(p) <= eps) break;
+            const float y = (float)((W[l] - W[k]) * 0.5);
+            float t = std::fabs(y) + hypot_cv(p, y);
+            float sn = hypot_cv(p, t);
+            const float c = t / sn;
+            sn = p / sn; t = (p / t) * p;
+            if (y < 0) sn = -sn, t = -t;
+            A[n * k + l] = 0;
+            W[k] -= t; W[l] += t;
+            auto rot = [&](float& v0, float& v1) { const float a0 = v0, b0 = v1; v0 = a0 * c - b0 * sn; v1 = a0 * sn + b0 * c; };
+            for (int i = 0; i < k; i++) rot(A[n * i + k], A[n * i + l]);
+            for (int i = k + 1; i < l; i++) rot(A[n * k + i], A[n * i + l]);
+            for (int i = l + 1; i < n; i++) rot(A[n * k + i], A[n * l + i]);
+            for (int i = 0; i < n; i++) rot(V[n * k + i], V[n * l + i]);
+            for (int j = 0; j < 2; j++) {
+                const int idx = j == 0 ? k : l;
+                if (idx < n - 1) indR[idx] = row_max(idx);
+                if (idx > 0) indC[idx] = col_max(idx);
+            }
+        }
+    for (int k = 0; k < n - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
+        if (k != m) { std::swap(W[m], W[k]); for (int i = 0; i < n; i++) std::swap(V[n * m + i], V[n * k + i]); }
+    }
 }
 
 }  // namespace
@@ -386,11 +441,17 @@ extern "C" int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* feat
     ad.cam.assign((size_t)n * 7, 0.);
     for (int i = 0; i < n; i++) {
         ad.cam[i * 7] = cameras[i].focal; ad.cam[i * 7 + 1] = cameras[i].ppx; ad.cam[i * 7 + 2] = cameras[i].ppy; ad.cam[i * 7 + 3] = cameras[i].aspect;
-        double u[9], w[3], vt[9], R[9];
-        svd3(cameras[i].R, u, w, vt);
+        // the reference's cameras carry CV_32F rotations (image_stitching.cpp:626-634): SVD, u * vt and the sign fix in float,
+        // Rodrigues in double on the float matrix, the rotation vector stored as CV_32F
+        float Rf[9], u[9], w[3], vt[9], R[9];
+        for (int k = 0; k < 9; k++) Rf[k] = (float)cameras[i].R[k];
+        svd3(Rf, u, w, vt);
         mul3(u, vt, R);
-        if (det3(R) < 0) for (double& v : R) v = -v;
-        rodrigues_to_vec(R, &ad.cam[i * 7 + 4]);
+        if (det3(R) < 0) for (float& v : R) v *= -1;
+        double Rd[9], rv[3];
+        for (int k = 0; k < 9; k++) Rd[k] = R[k];
+        rodrigues_to_vec(Rd, rv);
+        for (int k = 0; k < 3; k++) ad.cam[i * 7 + 4 + k] = (double)(float)rv[k];
     }
     // leave only consistent image pairs
     for (int i = 0; i < n - 1; i++)
@@ -416,7 +477,7 @@ extern "C" int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* feat
     for (;;) {
         bool want_J, want_err;
         const bool proceed = solver.update(want_J, want_err);
-        if (trace) fprintf(stderr, "[ba] state %d iters %d lambdaLg10 %d prevErr %.6g err %.6g\n", solver.state, solver.iters, solver.lambdaLg10, solver.prevErrNorm, solver.errNorm);
+        if (trace) fprintf(stderr, "[ba] state %d iters %d lambdaLg10 %d prevErr %.17g err %.17g p0 %.17g p4 %.17g\n", solver.state, solver.iters, solver.lambdaLg10, solver.prevErrNorm, solver.errNorm, solver.param[0], solver.param[4]);
         ad.cam = solver.param;
         if (!proceed || !want_err) break;
         if (want_J) ad.calc_jacobian(solver.J);
@@ -426,50 +487,61 @@ extern "C" int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* feat
     // obtainRefinedCameraParams
     for (int i = 0; i < n; i++) {
         cameras[i].focal = ad.cam[i * 7]; cameras[i].ppx = ad.cam[i * 7 + 1]; cameras[i].ppy = ad.cam[i * 7 + 2]; cameras[i].aspect = ad.cam[i * 7 + 3];
-        rodrigues_to_mat(&ad.cam[i * 7 + 4], cameras[i].R);
+        double R[9];
+        rodrigues_to_mat(&ad.cam[i * 7 + 4], R);
+        for (int k = 0; k < 9; k++) cameras[i].R[k] = (double)(float)R[k];      // R.convertTo(tmp, CV_32F)
     }
-    // normalise the motion to the centre image of the maximum spanning tree
+    // normalise the motion to the centre image of the maximum spanning tree: R_i = R_c^-1 * R_i on the CV_32F matrices
     std::vector<int> centers;
     max_spanning_tree_centers(n, pairwise, centers);
     if (!centers.empty()) {
-        double Rinv[9];
-        if (inv3(cameras[centers[0]].R, Rinv))
-            for (int i = 0; i < n; i++) mul3(Rinv, cameras[i].R, cameras[i].R);
+        float Rc[9], Rinv[9];
+        for (int k = 0; k < 9; k++) Rc[k] = (float)cameras[centers[0]].R[k];
+        if (inv3(Rc, Rinv))
+            for (int i = 0; i < n; i++) {
+                float Ri[9], Ro[9];
+                for (int k = 0; k < 9; k++) Ri[k] = (float)cameras[i].R[k];
+                mul3(Rinv, Ri, Ro);
+                for (int k = 0; k < 9; k++) cameras[i].R[k] = Ro[k];
+            }
     }
     return MIS_OK;
 }
 
-// detail::waveCorrect (motion_estimators.cpp): kind 0 = WAVE_CORRECT_HORIZ, 1 = WAVE_CORRECT_VERT; rmats: n x 9 doubles
+// detail::waveCorrect (motion_estimators.cpp): kind 0 = WAVE_CORRECT_HORIZ, 1 = WAVE_CORRECT_VERT; rmats: n x 9 doubles holding the
+// CV_32F rotations the reference passes (image_stitching.cpp:720-722); everything in float as there, results returned in place
 extern "C" int mis_wave_correct(double* rmats, int n, int kind) {
     if (!rmats || n < 1 || (kind != 0 && kind != 1)) return MIS_E_INVALID;
     if (n <= 1) return MIS_OK;
-    double moment[9] = {0};
+    std::vector<float> R((size_t)n * 9);
+    for (int i = 0; i < 9 * n; i++) R[i] = (float)rmats[i];
+    float moment[9] = {0};
     for (int i = 0; i < n; i++) {
-        const double* R = rmats + 9 * i;
-        const double col[3] = {R[0], R[3], R[6]};   // first column: the camera's x axis
+        const float col[3] = {R[9 * i], R[9 * i + 3], R[9 * i + 6]};   // col(0): the camera's x axis
         for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) moment[a * 3 + b] += col[a] * col[b];
     }
-    double evals[3], evecs[9];
-    eigen3(moment, evals, evecs);
-    double rg1[3];
-    if (kind == 0) memcpy(rg1, evecs + 6, sizeof(rg1));   // HORIZ: the eigenvector of the smallest eigenvalue
-    else memcpy(rg1, evecs, sizeof(rg1));                 // VERT: of the largest
-    double img_k[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++) { img_k[0] += rmats[9 * i + 2]; img_k[1] += rmats[9 * i + 5]; img_k[2] += rmats[9 * i + 8]; }   // sum of the z axes
-    double rg0[3] = {rg1[1] * img_k[2] - rg1[2] * img_k[1], rg1[2] * img_k[0] - rg1[0] * img_k[2], rg1[0] * img_k[1] - rg1[1] * img_k[0]};
-    const double rg0n = std::sqrt(rg0[0] * rg0[0] + rg0[1] * rg0[1] + rg0[2] * rg0[2]);
+    float evals[3], evecs[9];
+    jacobi_eigen_f32(moment, 3, evals, evecs);
+    float rg1[3], img_k[3] = {0, 0, 0};
+    memcpy(rg1, kind == 0 ? evecs + 6 : evecs, sizeof(rg1));   // HORIZ: the eigenvector of the smallest eigenvalue; VERT: of the largest
+    for (int i = 0; i < n; i++) { img_k[0] += R[9 * i + 2]; img_k[1] += R[9 * i + 5]; img_k[2] += R[9 * i + 8]; }   // sum of the z axes
+    float rg0[3] = {rg1[1] * img_k[2] - rg1[2] * img_k[1], rg1[2] * img_k[0] - rg1[0] * img_k[2], rg1[0] * img_k[1] - rg1[1] * img_k[0]};
+    const double rg0n = std::sqrt((double)rg0[0] * rg0[0] + (double)rg0[1] * rg0[1] + (double)rg0[2] * rg0[2]);
     if (rg0n <= DBL_MIN) return MIS_OK;
-    for (double& v : rg0) v /= rg0n;
-    double rg2[3] = {rg0[1] * rg1[2] - rg0[2] * rg1[1], rg0[2] * rg1[0] - rg0[0] * rg1[2], rg0[0] * rg1[1] - rg0[1] * rg1[0]};
+    for (float& v : rg0) v = (float)(v * (1. / rg0n));    // rg0 /= norm: scaled by the reciprocal, in double
+    const float rg2[3] = {rg0[1] * rg1[2] - rg0[2] * rg1[1], rg0[2] * rg1[0] - rg0[0] * rg1[2], rg0[0] * rg1[1] - rg0[1] * rg1[0]};
     double conf = 0;
-    if (kind == 0) {
-        for (int i = 0; i < n; i++) conf += rg0[0] * rmats[9 * i] + rg0[1] * rmats[9 * i + 3] + rg0[2] * rmats[9 * i + 6];
-        if (conf < 0) { for (double& v : rg0) v = -v; for (double& v : rg1) v = -v; }
-    } else {
-        for (int i = 0; i < n; i++) conf -= rg1[0] * rmats[9 * i] + rg1[1] * rmats[9 * i + 3] + rg1[2] * rmats[9 * i + 6];
-        if (conf < 0) { for (double& v : rg0) v = -v; for (double& v : rg1) v = -v; }
+    for (int i = 0; i < n; i++) {
+        const float* g = kind == 0 ? rg0 : rg1;     // Mat::dot on CV_32F: products and sum in double
+        const double d = (double)g[0] * R[9 * i] + (double)g[1] * R[9 * i + 3] + (double)g[2] * R[9 * i + 6];
+        conf += kind == 0 ? d : -d;
     }
-    const double Rg[9] = {rg0[0], rg0[1], rg0[2], rg1[0], rg1[1], rg1[2], rg2[0], rg2[1], rg2[2]};
-    for (int i = 0; i < n; i++) mul3(Rg, rmats + 9 * i, rmats + 9 * i);
+    if (conf < 0) { for (float& v : rg0) v *= -1; for (float& v : rg1) v *= -1; }
+    const float Rg[9] = {rg0[0], rg0[1], rg0[2], rg1[0], rg1[1], rg1[2], rg2[0], rg2[1], rg2[2]};
+    for (int i = 0; i < n; i++) {
+        float o[9];
+        mul3(Rg, &R[9 * i], o);
+        for (int k = 0; k < 9; k++) rmats[9 * i + k] = o[k];
+    }
     return MIS_OK;
 }

@@ -786,3 +786,61 @@ def dp_seams(images, corners, masks):
     L.mo_seam_dp_color.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mo_seam_dp_color(n, _p(c), _p(s), ip, mp)
     return msks
+
+
+class Camera(C.Structure):
+    _fields_ = [("focal", C.c_double), ("aspect", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double), ("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+def bundle_adjust_reproj(feats, matches, cameras, conf_thresh=0.95, refine_mask="xxxxx"):
+    """BundleAdjusterReproj (image_stitching.cpp:681-712).  feats: dicts as for match_all_pairs (xy is what matters); matches: the
+    n*n list of dicts match_all_pairs returns (or objects with the same fields as attributes); cameras: dicts focal, ppx, ppy,
+    aspect, R -> (new list of dicts, LM iterations)."""
+    n = len(feats)
+    fa = (Features * n)()
+    keep = []
+    for i, f in enumerate(feats):
+        F, k = _mk_features(f)
+        fa[i] = F
+        keep.append(k)
+    mis = (MatchesInfo * (n * n))()
+
+    def g(m, name):
+        return m[name] if isinstance(m, dict) else getattr(m, name)
+    for k, m in enumerate(matches):
+        mm = np.ascontiguousarray(g(m, "matches"), DMATCH_DTYPE)
+        mk = np.ascontiguousarray(g(m, "inliers_mask"), np.uint8)
+        keep += [mm, mk]
+        mis[k].src_img_idx, mis[k].dst_img_idx, mis[k].n_matches = int(g(m, "src_img_idx")), int(g(m, "dst_img_idx")), len(mm)
+        mis[k].matches = C.cast(mm.ctypes.data, C.POINTER(DMatch)) if len(mm) else None
+        mis[k].inliers_mask = C.cast(mk.ctypes.data, C.POINTER(C.c_uint8)) if len(mk) else None
+        mis[k].num_inliers = int(g(m, "num_inliers"))
+        H = g(m, "H")
+        has = (g(m, "has_H") if isinstance(m, dict) else H is not None)
+        mis[k].has_H = 1 if has else 0
+        if has:
+            for q, v in enumerate(np.asarray(H, np.float64).reshape(9)):
+                mis[k].H[q] = v
+        mis[k].confidence = float(g(m, "confidence"))
+    cams = (Camera * n)()
+    for k, c in enumerate(cameras):
+        cams[k].focal, cams[k].aspect, cams[k].ppx, cams[k].ppy = float(c["focal"]), float(c.get("aspect", 1.0)), float(c["ppx"]), float(c["ppy"])
+        for q, v in enumerate(np.asarray(c["R"], np.float64).reshape(9)):
+            cams[k].R[q] = v
+    it = C.c_int(0)
+    L = lib()
+    L.mo_bundle_adjust_reproj.argtypes = [C.c_int, C.POINTER(Features), C.POINTER(MatchesInfo), C.c_float, C.c_char_p, C.POINTER(Camera), C.POINTER(C.c_int)]
+    rc = L.mo_bundle_adjust_reproj(n, fa, mis, float(conf_thresh), refine_mask.encode(), cams, C.byref(it))
+    if rc:
+        raise RuntimeError("mo_bundle_adjust_reproj: %d" % rc)
+    return [dict(focal=cams[k].focal, aspect=cams[k].aspect, ppx=cams[k].ppx, ppy=cams[k].ppy, R=np.array(list(cams[k].R)).reshape(3, 3)) for k in range(n)], it.value
+
+
+def wave_correct(rmats, kind=0):
+    """detail::waveCorrect (image_stitching.cpp:718-726): kind 0 = HORIZ, 1 = VERT -> list of 3x3 rotations."""
+    a = np.ascontiguousarray(np.stack([np.asarray(r, np.float64).reshape(3, 3) for r in rmats]))
+    L = lib()
+    L.mo_wave_correct.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    if L.mo_wave_correct(a.ctypes.data, len(rmats), int(kind)):
+        raise RuntimeError("mo_wave_correct failed")
+    return [a[i].copy() for i in range(len(rmats))]

@@ -115,8 +115,13 @@ def test_stitch_main_seam_step_and_sift_match_python_pipeline(tmp_path, ctx, ora
     assert counts == [len(f.detect(d)) for d in dev]
     assert "kept 3 of 3" in r.stdout
     assert np.array_equal(_read_ppm(os.path.join(str(tmp_path), "result.ppm")), np.clip(plain.cpu().numpy(), 0, 255).astype(np.uint8))
+    # the reference's default seam finder through the C++ driver = through the Python mirror
+    r = subprocess.run([exe, str(tmp_path), "--expos_comp", "gain_blocks", "--seam", "dp_color"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref_default, _ = isa.Stitcher(ctx, size, isa.StitchConfig(compose_megapix=-1)).compose(dev, cams)      # gain_blocks + dp_color
+    assert np.array_equal(np.clip(ref_default.cpu().numpy(), 0, 255).astype(np.uint8), _read_ppm(os.path.join(str(tmp_path), "result.ppm")))
     # options the library does not implement are refused, not ignored
-    r = subprocess.run([exe, str(tmp_path), "--seam", "dp_color"], capture_output=True, text=True)
+    r = subprocess.run([exe, str(tmp_path), "--seam", "gc_color"], capture_output=True, text=True)
     assert r.returncode == 1 and "not implemented" in r.stdout
 
 

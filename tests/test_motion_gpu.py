@@ -1,6 +1,7 @@
 """Camera refinement (row N1 of SURVEY section 8; image_stitching.cpp:681-726): bundle adjustment with the
-reprojection cost and wave correction.  Host logic restated from OpenCV (parity unpinned): the checks are behavioural
--- perturbed cameras come back to the ground truth, the reprojection error collapses, the horizon is levelled."""
+reprojection cost and wave correction.  Host logic restated from OpenCV (parity unpinned): bit-exact against the oracle's
+independent restatement (oracle/mo_motion.c) and behavioural checks -- perturbed cameras come back to the ground truth, the
+reprojection error collapses, the horizon is levelled."""
 import math
 
 import numpy as np
@@ -23,11 +24,30 @@ def test_wave_correct_levels_a_tilted_sweep():
     after = max(abs(R[1, 0]) for R in out)
     assert before > 0.09 and after < 0.012        # the x axes of a rolled + pitched sweep lie on a cone: a least-squares plane remains
     for R in out:
-        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        assert np.allclose(R @ R.T, np.eye(3), atol=2e-6)            # the reference corrects CV_32F rotations: float round-off
     # relative rotations are preserved (one global rotation applied to all)
     for i in range(5):
-        assert _rot_err_deg(Rs[i].T @ Rs[i + 1], out[i].T @ out[i + 1]) < 1e-4     # acos near 1: ~1e-6 degree of round-off
+        assert _rot_err_deg(Rs[i].T @ Rs[i + 1], out[i].T @ out[i + 1]) < 0.05     # float rotations: acos near 1 magnifies 1e-7 to ~0.03 degree
     assert len(isa.wave_correct(Rs[:1])) == 1
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_wave_correct_matches_oracle(oracle_mod, kind):
+    """waveCorrect HORIZ / VERT on CV_32F rotations: library (host logic, no GPU needed) == oracle, bit for bit."""
+    import synth
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(40 + kind)
+    for n in (2, 5, 16):
+        Rs = [synth.rotation_yxz(math.radians(15.0 * i - 40 + rng.normal(0, 1)), math.radians(rng.normal(0, 3)), math.radians(4.0 + rng.normal(0, 2))) for i in range(n)]
+        got = isa.wave_correct(Rs, kind)
+        want = oracle_mod.wave_correct(Rs, kind)
+        for g, w_ in zip(got, want):
+            assert np.array_equal(_bits(g), _bits(w_))
+            assert np.array_equal(g, g.astype(np.float32).astype(np.float64))       # CV_32F values
 
 
 def _reproj_rms(feats, pm, n, cl, strong):
@@ -78,6 +98,18 @@ def test_bundle_adjustment_recovers_perturbed_cameras(ctx):
                           aspect=1.0, R=d @ c["R"]))
     e_truth, e_start = reproj_rms(truth), reproj_rms(start)
     refined = isa.bundle_adjust_reproj(ctx, feats, pm, start, conf_thresh=0.95)
+    # the oracle's restatement on the same features / matches / cameras: every refined parameter bit for bit
+    import oracle
+    host = [f.download() for f in feats]
+    ofe = [dict(img_w=w, img_h=h, xy=np.stack([k["x"], k["y"]], 1), desc=d) for k, d in host]
+    for mask_s in ("xxxxx", "_____", "x_xxx"):
+        want, iters = oracle.bundle_adjust_reproj(ofe, [pm[k] for k in range(n * n)], start, 0.95, mask_s)
+        got = refined if mask_s == "xxxxx" else isa.bundle_adjust_reproj(ctx, feats, pm, start, conf_thresh=0.95, refine_mask=mask_s)
+        assert iters >= 2
+        for g, o in zip(got, want):
+            for key in ("focal", "aspect", "ppx", "ppy"):
+                assert g[key] == o[key], (mask_s, key)
+            assert np.array_equal(_bits(g["R"]), _bits(o["R"])), mask_s
     e_ref = reproj_rms(refined)
     print("reprojection rms (px): truth %.3f  perturbed %.3f  refined %.3f" % (e_truth, e_start, e_ref))
     assert e_truth < 2.0 and e_start > 5 * e_truth                                 # ORB localisation noise; the perturbation matters
@@ -88,9 +120,9 @@ def test_bundle_adjustment_recovers_perturbed_cameras(ctx):
     print("relative rotation error (deg): perturbed", np.round(err_start, 3), "refined", np.round(err_ref, 3))
     assert max(err_ref) < 0.8 and np.mean(err_ref) < 0.6 * np.mean(err_start)   # focal / principal point are free too: a few tenths remain
     # the centre image of the spanning tree carries the identity
-    assert min(_rot_err_deg(np.eye(3), c["R"]) for c in refined) < 1e-4
+    assert min(_rot_err_deg(np.eye(3), c["R"]) for c in refined) < 0.05          # R_c^-1 * R_c on CV_32F matrices
     for c in refined:
-        assert abs(c["focal"] / truth[0]["focal"] - 1) < 0.03
+        assert abs(c["focal"] / truth[0]["focal"] - 1) < 0.06     # a yaw sweep observes the focal length weakly: the solver drifts a few % along it
     # refinement mask: nothing but the rotations may move
     fixed = isa.bundle_adjust_reproj(ctx, feats, pm, start, conf_thresh=0.95, refine_mask="_____")
     for a, b in zip(fixed, start):
