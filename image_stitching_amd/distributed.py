@@ -111,6 +111,15 @@ class Comm:
                 o += int(n)
         return [r.to(dev) for r in recv]
 
+    def all_gather_objects(self, obj):
+        """Small host-side records of every rank (pickled by torch.distributed) -> list in rank order."""
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
     def gather_to_root(self, t):
         """Equal-sized 1-D tensors -> list of world tensors on rank 0 (None elsewhere)."""
         if self.world == 1:
@@ -206,6 +215,25 @@ class HipEngine:
 
     def refine_cameras(self, feats, pm, indices, cams):
         return st.refine_cameras(self.ctx, feats, pm, indices, cams, self.cfg)
+
+    def match_entries(self, pm, conf_thresh):
+        """What bundle adjustment needs of this rank's pairs (i < j): (i, j, matches, inliers_mask, num_inliers, has_H, H,
+        confidence); the match arrays only for pairs above the confidence threshold (the others are never read)."""
+        out = []
+        n = pm.n
+        for i in range(n):
+            for j in range(i + 1, n):
+                raw = pm._mis[i * n + j]
+                if raw.src_img_idx < 0:
+                    continue                       # a pair of another rank (or without keypoints)
+                m = pm[i * n + j]
+                strong = m.confidence > conf_thresh
+                out.append((i, j, m.matches if strong else m.matches[:0], m.inliers_mask if strong else m.inliers_mask[:0], m.num_inliers, m.H is not None,
+                            m.H, m.confidence))
+        return out
+
+    def matches_from_entries(self, per_rank, n):
+        return st.PairwiseMatches.from_entries(self.ctx, n, [e for entries in per_rank for e in entries])
 
     # ---- compose ----
     def warp_roi(self, scale, cam):
@@ -335,8 +363,6 @@ class StitchJob:
 
     def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
         self.cfg = config or st.StitchConfig.hot_path()
-        if self.cfg.ba_cost_func != "no" and world_size > 1:
-            raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         if self.cfg.expos_comp_type != "no" or self.cfg.seam_find_type != "no":
             # refused rather than ignored: the seam-scale step needs every warped image on one rank
             raise NotImplementedError("the sharded job composes without exposure compensation / seam finding; "
@@ -514,8 +540,6 @@ class StitchJob:
 
     def run(self, frames):
         refine = self.cfg.ba_cost_func != "no"
-        if refine and self.world > 1:
-            raise NotImplementedError("bundle adjustment needs every pair's matches on one rank: run it with world_size 1")
         spec = getattr(self.engine, "speculative_compose", False) and not refine   # refined cameras: compose must wait
         prepared = None
         side = getattr(self.engine, "compose_stream", None)
@@ -572,6 +596,10 @@ class StitchJob:
             if refine:
                 if self.cfg.ba_cost_func != "reproj":
                     raise ValueError("ba_cost_func must be 'no' or 'reproj'")
+                if self.world > 1 or self.force_collectives:
+                    # the adjuster needs every connected pair's inlier matches, and the pairs were dealt over the ranks: every
+                    # rank contributes the entries it owns, all ranks assemble the same table and run the same (host) solver
+                    pm = self.engine.matches_from_entries(self.comm.all_gather_objects(self.engine.match_entries(pm, self.cfg.conf_thresh)), self.n)
                 refined = self.engine.refine_cameras(feats, pm, indices, self.cams)
                 self.cams = list(self.cams)
                 for i, c in zip(indices, refined):

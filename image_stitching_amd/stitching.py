@@ -653,6 +653,35 @@ class PairwiseMatches:
         self._ctx, self._mis, self.n = ctx, mis, n
         self._cache = {}
 
+    @classmethod
+    def from_entries(cls, ctx, n, entries):
+        """A table assembled on the host from (i, j, matches, inliers_mask, num_inliers, has_H, H, confidence) records of the
+        pairs i < j (a sharded job gathers them from the ranks that matched them); the mirrored entries are filled as
+        FeaturesMatcher::operator() fills them.  The arrays live in this object, not in the library."""
+        mis = (capi.MisMatchesInfo * (n * n))()
+        keep = []
+        for k in range(n * n):
+            mis[k].src_img_idx = mis[k].dst_img_idx = -1
+        for i, j, matches, mask, num_inliers, has_H, H, conf in entries:
+            mm = np.ascontiguousarray(matches, DMATCH_DTYPE)
+            mk = np.ascontiguousarray(mask, np.uint8)
+            sw = mm.copy()
+            sw["query_idx"], sw["train_idx"] = mm["train_idx"], mm["query_idx"]
+            Hd = np.asarray(H, np.float64).reshape(3, 3) if has_H else None
+            for (a, b, arr, Hm) in ((i, j, mm, Hd), (j, i, sw, np.linalg.inv(Hd) if has_H else None)):
+                e = mis[a * n + b]
+                e.src_img_idx, e.dst_img_idx, e.n_matches = a, b, len(arr)
+                e.matches = C.cast(arr.ctypes.data, C.POINTER(capi.MisDMatch)) if len(arr) else None
+                e.inliers_mask = C.cast(mk.ctypes.data, C.POINTER(C.c_uint8)) if len(mk) else None
+                e.num_inliers, e.has_H, e.confidence = int(num_inliers), 1 if has_H else 0, float(conf)
+                if has_H:
+                    for q, v in enumerate(Hm.reshape(9)):
+                        e.H[q] = v
+            keep += [mm, mk, sw]
+        obj = cls(ctx, mis, n)
+        obj._keep, obj._borrowed = keep, True
+        return obj
+
     def __len__(self):
         return self.n * self.n
 
@@ -674,7 +703,7 @@ class PairwiseMatches:
 
     def __del__(self):
         try:
-            if self._mis is not None and self._ctx.h:
+            if self._mis is not None and self._ctx.h and not getattr(self, "_borrowed", False):
                 self._ctx.lib.mis_matches_free(self._mis, self.n * self.n)
             self._mis = None
         except Exception:

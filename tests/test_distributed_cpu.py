@@ -149,5 +149,3 @@ def test_job_refuses_options_it_does_not_run():
     for cfg in (StitchConfig.hot_path(expos_comp_type="gain_blocks"), StitchConfig.hot_path(seam_find_type="voronoi")):
         with pytest.raises(NotImplementedError):
             StitchJob(None, (W, H), cams, engine=OracleEngine((W, H)), config=cfg)
-    with pytest.raises(NotImplementedError):
-        StitchJob(None, (W, H), cams, rank=0, world_size=2, engine=OracleEngine((W, H)), config=StitchConfig.hot_path(ba_cost_func="reproj"))

@@ -172,6 +172,71 @@ def test_two_ranks_on_one_gpu_match_single_rank(ctx, tmp_path):
     assert d.max() <= 1 and (d > 0).mean() < 0.02          # f32 weight sums in a different order where >= 3 frames overlap
 
 
+def _ba_scene():
+    import synth
+    w, h = 480, 270
+    rng = np.random.default_rng(9)
+    exact = [synth.make_camera(w, h, 60.0, 13.0 * i - 20.0, 2.5 * ((i % 3) - 1), 1.5 * ((i % 2) - 0.5)) for i in range(4)]
+    noisy = []
+    for c in exact:
+        d = dict(c)
+        d["R"] = synth.rotation_yxz(*np.radians(rng.normal(0, 0.5, 3))) @ c["R"]
+        noisy.append(d)
+    return w, h, exact, noisy
+
+
+def _gpu_rank_ba(rank, world, port, out_path):
+    """Two ranks with camera refinement: the matches of the pairs each rank owns are gathered, every rank solves the same problem."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth
+        import image_stitching_amd as isa
+        from image_stitching_amd.distributed import StitchJob
+        w, h, exact, noisy = _ba_scene()
+        ctx = isa.Context(0)
+        job = StitchJob(ctx, (w, h), noisy, rank=rank, world_size=world, group=dist.group.WORLD, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))
+        frames = {i: torch.from_numpy(synth.render_frame(exact[i])).cuda() for i in job.my_frames}
+        out = job.run(frames)
+        if rank == 0:
+            np.savez(out_path, pano=out["pano"].cpu().numpy(), mask=out["mask"].cpu().numpy(), R=np.stack([np.asarray(c["R"]) for c in job.cams]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_bundle_adjustment_match_single_rank(ctx, tmp_path):
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd.distributed import StitchJob
+    w, h, exact, noisy = _ba_scene()
+    frames = {i: torch.from_numpy(synth.render_frame(c)).cuda() for i, c in enumerate(exact)}
+    solo = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))
+    ref = solo.run(frames)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "rank0.npz")
+    mp.start_processes(_gpu_rank_ba, args=(2, port, out_path), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out_path)
+    assert np.array_equal(got["R"], np.stack([np.asarray(c["R"]) for c in solo.cams]))        # the same refined cameras, bit for bit
+    assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
+    d = np.abs(got["pano"].astype(np.int32) - ref["pano"].cpu().numpy().astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+
+
 def _gpu_rank6(rank, world, port, out_path):
     """One rank of a 3-process job over 6 frames on the same GPU (3 strips, halos crossing two owners)."""
     import os

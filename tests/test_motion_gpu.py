@@ -164,12 +164,15 @@ def test_job_with_camera_refinement_from_perturbed_cameras(ctx):
     assert e_noisy > 4 * e_exact and e_refined < 1.2 * e_exact + 0.2
     # the reference's default mask "_____" refines the rotations only: intrinsics stay, the error still collapses
     job2 = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))
-    job2.run(frames)
+    out2 = job2.run(frames)
     for a, b in zip(job2.cams, noisy):
         assert np.array_equal(a["K"], b["K"])
     assert _reproj_rms(feats, pm, n, [_as_params(c) for c in job2.cams], strong) < 1.3 * e_exact + 0.3
     pw, ph = out["pano_size"]
     assert pw > 2 * w * 0.8 and out["mask"].float().mean() > 100            # a panorama of sensible extent came out
-    # the multi-rank path refuses the refinement (matches are sharded)
-    with pytest.raises(NotImplementedError):
-        StitchJob(ctx, (w, h), noisy + noisy[:1], rank=0, world_size=2, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"))
+    # the sharded job's path (match entries gathered from the ranks, table rebuilt on the host) gives the same cameras and panorama
+    job3 = StitchJob(ctx, (w, h), noisy, config=isa.StitchConfig.hot_path(ba_cost_func="reproj"), force_collectives=True)
+    out3 = job3.run(frames)
+    for a, b in zip(job2.cams, job3.cams):
+        assert np.array_equal(np.asarray(a["R"]), np.asarray(b["R"])) and np.array_equal(np.asarray(a["K"]), np.asarray(b["K"]))
+    assert torch.equal(out3["pano"], out2["pano"]) and torch.equal(out3["mask"], out2["mask"])
