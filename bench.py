@@ -24,11 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The job's streams (feature lanes, compose, the matcher's side chains) are sized for the runtime's default of 4 hardware
-# queues per process: streams beyond that share queues and serialise (3 / 5 / 8 queues cost the step
-# 1-3 ms).  Pinned here, before the HIP runtime starts, so that an inherited setting cannot change what is measured.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
-
 import numpy as np
 import torch
 

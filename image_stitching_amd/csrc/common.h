@@ -26,6 +26,11 @@ struct MisContext {
     // grow-only scratch for host<->device staging
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // The context's two auxiliary streams (non-blocking, created on first use).  Every stage that forks work off the
+    // context's stream takes them from here -- the ORB batch's helper lanes, then the matcher's side chains -- so a job owns
+    // four streams in all (this one, the two auxiliaries, the caller's compose stream): one per hardware queue of the
+    // runtime's default of four, whichever stage is running.
+    hipStream_t aux[2] = {nullptr, nullptr};
     // pinned, device-visible host block of mis_warp_roi_batch (jobs in, extremes out)
     void* roi_pinned = nullptr;
     size_t roi_pinned_bytes = 0;
@@ -33,6 +38,7 @@ struct MisContext {
 
 int mis_set_error(MisContext* ctx, int code, const char* fmt, ...);
 int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got);
+int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out);   // k = 0, 1
 void mis_pool_free(MisContext* ctx, void* p, size_t bytes);
 
 #define MIS_HIP(ctx, call)                                                                             \

@@ -27,6 +27,13 @@ int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got) {
     return MIS_OK;
 }
 
+int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out) {
+    MIS_CHECK(ctx, k == 0 || k == 1, MIS_E_INVALID, "auxiliary stream index %d", k);
+    if (!ctx->aux[k]) MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking));
+    *out = ctx->aux[k];
+    return MIS_OK;
+}
+
 void mis_pool_free(MisContext* ctx, void* p, size_t bytes) {
     // stream-ordered reuse: every consumer of the block was enqueued on ctx->stream before this call
     if (p) ctx->pool.emplace_back(bytes, p);
@@ -62,6 +69,7 @@ extern "C" int mis_context_destroy(MisContext* ctx) {
     for (auto& b : ctx->pool) hipFree(b.second);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->roi_pinned) hipHostFree(ctx->roi_pinned);
+    for (hipStream_t& a : ctx->aux) if (a) { hipStreamSynchronize(a); hipStreamDestroy(a); a = nullptr; }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MIS_OK;

@@ -604,8 +604,7 @@ struct MatchWorkspace : MisWorkspace {
     ~MatchWorkspace() override {
         dev.release(); pinned.release(); l2.release();
         homo_batch_release(&b1); homo_batch_release(&b2); homo_batch_release(&b3);
-        if (side) hipStreamDestroy(side);
-        if (third) hipStreamDestroy(third);
+        // side / third are the context's auxiliary streams: not owned here
         if (ev_phase1) hipEventDestroy(ev_phase1);
         if (ev_third_done) hipEventDestroy(ev_third_done);
         if (ev_phase0) hipEventDestroy(ev_phase0);
@@ -754,7 +753,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
                        (const float*)d_dst, d_mask, p->num_matches_thresh1, ws->b1.calls, d_out);
     if (!ws->side) {
-        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));   // default priority
+        if ((rc = mis_aux_stream(ctx, 0, &ws->side)) != MIS_OK) return rc;
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase0, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }
@@ -777,16 +776,14 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 1);
     if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, st)) != MIS_OK) return rc;
     } else {
-    // Three chains (the default; MIS_MATCH_CHAINS=2 selects the flow above).  0.45 ms faster per 16 x 4K step -- provided the third
-    // stream does not share a hardware queue with the job's compose stream, hence its own priority class: findHomography returns the RANSAC mask, not one recomputed after
-    // its refinement, so the second estimation starts from the mask while the DLT + LM refinement of the first H runs on a
-    // third stream; the |det H| test of the reference moves to the host assembly below.
+    // Three chains (the default; MIS_MATCH_CHAINS=2 selects the flow above): findHomography returns the RANSAC mask, not one
+    // recomputed after its refinement, so the second estimation starts from the mask while the DLT + LM refinement of the first H
+    // runs on a third stream; the |det H| test of the reference moves to the host assembly below.  Side and third are the
+    // context's two auxiliary streams -- the streams the ORB batch's helper lanes ran on a moment ago -- so that the job keeps to
+    // four streams (an earlier version created two more here, one in a priority class of its own to dodge a shared hardware
+    // queue: the step then moved by 25 % with GPU_MAX_HW_QUEUES).
     if (!ws->third) {
-        // its own priority class, i.e. its own hardware queue: at the default priority this stream came to share a queue with
-        // the job's compose stream and the 2 ms refinement kernels stalled the composition (step 13.5 -> 16.6 ms)
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
-        MIS_HIP(ctx, hipStreamCreateWithPriority(&ws->third, hipStreamNonBlocking, greatest));
+        if ((rc = mis_aux_stream(ctx, 1, &ws->third)) != MIS_OK) return rc;
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_phase1, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_third_done, hipEventDisableTiming));
     }

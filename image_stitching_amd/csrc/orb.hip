@@ -933,8 +933,7 @@ extern "C" int mis_orb_destroy(MisOrb* o) {
     for (MisOrb* hlp : o->helpers) {
         MisContext* hc = hlp->ctx;
         mis_orb_destroy(hlp);
-        hipStreamDestroy(hc->stream);
-        delete hc;
+        delete hc;      // (its stream is the parent context's auxiliary stream)
     }
     for (hipEvent_t e : o->helper_done) hipEventDestroy(e);
     if (o->fork_event) hipEventDestroy(o->fork_event);
@@ -961,10 +960,12 @@ int ensure_helpers(MisOrb* o) {
     for (int k = 0; k < ORB_HELPERS; k++) {
         MisContext* hc = new MisContext();
         hc->device = ctx->device; hc->num_cu = ctx->num_cu;
-        if (hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking) != hipSuccess) { delete hc; return mis_set_error(ctx, MIS_E_HIP, "cannot create a helper stream"); }
+        // a helper lane runs on one of the context's auxiliary streams (shared with the matcher's side chains, which run later)
+        int rc = mis_aux_stream(ctx, k % 2, &hc->stream);
+        if (rc != MIS_OK) { delete hc; return rc; }
         MisOrb* hlp = nullptr;
-        int rc = mis_orb_create(hc, &o->p, o->max_w, o->max_h, &hlp);
-        if (rc != MIS_OK) { mis_set_error(ctx, rc, "helper finder: %s", hc->err.c_str()); hipStreamDestroy(hc->stream); delete hc; return rc; }
+        rc = mis_orb_create(hc, &o->p, o->max_w, o->max_h, &hlp);
+        if (rc != MIS_OK) { mis_set_error(ctx, rc, "helper finder: %s", hc->err.c_str()); delete hc; return rc; }
         hlp->is_helper = true;
         hipEvent_t e;
         MIS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

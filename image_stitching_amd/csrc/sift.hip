@@ -845,8 +845,9 @@ extern "C" int mis_sift_detect_batch(MisSift* s, const MisImage* imgs, int n, Mi
     if (n == 1) return mis_sift_detect(s, imgs, out);
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     if (!s->helper) {
-        int rc = mis_stream_create(ctx->device, 0, &s->helper_stream);
-        if (rc == MIS_OK) rc = mis_context_create(ctx->device, s->helper_stream, &s->helper_ctx);
+        hipStream_t aux = nullptr;       // the second lane runs on the context's first auxiliary stream (shared with the matcher, which runs later)
+        int rc = mis_aux_stream(ctx, 0, &aux);
+        if (rc == MIS_OK) rc = mis_context_create(ctx->device, (void*)aux, &s->helper_ctx);
         if (rc == MIS_OK) rc = mis_sift_create(s->helper_ctx, &s->p, s->max_w, s->max_h, &s->helper);
         if (rc != MIS_OK) return mis_set_error(ctx, rc, "SIFT batch: cannot create the second lane (%s)", s->helper_ctx ? s->helper_ctx->err.c_str() : "stream / context");
     }
