@@ -221,17 +221,19 @@ def measure_roofline(ctx, job, frames, cams, launches):
     us = sum(warper.warp_fused_timed(frames[i], cam["K"], cam["R"], roi, dst, msk, launches) for _ in range(3)) / 3.0
     t_w = us * 1e-6
     del dst, msk
-    # HBM traffic per launch from the PMC passes of profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # runs; FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes): not collectable from inside
-    # this process, so it is read from the committed summary when that belongs to this frame size.
-    traffic = None
+    # HBM traffic from the PMC passes of profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as
+    # the gfx950 note of MI355X_MICROARCH.md prescribes): counters cannot be collected from inside this process, so the committed
+    # summary of the same kernels is read when it belongs to this frame size (tools/profile_round2.sh, tools/collect_profiles.py).
+    traffic, pmc = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")) as f:
-            pm = json.load(f)
-        if pm.get("frame_size") == [cam["width"], cam["height"]]:
-            traffic = pm["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("frame_size") != [cam["width"], cam["height"]]:
+            pmc = None
+        else:
+            traffic = pmc["warp"]["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
-        pass
+        pmc = None
     parts = {"warp": {"kernel": "warp_fused_kernel", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
                       "algorithmic_bytes_per_launch": algo_w, "avg_launch_us": round(t_w * 1e6, 2), "launches": launches,
                       "traffic": traffic}}
@@ -276,19 +278,21 @@ def measure_roofline(ctx, job, frames, cams, launches):
     t_b2 = _events_ms(side, fin) * 1e-3
     t_f, t_b = min(t_f, t_f2), min(t_b, t_b2)
     nmine = len(mine)
-    parts["feed"] = {"kernels": "feed_* / pyr_down_* / laplace_* (mis_blender_feed)", "achieved": round(algo_f / t_f / 1e9, 1),
+    parts["feed"] = {"kernels": "pyr_down_view / feed_tail_build / feed_accumulate (mis_blender_feed)", "achieved": round(algo_f / t_f / 1e9, 1),
                      "frac": round(algo_f / t_f / 8e12, 4), "algorithmic_bytes": algo_f, "frames": nmine, "num_bands": bands,
-                     "padded_tile_px_per_frame": pb_total // nmine, "us_per_frame": round(t_f / nmine * 1e6, 2)}
+                     "padded_tile_px_per_frame": pb_total // nmine, "us_per_frame": round(t_f / nmine * 1e6, 2),
+                     "traffic_per_frame": pmc["feed"]["traffic_bytes_per_frame"] if pmc else None}
     parts["finalize"] = {"kernels": "normalize / collapse2x2 / finalize (mis_blender_blend)", "achieved": round(algo_b / t_b / 1e9, 1),
                          "frac": round(algo_b / t_b / 8e12, 4), "algorithmic_bytes": algo_b, "padded_pano_px": p_pano,
-                         "us": round(t_b * 1e6, 2)}
+                         "us": round(t_b * 1e6, 2), "traffic": pmc["finalize"]["traffic_bytes_per_panorama"] if pmc else None}
     # aggregate over this rank's frames: every frame's warp is costed at the measured frame's launch duration scaled by its bytes
     algo_w_all = sum(3 * S + 7 * rois[k][2] * rois[k][3] for k in mine)
     t_w_all = t_w * algo_w_all / algo_w
     total_b, total_t = algo_w_all + algo_f + algo_b, t_w_all + t_f + t_b
     ach = total_b / total_t / 1e9
     return {"bound": "hbm", "kernel": "K10-K14 aggregate (warp + blend feed + blend finalise; SURVEY 8(d))", "achieved": round(ach, 1),
-            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+            "traffic": (int(traffic * algo_w_all / algo_w) + pmc["feed"]["traffic_bytes_per_frame"] * nmine + pmc["finalize"]["traffic_bytes_per_panorama"]) if pmc else None,
             "algorithmic_bytes": total_b, "device_ms": round(total_t * 1e3, 3), "parts": parts}
 
 

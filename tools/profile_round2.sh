@@ -1,0 +1,23 @@
+#!/bin/bash
+# The judged profile set of round 2 (run through gpurun): bench line, rocprofv3 kernel statistics of the same command, the
+# roofline legs alone (warp / feed / finalise isolated), PMC traffic passes, config-4 (one GPU) and config-5 jobs.
+# bash tools/profile_round2.sh <tag>
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=${1:-a}
+O=$R/gpurun_out/prof2_$tag
+rm -rf $O && mkdir -p $O
+cd $R && python3 bench.py > $O/bench.json 2> $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -o b -- python3 $R/bench.py --roofline-only > $O/roofline.log 2>&1
+cd $R
+# PMC passes (feed_only.py runs the roofline legs: 16 feeds x 2 passes + 2 finalises; warp 3 x 200 + warm-up launches)
+bash tools/pmc_feed.sh > $O/feed_pmc_summary.txt 2>&1
+python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/feed_pmc.json 32 pyr_down_view_kernel feed_accumulate_kernel feed_tail_build_kernel > /dev/null
+python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/finalize_pmc.json 2 normalize_kernel collapse2x2_kernel finalize_kernel > /dev/null
+python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/warp_pmc_raw.json 1 warp_fused_kernel > /dev/null
+python3 bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
+python3 bench.py --workload config4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4_1gpu.json 2> $O/bench_config4_1gpu.err
+tail -1 $O/bench.json | cut -c1-300
+tail -1 $O/bench_config5.json | cut -c1-200
+tail -1 $O/bench_config4_1gpu.json | cut -c1-200
