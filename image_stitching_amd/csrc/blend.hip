@@ -572,6 +572,69 @@ __global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ 
     }
 }
 
+// The last collapse step (level 1 -> level 0) fused with the crop: the collapsed level-0 pixels go straight to the result image
+// (zero outside the mask) and the mask (wsum0 > eps), columns xoff .. xoff + ow - 1 and rows < oh of the padded level -- the
+// level-0 Laplacian is not written back and read again (16 bytes per panorama pixel less than collapse + finalize_kernel).
+// A row of a thread's 2 x 2 block is 12 contiguous bytes of 16SC3 and 8 of f32: whole dwords when `vec` (even widths / aligned rows).
+__global__ __launch_bounds__(256) void collapse2x2_final_kernel(const int16_t* __restrict__ fine, const float* __restrict__ fwgt, int fw, const int16_t* __restrict__ coarse,
+                                                                int cw, int ch, int cx0, int cx1, int xoff, int ow, int oh, int16_t* __restrict__ dst, size_t dstride,
+                                                                uint8_t* __restrict__ dmask, size_t mstride, int vec) {
+    const int X = cx0 + blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= cx1 || Y >= ch) return;
+    const int ox = 2 * X - xoff;                      // output column of the block's left pixel
+    if (ox + 1 < 0 || ox >= ow || 2 * Y >= oh) return;
+    int up[4][3];
+    pyr_up_block(coarse, cw, ch, X, Y, (cw & 1) == 0, up);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = 2 * Y + r;
+        if (y >= oh) break;
+        const size_t o = (size_t)y * fw + 2 * X;
+        int f[6];
+        float w[2];
+        if (vec) {
+            const uint3 d = *reinterpret_cast<const uint3*>(fine + o * 3);
+            f[0] = (int16_t)(d.x & 0xffffu); f[1] = (int16_t)(d.x >> 16); f[2] = (int16_t)(d.y & 0xffffu); f[3] = (int16_t)(d.y >> 16); f[4] = (int16_t)(d.z & 0xffffu); f[5] = (int16_t)(d.z >> 16);
+            const float2 ww = *reinterpret_cast<const float2*>(fwgt + o);
+            w[0] = ww.x; w[1] = ww.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) f[q] = fine[o * 3 + q];
+            w[0] = fwgt[o]; w[1] = fwgt[o + 1];
+        }
+        int v[6];
+        unsigned m[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            m[q] = w[q] > WEIGHT_EPS ? 255u : 0u;
+            const float wn = w[q] + WEIGHT_EPS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int val = sat_s16(up[2 * r + q][c] + (int)(int16_t)((float)f[3 * q + c] / wn));
+                v[3 * q + c] = m[q] ? val : 0;
+            }
+        }
+        int16_t* drow = (int16_t*)((uint8_t*)dst + (size_t)y * dstride);
+        uint8_t* mrow = dmask + (size_t)y * mstride;
+        if (vec && ox >= 0 && ox + 1 < ow) {
+            uint3 pk;
+            pk.x = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+            pk.y = (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16);
+            pk.z = (unsigned)(unsigned short)v[4] | ((unsigned)(unsigned short)v[5] << 16);
+            *reinterpret_cast<uint3*>(drow + 3 * (size_t)ox) = pk;
+            *reinterpret_cast<unsigned short*>(mrow + ox) = (unsigned short)(m[0] | (m[1] << 8));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int x = ox + q;
+                if (x < 0 || x >= ow) continue;
+                drow[3 * (size_t)x] = (int16_t)v[3 * q]; drow[3 * (size_t)x + 1] = (int16_t)v[3 * q + 1]; drow[3 * (size_t)x + 2] = (int16_t)v[3 * q + 2];
+                mrow[x] = (uint8_t)m[q];
+            }
+        }
+    }
+}
+
 // crop to the un-padded roi, dst_mask = wsum0 > eps (or the or-ed mask), zero outside the mask
 // (columns xoff .. xoff + fw - 1 of the panorama -> columns 0 .. fw - 1 of dst)
 __global__ __launch_bounds__(256) void finalize_kernel(const int16_t* lap0, const float* w0, const uint8_t* pmask, int pw, int fw, int fh,
@@ -936,10 +999,18 @@ static int blend_columns(MisBlender* b, int x0, int x1, MisImage* dst, MisImage*
         for (int i = nb; i > 0; i--) {
             MIS_CHECK(ctx, b->lw[i - 1] == 2 * b->lw[i] && b->lh[i - 1] == 2 * b->lh[i], MIS_E_STATE, "pyramid level %d is not twice level %d", i - 1, i);   // by the padding of prepare()
             const int cx0 = lo[i - 1] >> 1, cx1 = ((hi[i - 1] - 1) >> 1) + 1;    // coarse columns whose 2 x 2 blocks cover need[i - 1]
+            if (i == 1) {
+                // the last step writes the cropped, masked result directly
+                const int vec = (b->lw[0] & 1) == 0 && (x0 & 1) == 0 && dd.stride % 4 == 0 && ((uintptr_t)dd.data & 3) == 0 && dm.stride % 2 == 0 && ((uintptr_t)dm.data & 1) == 0;
+                hipLaunchKernelGGL(collapse2x2_final_kernel, grid2d(cx1 - cx0, b->lh[1]), dim3(256), 0, ctx->stream, (const int16_t*)b->lap[0], (const float*)b->wgt[0], b->lw[0],
+                                   (const int16_t*)b->lap[1], b->lw[1], b->lh[1], cx0, cx1, x0, x1 - x0, b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride, vec);
+                break;
+            }
             hipLaunchKernelGGL(collapse2x2_kernel, grid2d(cx1 - cx0, b->lh[i]), dim3(256), 0, ctx->stream, b->lap[i - 1], b->wgt[i - 1], b->lw[i - 1], b->lh[i - 1],
                                (const int16_t*)b->lap[i], b->lw[i], b->lh[i], cx0, cx1);
         }
     }
+    if (b->type == MIS_BLEND_NO || nb == 0)
     hipLaunchKernelGGL(finalize_kernel, grid2d(x1 - x0, b->fh), dim3(256), 0, ctx->stream, b->lap[0], b->wgt[0], b->dst_mask, b->lw[0], x1 - x0,
                        b->fh, (int16_t*)dd.data, dd.stride, (uint8_t*)dm.data, dm.stride, x0);
     MIS_HIP(ctx, hipGetLastError());
