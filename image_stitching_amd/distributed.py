@@ -235,6 +235,36 @@ class HipEngine:
     def matches_from_entries(self, per_rank, n):
         return st.PairwiseMatches.from_entries(self.ctx, n, [e for entries in per_rank for e in entries])
 
+    # ---- seam-scale step (exposure compensation + seam finder) ----
+    def seam_local(self, frames, cams, scale):
+        """This rank's frames at seam scale -> [(corner, image 8UC3 tensor, mask 8U tensor)] (compose stream)."""
+        return [st.seam_scale_warp(self.cctx, self.cfg, self.frame_size, f, c, scale) for f, c in zip(frames, cams)]
+
+    def seam_pack(self, item, cap):
+        """(corner, image, mask) -> one uint8 tensor of cap * 4 bytes (image, then mask) for the all-gather."""
+        _, iw, mw = item
+        buf = torch.zeros(cap * 4, dtype=torch.uint8, device=self.ctx.device)
+        n = mw.numel()
+        buf[:3 * n] = iw.reshape(-1)
+        buf[3 * cap:3 * cap + n] = mw.reshape(-1)
+        return buf
+
+    def seam_unpack(self, buf, w, h, cap):
+        return buf[:3 * w * h].view(h, w, 3), buf[3 * cap:3 * cap + w * h].view(h, w)
+
+    def seam_global(self, corners, images, masks):
+        """Gains and seam masks from every kept frame's seam-scale image (same inputs on every rank: same result)."""
+        self._seam = st.seam_solve(self.cctx, self.cfg, corners, images, masks)
+
+    def warp_feed_seam(self, frame, cam, roi, k):
+        """warp -> gains of image k -> seam mask of image k -> feed (image_stitching.cpp:1154-1171, :1218)."""
+        tl, img_s, mask = self.warper.warp_fused(frame, cam["K"], cam["R"], roi)
+        compensator, seam_masks = self._seam
+        if compensator is not None:
+            compensator.apply(k, tl, img_s, mask)
+        st.seam_mask_apply(self.cctx, seam_masks[k], mask)
+        self.blender.feed(img_s, mask, tl)
+
     # ---- compose ----
     def warp_roi(self, scale, cam):
         return st.warp_roi(scale, self.frame_size, cam["K"], cam["R"])
@@ -363,10 +393,7 @@ class StitchJob:
 
     def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
         self.cfg = config or st.StitchConfig.hot_path()
-        if self.cfg.expos_comp_type != "no" or self.cfg.seam_find_type != "no":
-            # refused rather than ignored: the seam-scale step needs every warped image on one rank
-            raise NotImplementedError("the sharded job composes without exposure compensation / seam finding; "
-                                      "use Stitcher.compose (single GPU) for expos_comp_type / seam_find_type")
+        st.check_seam_config(self.cfg)
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
         self.n = len(cameras)
@@ -376,6 +403,7 @@ class StitchJob:
         self.frame_size = frame_size
         self.scale = st.Stitcher.warped_image_scale(cameras)
         self.force_collectives = force_collectives   # run the pack / gather / reduce code even at world size 1 (tests)
+        self.seam_needed = self.cfg.expos_comp_type != "no" or self.cfg.seam_find_type != "no"
         counts = {len(frame_block(self.n, r, world_size)) for r in range(world_size)}
         if len(counts) != 1:
             raise ValueError("the frame count must divide evenly over the ranks")
@@ -425,12 +453,44 @@ class StitchJob:
         btype, bands = prepared if prepared is not None else self.stage_compose_prepare(indices)
         rois = self._compose_rois
         mine = [i for i in self.my_frames if i in rois]
+        if self.seam_needed:
+            self.stage_seam(frames, indices)
+            for i in mine:
+                eng.warp_feed_seam(frames[i], self.cams[i], rois[i], indices.index(i))
+            return btype, bands
         if hasattr(eng, "warp_feed_many"):
             eng.warp_feed_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine])
         else:
             for i in mine:
                 eng.warp_feed(frames[i], self.cams[i], rois[i])
         return btype, bands
+
+    def stage_seam(self, frames, indices):
+        """The seam-scale step for the kept frames: every rank warps its own frames at seam scale, the small images are
+        all-gathered (0.1 MP each), every rank solves the gains / seams of all of them (host + small kernels, deterministic)."""
+        eng = self.engine
+        mine = [i for i in self.my_frames if i in indices]
+        local = eng.seam_local([frames[i] for i in mine], [self.cams[i] for i in mine], self.scale)
+        if self.world == 1 and not self.force_collectives:
+            items = local
+        else:
+            per = len(self.my_frames)          # equal on every rank; ranks with dropped frames pad with empty records
+            meta = torch.zeros((per, 5), dtype=torch.int32)
+            for k, (i, it) in enumerate(zip(mine, local)):
+                meta[k] = torch.tensor([i, it[0][0], it[0][1], it[2].shape[1], it[2].shape[0]], dtype=torch.int32)
+            meta[len(mine):, 0] = -1
+            dev = local[0][1].device if local else torch.device("cpu")
+            meta_all = self.comm.all_gather(meta.to(dev)).flatten(0, 1).cpu()
+            cap = max(int((meta_all[:, 3] * meta_all[:, 4]).max()), 1)
+            bufs = [eng.seam_pack(it, cap) for it in local] + [torch.zeros(cap * 4, dtype=torch.uint8, device=dev) for _ in range(per - len(mine))]
+            all_bufs = self.comm.all_gather(torch.stack(bufs)).flatten(0, 1)
+            by_index = {}
+            for row, buf in zip(meta_all.tolist(), all_bufs):
+                if row[0] >= 0:
+                    iw, mw = eng.seam_unpack(buf, row[3], row[4], cap)
+                    by_index[row[0]] = ((row[1], row[2]), iw, mw)
+            items = [by_index[i] for i in indices]
+        eng.seam_global([it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
 
     # -- blend exchange: column strips ----------------------------------------------------------
     def rank_region(self, r, indices, rois, bands, w0, h0):
@@ -535,12 +595,15 @@ class StitchJob:
     def _compose_on_side_stream(self, frames, indices, prepared=None):
         """stage_compose with the engine's compose stream current (allocations and launches belong to it)."""
         eng = self.engine
+        if getattr(eng, "compose_stream", None) is None:
+            return self.stage_compose(frames, indices, prepared)
         with torch.cuda.stream(eng.compose_stream):
             return self.stage_compose(frames, indices, prepared)
 
     def run(self, frames):
         refine = self.cfg.ba_cost_func != "no"
-        spec = getattr(self.engine, "speculative_compose", False) and not refine   # refined cameras: compose must wait
+        # refined cameras or a seam-scale step (which needs the kept set): compose must wait for the matcher
+        spec = getattr(self.engine, "speculative_compose", False) and not refine and not self.seam_needed
         prepared = None
         side = getattr(self.engine, "compose_stream", None)
         if side is not None:
@@ -605,7 +668,7 @@ class StitchJob:
                 for i, c in zip(indices, refined):
                     self.cams[i] = c
                 self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])
-            btype, bands = self.stage_compose(frames, indices)
+            btype, bands = self._compose_on_side_stream(frames, indices)     # (torch allocations of the seam step on the library's stream)
             pano, mask = self.stage_exchange_finalize()
         self.engine.sync()      # the job's results are complete when run() returns
         return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,

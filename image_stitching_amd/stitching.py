@@ -854,6 +854,45 @@ def find_homography(ctx, src, dst, thresh=3.0, max_iters=2000, confidence=0.995)
 
 
 # ------------------------------------------------------------------------------------------------
+def check_seam_config(cfg):
+    if cfg.seam_find_type not in ("no", "voronoi", "dp_color"):
+        raise NotImplementedError("seam_find_type %r: 'no', 'voronoi' and 'dp_color' are implemented (dp_colorgrad and the "
+                                  "graph-cut finders are outside this library; DESIGN.md section 8)" % (cfg.seam_find_type,))
+    if cfg.expos_comp_type not in ("no", "gain_blocks"):
+        raise NotImplementedError("expos_comp_type %r: only 'no' and 'gain_blocks' are implemented" % (cfg.expos_comp_type,))
+
+
+def seam_scale_warp(ctx, cfg, frame_size, frame, camera, warped_image_scale, work_scale=1.0):
+    """One frame of the seam-scale loop of main() (image_stitching.cpp:604-622 resize to seam_megapix, :973-990 warp of image and
+    mask with K scaled by seam_work_aspect) -> (corner, image_warped 8UC3, mask_warped 8U) on the device."""
+    w, h = frame_size
+    seam_scale = min(1.0, float(np.sqrt(cfg.seam_megapix * 1e6 / (w * h))))
+    swa = np.float32(seam_scale / work_scale)
+    warper = SphericalWarper(ctx, np.float32(np.float32(warped_image_scale) * swa))
+    img = resize(ctx, frame, fx=seam_scale, fy=seam_scale) if seam_scale < 1.0 else frame
+    K = np.array(camera["K"], np.float32).copy()
+    K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
+    R = np.asarray(camera["R"], np.float32)
+    tl, iw = warper.warp(img, K, R, capi.INTER_LINEAR, capi.BORDER_REFLECT)
+    full = torch.full((img.shape[0], img.shape[1]), 255, dtype=torch.uint8, device=ctx.device)
+    _, mw = warper.warp(full, K, R, capi.INTER_NEAREST, capi.BORDER_CONSTANT)
+    return tl, iw, mw
+
+
+def seam_solve(ctx, cfg, corners, images_warped, masks_warped):
+    """The part of the seam-scale pass that needs every image (image_stitching.cpp:1002-1023 exposure compensator feed, :1029-1065
+    seam finder) -> (compensator | None, masks_warped edited in place)."""
+    compensator = None
+    if cfg.expos_comp_type == "gain_blocks":
+        compensator = BlocksGainCompensator(ctx, cfg.expos_comp_block_size, cfg.expos_comp_block_size, cfg.expos_comp_nr_filtering)
+        compensator.feed(corners, images_warped, masks_warped)
+    if cfg.seam_find_type == "voronoi":
+        VoronoiSeamFinder(ctx).find(images_warped, corners, masks_warped)
+    elif cfg.seam_find_type == "dp_color":
+        DpSeamFinder(ctx, DpSeamFinder.COLOR).find(images_warped, corners, masks_warped)
+    return compensator, masks_warped
+
+
 @dataclass
 class StitchConfig:
     """The reference's globals-as-config (image_stitching.cpp:49-85), same defaults; compose_megapix
@@ -950,37 +989,11 @@ class Stitcher:
     def seam_step(self, frames, cameras, indices, warped_image_scale, work_scale=1.0):
         """The seam-scale pass of main() (image_stitching.cpp:604-622 resize, :973-990 warp, :1002-1023 exposure
         compensator feed, :1029-1065 seam finder) -> (compensator | None, masks_warped) or None when both are off."""
-        cfg = self.cfg
-        if cfg.seam_find_type not in ("no", "voronoi", "dp_color"):
-            raise NotImplementedError("seam_find_type %r: 'no', 'voronoi' and 'dp_color' are implemented (dp_colorgrad and the "
-                                      "graph-cut finders are outside this library; DESIGN.md section 8)" % (cfg.seam_find_type,))
-        if cfg.expos_comp_type not in ("no", "gain_blocks"):
-            raise NotImplementedError("expos_comp_type %r: only 'no' and 'gain_blocks' are implemented" % (cfg.expos_comp_type,))
-        if cfg.expos_comp_type == "no" and cfg.seam_find_type == "no":
+        check_seam_config(self.cfg)
+        if self.cfg.expos_comp_type == "no" and self.cfg.seam_find_type == "no":
             return None
-        w, h = self.frame_size
-        seam_scale = min(1.0, float(np.sqrt(cfg.seam_megapix * 1e6 / (w * h))))
-        swa = np.float32(seam_scale / work_scale)
-        warper = SphericalWarper(self.ctx, np.float32(np.float32(warped_image_scale) * swa))
-        corners, images_warped, masks_warped = [], [], []
-        for i in indices:
-            img = resize(self.ctx, frames[i], fx=seam_scale, fy=seam_scale) if seam_scale < 1.0 else frames[i]
-            K = np.array(cameras[i]["K"], np.float32).copy()
-            K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
-            R = np.asarray(cameras[i]["R"], np.float32)
-            tl, iw = warper.warp(img, K, R, capi.INTER_LINEAR, capi.BORDER_REFLECT)
-            full = torch.full((img.shape[0], img.shape[1]), 255, dtype=torch.uint8, device=self.ctx.device)
-            _, mw = warper.warp(full, K, R, capi.INTER_NEAREST, capi.BORDER_CONSTANT)
-            corners.append(tl); images_warped.append(iw); masks_warped.append(mw)
-        compensator = None
-        if cfg.expos_comp_type == "gain_blocks":
-            compensator = BlocksGainCompensator(self.ctx, cfg.expos_comp_block_size, cfg.expos_comp_block_size, cfg.expos_comp_nr_filtering)
-            compensator.feed(corners, images_warped, masks_warped)
-        if cfg.seam_find_type == "voronoi":
-            VoronoiSeamFinder(self.ctx).find(images_warped, corners, masks_warped)
-        elif cfg.seam_find_type == "dp_color":
-            DpSeamFinder(self.ctx, DpSeamFinder.COLOR).find(images_warped, corners, masks_warped)
-        return compensator, masks_warped
+        items = [seam_scale_warp(self.ctx, self.cfg, self.frame_size, frames[i], cameras[i], warped_image_scale, work_scale) for i in indices]
+        return seam_solve(self.ctx, self.cfg, [it[0] for it in items], [it[1] for it in items], [it[2] for it in items])
 
     def stitch(self, frames, cameras):
         feats = self.features(frames)

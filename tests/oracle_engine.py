@@ -21,7 +21,8 @@ class _MI:
 class OracleEngine:
     CAP = 4000 + 128 * 8
 
-    def __init__(self, frame_size, blend_type=oracle.BLEND_MULTI_BAND, blend_strength=5.0, match_conf=0.32):
+    def __init__(self, frame_size, blend_type=oracle.BLEND_MULTI_BAND, blend_strength=5.0, match_conf=0.32, config=None):
+        self.cfg = config
         self.frame_size = frame_size
         self.orb = oracle.Orb(*frame_size)
         self.blend_type, self.blend_strength, self.match_conf = blend_type, blend_strength, match_conf
@@ -98,6 +99,59 @@ class OracleEngine:
         f = np.asarray(frame)
         img, tl = oracle.warp_spherical(f, self.scale, K, R)
         msk, _ = oracle.warp_spherical(np.full(f.shape[:2], 255, np.uint8), self.scale, K, R, oracle.INTER_NEAREST, oracle.BORDER_CONSTANT)
+        self.blender.feed(img.astype(np.int16), msk, tl)
+
+    # ---- seam-scale step (oracle twins of seam_scale_warp / seam_solve) ----
+    def seam_local(self, frames, cams, scale):
+        w, h = self.frame_size
+        seam_scale = min(1.0, float(np.sqrt(self.cfg.seam_megapix * 1e6 / (w * h))))
+        swa = np.float32(seam_scale)
+        sscale = float(np.float32(np.float32(scale) * swa))
+        out = []
+        for f, cam in zip(frames, cams):
+            f = np.asarray(f)
+            img = oracle.resize_exact(f, fx=seam_scale, fy=seam_scale) if seam_scale < 1 else f
+            K = cam["K"].astype(np.float32).copy()
+            K[0, 0] *= swa; K[0, 2] *= swa; K[1, 1] *= swa; K[1, 2] *= swa
+            R = cam["R"].astype(np.float32)
+            wi, tl = oracle.warp_spherical(img, sscale, K, R)
+            wm, _ = oracle.warp_spherical(np.full(img.shape[:2], 255, np.uint8), sscale, K, R, oracle.INTER_NEAREST, oracle.BORDER_CONSTANT)
+            out.append((tl, torch.from_numpy(wi), torch.from_numpy(wm)))
+        return out
+
+    def seam_pack(self, item, cap):
+        _, iw, mw = item
+        buf = torch.zeros(cap * 4, dtype=torch.uint8)
+        n = mw.numel()
+        buf[:3 * n] = iw.reshape(-1)
+        buf[3 * cap:3 * cap + n] = mw.reshape(-1)
+        return buf
+
+    def seam_unpack(self, buf, w, h, cap):
+        return buf[:3 * w * h].view(h, w, 3), buf[3 * cap:3 * cap + w * h].view(h, w)
+
+    def seam_global(self, corners, images, masks):
+        iw = [np.ascontiguousarray(i.numpy()) for i in images]
+        mw = [np.ascontiguousarray(m.numpy()) for m in masks]
+        comp = None
+        if self.cfg.expos_comp_type == "gain_blocks":
+            comp = oracle.Compensator(self.cfg.expos_comp_block_size, self.cfg.expos_comp_block_size, self.cfg.expos_comp_nr_filtering)
+            comp.feed(corners, iw, mw)
+        if self.cfg.seam_find_type == "voronoi":
+            mw = oracle.voronoi_seams(corners, mw)
+        elif self.cfg.seam_find_type == "dp_color":
+            mw = oracle.dp_seams(iw, corners, mw)
+        self._seam = (comp, mw)
+
+    def warp_feed_seam(self, frame, cam, roi, k):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        f = np.asarray(frame)
+        img, tl = oracle.warp_spherical(f, self.scale, K, R)
+        msk, _ = oracle.warp_spherical(np.full(f.shape[:2], 255, np.uint8), self.scale, K, R, oracle.INTER_NEAREST, oracle.BORDER_CONSTANT)
+        comp, seam_masks = self._seam
+        if comp is not None:
+            img = comp.apply(k, img)
+        msk = oracle.seam_mask_apply(seam_masks[k], msk)
         self.blender.feed(img.astype(np.int16), msk, tl)
 
     def accumulators(self):

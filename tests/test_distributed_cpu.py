@@ -26,23 +26,25 @@ def _cams():
     return [synth.make_camera(W, H, 60.0, 13.0 * i - 20.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(NFRAMES)]
 
 
-def _run_job(rank, world, group):
+def _run_job(rank, world, group, seam=False):
     import synth
     from image_stitching_amd.distributed import StitchJob
+    from image_stitching_amd.stitching import StitchConfig
     from oracle_engine import OracleEngine
     cams = _cams()
-    job = StitchJob(None, (W, H), cams, rank=rank, world_size=world, group=group, engine=OracleEngine((W, H)))
+    cfg = StitchConfig(seam_megapix=0.02) if seam else StitchConfig.hot_path()     # seam: the reference's defaults (gain_blocks + dp_color)
+    job = StitchJob(None, (W, H), cams, rank=rank, world_size=world, group=group, engine=OracleEngine((W, H), config=cfg), config=cfg)
     frames = {i: synth.render_frame(cams[i]) for i in job.my_frames}
     return job, job.run(frames)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, seam=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        job, out = _run_job(rank, world, dist.group.WORLD)
+        job, out = _run_job(rank, world, dist.group.WORLD, seam)
         assert job.my_frames == list(range(rank * 2, rank * 2 + 2))
         if rank == 0:
             np.savez(out_path, pano=out["pano"], mask=out["mask"], conf=out["confidence"].numpy(), indices=np.array(out["indices"]),
@@ -140,12 +142,26 @@ def test_strip_plan_covers_what_a_strip_needs():
     assert StitchJob.exchange_rects((0, 0, 320, 64), need, sizes)[0][0][:3] == (4, 19, 0)      # a region left of the strip only meets its coarse halo
 
 
+def test_two_rank_job_with_seam_step_matches_single_rank(tmp_path):
+    """The reference's default seam-scale step (block gains + DpSeamFinder) inside the sharded job: the seam-scale images are
+    all-gathered and every rank solves the same problem -- masks identical, pixels within the f32 association of the exchange."""
+    _, ref = _run_job(0, 1, None, seam=True)
+    _, plain = _run_job(0, 1, None, seam=False)
+    out_path = str(tmp_path / "rank0.npz")
+    mp.start_processes(_worker, args=(2, _free_port(), out_path, True), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out_path)
+    assert np.array_equal(got["mask"], ref["mask"])
+    d = np.abs(got["pano"].astype(np.int32) - ref["pano"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+    assert not np.array_equal(ref["pano"], plain["pano"])        # the seam step did change the panorama
+
+
 def test_job_refuses_options_it_does_not_run():
-    """Options the sharded job cannot honour are refused at construction, never silently ignored."""
+    """Options the library does not implement are refused at construction, never silently ignored."""
     from image_stitching_amd.distributed import StitchJob
     from image_stitching_amd.stitching import StitchConfig
     from oracle_engine import OracleEngine
     cams = _cams()
-    for cfg in (StitchConfig.hot_path(expos_comp_type="gain_blocks"), StitchConfig.hot_path(seam_find_type="voronoi")):
+    for cfg in (StitchConfig.hot_path(expos_comp_type="channels"), StitchConfig.hot_path(seam_find_type="gc_color")):
         with pytest.raises(NotImplementedError):
             StitchJob(None, (W, H), cams, engine=OracleEngine((W, H)), config=cfg)

@@ -172,6 +172,28 @@ def test_two_ranks_on_one_gpu_match_single_rank(ctx, tmp_path):
     assert d.max() <= 1 and (d > 0).mean() < 0.02          # f32 weight sums in a different order where >= 3 frames overlap
 
 
+@pytest.mark.parametrize("forced", [False, True])
+def test_job_with_the_reference_default_seam_step_equals_the_stitcher(ctx, forced):
+    """StitchConfig() -- the reference's defaults: block gain compensation + DpSeamFinder(COLOR) -- inside the job (also with the
+    all-gather of the seam-scale images forced on) against Stitcher.compose, which makes one library call per reference call."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd.distributed import StitchJob
+    w, h = 640, 360
+    cams = [synth.make_camera(w, h, 60.0, 13.0 * i - 20.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(4)]
+    gains = [0.8, 1.0, 1.2, 0.9]
+    host = [np.clip(synth.render_frame(c).astype(np.float32) * g, 0, 255).astype(np.uint8) for c, g in zip(cams, gains)]
+    dev = [torch.from_numpy(f).cuda() for f in host]
+    cfg = isa.StitchConfig(compose_megapix=-1)
+    want, wmask = isa.Stitcher(ctx, (w, h), cfg).compose(dev, cams)
+    out = StitchJob(ctx, (w, h), cams, config=cfg, force_collectives=forced).run({i: f for i, f in enumerate(dev)})
+    assert out["indices"] == [0, 1, 2, 3]
+    assert torch.equal(out["mask"], wmask) and torch.equal(out["pano"], want)
+    plain = StitchJob(ctx, (w, h), cams).run({i: f for i, f in enumerate(dev)})
+    assert not torch.equal(plain["pano"], want)
+
+
 def _ba_scene():
     import synth
     w, h = 480, 270
