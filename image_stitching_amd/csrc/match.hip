@@ -800,11 +800,14 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st)) != MIS_OK) return rc;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase1, st));
-    hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
-                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 0);
-    if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, st)) != MIS_OK) return rc;
+    // the refinement of the phase-1 finishers' first H stays on this stream (1.7 ms of latency-bound work: behind the 2 ms
+    // refinement of the phase-0 finishers on the third stream it ended the matcher 0.6 ms later); their inlier-only second
+    // estimation goes to the third stream instead
+    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 13, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase1, 0));
-    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 13, ws->third)) != MIS_OK) return rc;
+    hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->third, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
+                       (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 0);
+    if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, ws->third)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_third_done, ws->third));
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_third_done, 0));
     }
