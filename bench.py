@@ -200,8 +200,8 @@ def measure_roofline(ctx, job, frames, cams, launches):
     HIP events on the stream its kernels are launched on.
       warp (K10):      (3 S + 7 P) per frame / average duration of `launches` back-to-back launches of warp_fused_kernel
                        for one frame, enqueued from inside the library (mis_warp_spherical_fused_timed);
-      feed (K12-K13):  sum over this rank's frames of 7 P_i + 2 (6 + 4) (4/3) P_b,i / the time of their mis_blender_feed
-                       calls (P_b,i = the feed's padded tile, mis_blender_feed_rect);
+      feed (K12-K13):  sum over this rank's frames of 7 P_i + 2 (6 + 4) (4/3) P_b,i / the time of their mis_blender_feed_batch
+                       call (P_b,i = the feed's padded tile, mis_blender_feed_rect); the time of n single feeds beside it;
       finalise (K14):  44.3 B per padded panorama pixel / the time of mis_blender_blend.
     The headline object is the aggregate; `parts` carries each leg, the warp kernel alone first."""
     import ctypes as C
@@ -257,7 +257,10 @@ def measure_roofline(ctx, job, frames, cams, launches):
         pb_total += pb
         algo_f += 7 * rois[k][2] * rois[k][3] + (2 * (6 + 4) * 4 * pb) // 3
 
-    def feeds():
+    def feeds():   # what mis_compose_frames runs after its warps: the frames' pyramids built together, Laplacians added frame by frame
+        eng.blender.feed_batch([w[0] for w in warped], [w[1] for w in warped], [w[2] for w in warped])
+
+    def feeds_single():
         for img_s, mk, tl in warped:
             eng.blender.feed(img_s, mk, tl)
     t_f = _events_ms(side, feeds) * 1e-3
@@ -277,10 +280,14 @@ def measure_roofline(ctx, job, frames, cams, launches):
     t_f2 = _events_ms(side, feeds) * 1e-3
     t_b2 = _events_ms(side, fin) * 1e-3
     t_f, t_b = min(t_f, t_f2), min(t_b, t_b2)
+    with torch.cuda.stream(side):
+        job.stage_compose_prepare(list(range(job.n)))
+    t_f1 = _events_ms(side, feeds_single) * 1e-3   # the same frames through n separate mis_blender_feed calls
     nmine = len(mine)
-    parts["feed"] = {"kernels": "pyr_down_view / feed_tail_build / feed_accumulate (mis_blender_feed)", "achieved": round(algo_f / t_f / 1e9, 1),
+    parts["feed"] = {"kernels": "pyr_down_l1_batch / pyr_down_level_batch / feed_tail_build / feed_accumulate (mis_blender_feed_batch, as in mis_compose_frames)", "achieved": round(algo_f / t_f / 1e9, 1),
                      "frac": round(algo_f / t_f / 8e12, 4), "algorithmic_bytes": algo_f, "frames": nmine, "num_bands": bands,
                      "padded_tile_px_per_frame": pb_total // nmine, "us_per_frame": round(t_f / nmine * 1e6, 2),
+                     "us_per_frame_single_feeds": round(t_f1 / nmine * 1e6, 2),
                      "traffic_per_frame": pmc["feed"]["traffic_bytes_per_frame"] if pmc else None}
     parts["finalize"] = {"kernels": "normalize / collapse2x2 / finalize (mis_blender_blend)", "achieved": round(algo_b / t_b / 1e9, 1),
                          "frac": round(algo_b / t_b / 8e12, 4), "algorithmic_bytes": algo_b, "padded_pano_px": p_pano,

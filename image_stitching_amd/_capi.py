@@ -146,6 +146,7 @@ PROTOTYPES = {
     "mis_blender_prepare": (_i, [_vp, _P(MisPoint), _P(MisSize), _i]),
     "mis_blender_num_bands": (_i, [_vp]),
     "mis_blender_feed": (_i, [_vp, _P(MisImage), _P(MisImage), MisPoint]),
+    "mis_blender_feed_batch": (_i, [_vp, _P(MisImage), _P(MisImage), _P(MisPoint), _i]),
     "mis_blender_blend": (_i, [_vp, _P(MisImage), _P(MisImage)]),
     "mis_compose_frames": (_i, [_vp, _P(MisImage), _i, _f, _vp, _vp, _P(MisRect)]),
     "mis_blender_blend_columns": (_i, [_vp, _i, _i, _P(MisImage), _P(MisImage)]),

@@ -14,6 +14,8 @@
 #include "dev_math.h"
 #include <algorithm>
 #include <cmath>
+#include <utility>
+#include <vector>
 
 #define MIS_MAX_BANDS 16
 
@@ -110,13 +112,13 @@ constexpr int PDV_MROW_DW = (PD_SW + 3 + 3) / 4 + 1;      // same for the 67 mas
 // FROM_VIEW = false: the same pair of reductions for a level >= 1 (sources: the frame's Gaussian level `src` and weight level
 // `wsrc`, sw x sh, tightly packed), one launch instead of two per level.
 template <bool FROM_VIEW>
-__global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const int16_t* __restrict__ src, const float* __restrict__ wsrc, int psw, int psh,
-                                                            int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh) {
+__device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int16_t* __restrict__ src, const float* __restrict__ wsrc, int psw, int psh,
+                                                   int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh, int bx, int by) {
     __shared__ __attribute__((aligned(4))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
     __shared__ float wt[PD_SH * PD_SW];
     __shared__ int vbuf[PD_H * PDV_ROW_DW];   // vertical sums: 16 rows of packed u16 pairs (fast path) or 8 rows of one int per short
     unsigned wide_bits = 0;   // bits of the staged shorts outside 0..255 (0 for a converted 8-bit image: the packed 16-bit path is exact)
-    const int x0 = blockIdx.x * PD_W, y0 = blockIdx.y * PD_H, t = threadIdx.x;
+    const int x0 = bx * PD_W, y0 = by * PD_H, t = threadIdx.x;
     const int sw = FROM_VIEW ? v.tw : psw, sh = FROM_VIEW ? v.th : psh;
     const int tx0 = 2 * x0 - 2, ty0 = 2 * y0 - 2;                    // tile coordinates of the footprint's corner
     const int ix0 = tx0 - v.left, iy0 = ty0 - v.top;                 // image coordinates of the same
@@ -325,6 +327,40 @@ __global__ __launch_bounds__(256) void pyr_down_view_kernel(FrameView v, const i
     }
 }
 
+// ---- a batch of frames through the reductions ----
+// The Gaussian pyramids of up to FB_MAX frames are built together: one launch per level for all of them (grid z = frame) instead
+// of one per level and frame.  Below level 1 a 4K frame's levels are a few hundred workgroups: alone they leave most of the 256
+// CUs idle and cost ~7 us of launch-to-launch latency each (5 launches + the tail per frame: 50 of the 163 us of a feed).
+// Every frame owns one scratch region laid out for the largest tile of the batch, so the level offsets are the same for all.
+constexpr int FB_MAX = 16;
+struct FeedLayout {
+    int nb, first;                                               // levels first + 1 .. nb are built by the tail kernel (first > nb: none)
+    size_t goff[MIS_MAX_BANDS + 1], woff[MIS_MAX_BANDS + 1];     // byte offsets of G_l / W_l inside a frame's region (l >= 1)
+};
+struct FeedBatch {
+    int n;
+    uint8_t* base[FB_MAX];                                       // scratch region of frame k
+    FrameView v[FB_MAX];
+};
+__device__ __forceinline__ int level_dim(int d, int l) { for (int i = 0; i < l; i++) d = (d + 1) >> 1; return d; }
+
+__global__ __launch_bounds__(256) void pyr_down_l1_batch_kernel(FeedBatch fb, FeedLayout lay) {
+    const int f = blockIdx.z;
+    const FrameView v = fb.v[f];
+    const int dw = (v.tw + 1) >> 1, dh = (v.th + 1) >> 1;
+    if ((int)blockIdx.x * PD_W >= dw || (int)blockIdx.y * PD_H >= dh) return;   // the grid covers the largest frame of the batch
+    pyr_down_view_tile<true>(v, nullptr, nullptr, 0, 0, (int16_t*)(fb.base[f] + lay.goff[1]), (float*)(fb.base[f] + lay.woff[1]), dw, dh, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void pyr_down_level_batch_kernel(FeedBatch fb, FeedLayout lay, int l) {   // level l -> l + 1, l >= 1
+    const int f = blockIdx.z;
+    const int sw = level_dim(fb.v[f].tw, l), sh = level_dim(fb.v[f].th, l), dw = (sw + 1) >> 1, dh = (sh + 1) >> 1;
+    if ((int)blockIdx.x * PD_W >= dw || (int)blockIdx.y * PD_H >= dh) return;
+    uint8_t* base = fb.base[f];
+    FrameView none{};
+    pyr_down_view_tile<false>(none, (const int16_t*)(base + lay.goff[l]), (const float*)(base + lay.woff[l]), sw, sh, (int16_t*)(base + lay.goff[l + 1]),
+                              (float*)(base + lay.woff[l + 1]), dw, dh, blockIdx.x, blockIdx.y);
+}
+
 // pyrUp of a coarse 16SC3 level evaluated at one fine pixel (fine = 2 x coarse exactly):
 // even: r[x-1] + 6 r[x] + r[x+1], odd: 4 (r[x] + r[x+1]); left/top neighbour of sample 0 is sample 1,
 // right/bottom neighbour of the last sample is the last sample; (v + 32) >> 6.
@@ -423,11 +459,16 @@ struct FeedTail {
     int pw[MIS_MAX_BANDS + 1], x_tl[MIS_MAX_BANDS + 1], y_tl[MIS_MAX_BANDS + 1];
     int blk_off[MIS_MAX_BANDS + 2];                   // accumulate grid: first block of every level
 };
-__global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedTail t) {
-    for (int l = t.first; l < t.nb; l++) {
-        const int sw = t.tw[l], sh = t.th[l], dw = t.tw[l + 1], dh = t.th[l + 1];
-        const int16_t* src = t.G[l];
-        const float* wsrc = t.W[l];
+__global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedBatch fb, FeedLayout lay) {   // one workgroup per frame
+    const int f = blockIdx.x;
+    uint8_t* base = fb.base[f];
+    int sw = level_dim(fb.v[f].tw, lay.first), sh = level_dim(fb.v[f].th, lay.first);
+    for (int l = lay.first; l < lay.nb; l++) {
+        const int dw = (sw + 1) >> 1, dh = (sh + 1) >> 1;
+        const int16_t* src = (const int16_t*)(base + lay.goff[l]);
+        const float* wsrc = (const float*)(base + lay.woff[l]);
+        int16_t* gdst = (int16_t*)(base + lay.goff[l + 1]);
+        float* wdst = (float*)(base + lay.woff[l + 1]);
         for (int i = threadIdx.x; i < dw * dh; i += 1024) {
             const int y = i / dw, x = i - y * dw;
             int xi[5], yi[5];
@@ -445,10 +486,11 @@ __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedTail t) {
                 const float* wr = wsrc + (size_t)yi[j] * sw;
                 hr[j] = ((wr[xi[2]] * 6.f + (wr[xi[1]] + wr[xi[3]]) * 4.f) + wr[xi[0]]) + wr[xi[4]];
             }
-            int16_t* o = t.G[l + 1] + (size_t)i * 3;
+            int16_t* o = gdst + (size_t)i * 3;
             o[0] = (int16_t)((acc[0] + 128) >> 8); o[1] = (int16_t)((acc[1] + 128) >> 8); o[2] = (int16_t)((acc[2] + 128) >> 8);
-            t.W[l + 1][i] = (((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4]) * (1.f / 256.f);
+            wdst[i] = (((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4]) * (1.f / 256.f);
         }
+        sw = dw; sh = dh;
         __syncthreads();
     }
 }
@@ -749,66 +791,103 @@ void feed_tile_rect(const MisBlender* b, int w, int h, MisPoint tl, int* otnx, i
     *otnx = tnx; *otny = tny; *owidth = width; *oheight = height;
 }
 
-int feed_multiband(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
+// n frames into the multi-band pyramids, bit-identical to n single feeds in the same order: the Gaussian pyramids of all
+// frames are built first (batched launches, see FeedBatch), then the Laplacians are accumulated frame by frame (the f32 weight
+// sums keep the feed order).
+int feed_multiband_batch(MisBlender* b, const MisImage* imgs, const DevImage* dimg, const DevImage* dmask, const MisPoint* tls, int n) {
     MisContext* ctx = b->ctx;
     const int nb = b->num_bands;
     const MisRect& R = b->roi;
-    int tnx, tny, width, height;
-    feed_tile_rect(b, w, h, tl, &tnx, &tny, &width, &height);
-    const int bnx = tnx + width, bny = tny + height;
-    FrameView v;
-    v.img = (const int16_t*)dimg.data; v.istride = dimg.stride / 2;
-    v.mask = (const uint8_t*)dmask.data; v.mstride = dmask.stride;
-    v.w = w; v.h = h; v.left = tl.x - tnx; v.top = tl.y - tny; v.tw = width; v.th = height;
-    int bottom = bny - tl.y - h, right = bnx - tl.x - w;
-    MIS_CHECK(ctx, v.left >= 0 && v.top >= 0 && bottom >= 0 && right >= 0, MIS_E_INVALID, "frame does not fit the prepared panorama roi");
-
-    // scratch: Gaussian levels 1..nb of the frame (16SC3) and of the weights (f32)
-    int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1];
-    size_t goff[MIS_MAX_BANDS + 1], woff[MIS_MAX_BANDS + 1], total = 0;
-    tw[0] = width; th[0] = height;
-    for (int i = 1; i <= nb; i++) {
-        tw[i] = (tw[i - 1] + 1) / 2; th[i] = (th[i - 1] + 1) / 2;
-        goff[i] = total; total += mis_align_up((size_t)tw[i] * th[i] * 6, 256);
-        woff[i] = total; total += mis_align_up((size_t)tw[i] * th[i] * 4, 256);
+    struct Frame { FrameView v; int x_tl, y_tl, view_ok; };
+    std::vector<Frame> fr(n);
+    int mtw = 0, mth = 0;
+    for (int k = 0; k < n; k++) {
+        const int w = imgs[k].width, h = imgs[k].height;
+        int tnx, tny, width, height;
+        feed_tile_rect(b, w, h, tls[k], &tnx, &tny, &width, &height);
+        const int bnx = tnx + width, bny = tny + height;
+        FrameView& v = fr[k].v;
+        v.img = (const int16_t*)dimg[k].data; v.istride = dimg[k].stride / 2;
+        v.mask = (const uint8_t*)dmask[k].data; v.mstride = dmask[k].stride;
+        v.w = w; v.h = h; v.left = tls[k].x - tnx; v.top = tls[k].y - tny; v.tw = width; v.th = height;
+        const int bottom = bny - tls[k].y - h, right = bnx - tls[k].x - w;
+        MIS_CHECK(ctx, v.left >= 0 && v.top >= 0 && bottom >= 0 && right >= 0, MIS_E_INVALID, "frame %d does not fit the prepared panorama roi", k);
+        fr[k].x_tl = tnx - R.x; fr[k].y_tl = tny - R.y;
+        fr[k].view_ok = ((uintptr_t)v.img & 3) == 0 && (v.istride & 1) == 0;   // rows of the frame start on a dword: 8-byte pixel loads
+        mtw = std::max(mtw, width); mth = std::max(mth, height);
     }
-    int rc = ensure_scratch(b, total ? total : 256);
-    if (rc != MIS_OK) return rc;
-    auto G = [&](int i) { return (int16_t*)((uint8_t*)b->scratch + goff[i]); };
-    auto W = [&](int i) { return (float*)((uint8_t*)b->scratch + woff[i]); };
     dim3 blk(256);
-    // levels `first` .. nb (each at most FEED_TAIL_PIXELS pixels) go through the two tail kernels
-    int first = nb + 1;
-    for (int i = nb; i >= 2 && (size_t)tw[i] * th[i] <= FEED_TAIL_PIXELS; i--) first = i;
-    if (first >= nb) first = nb + 1;     // a single level is not worth it
-    const int view_ok = ((uintptr_t)v.img & 3) == 0 && (v.istride & 1) == 0;   // rows of the frame start on a dword: 8-byte pixel loads
-    int y_tl = tny - R.y, x_tl = tnx - R.x;
     if (nb == 0) {
-        hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), grid2d(width, height), blk, 0, ctx->stream, v, nullptr, nullptr, width, height, (const int16_t*)nullptr, 0, 0,
-                           b->lap[0], b->wgt[0], b->lw[0], x_tl, y_tl);
+        for (int k = 0; k < n; k++)
+            hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), grid2d(fr[k].v.tw, fr[k].v.th), blk, 0, ctx->stream, fr[k].v, nullptr, nullptr, fr[k].v.tw, fr[k].v.th,
+                               (const int16_t*)nullptr, 0, 0, b->lap[0], b->wgt[0], b->lw[0], fr[k].x_tl, fr[k].y_tl);
         MIS_HIP(ctx, hipGetLastError());
         return MIS_OK;
     }
-    // every level is accumulated by one multi-level grid (feed_accumulate_kernel; level 0 reads the frame view)
-    FeedTail ft;
-    ft.first = first; ft.nb = nb; ft.acc_first = 0;
-    for (int i = 0; i <= nb; i++) {
-        ft.tw[i] = tw[i]; ft.th[i] = th[i]; ft.G[i] = i ? G(i) : nullptr; ft.W[i] = i ? W(i) : nullptr; ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
-        ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
-        x_tl /= 2; y_tl /= 2;
+    // scratch: one region per frame, Gaussian levels 1..nb of the frame (16SC3) and of the weights (f32) for the largest tile
+    FeedLayout lay;
+    lay.nb = nb;
+    size_t region = 0;
+    {
+        int tw = mtw, th = mth;
+        for (int i = 1; i <= nb; i++) {
+            tw = (tw + 1) / 2; th = (th + 1) / 2;
+            lay.goff[i] = region; region += mis_align_up((size_t)tw * th * 6, 256);
+            lay.woff[i] = region; region += mis_align_up((size_t)tw * th * 4, 256);
+        }
+        lay.goff[0] = lay.woff[0] = 0;
     }
-    int nblk = 0;
-    for (int i = 0; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
-    ft.blk_off[nb + 1] = nblk;
-    // (tried: the small levels on a second stream beside the accumulation of level 0, joined by events -- 181 instead of 164 us per
-    // 4K frame: two cross-stream dependencies per frame cost more than the overlap gains)
-    hipLaunchKernelGGL((pyr_down_view_kernel<true>), dim3((tw[1] + PD_W - 1) / PD_W, (th[1] + PD_H - 1) / PD_H), blk, 0, ctx->stream, v, nullptr, nullptr, 0, 0, G(1), W(1), tw[1],
-                       th[1]);
-    for (int i = 1; i < nb && i < first; i++)   // G(first + 1 ..) are built by feed_tail_build_kernel
-        hipLaunchKernelGGL((pyr_down_view_kernel<false>), dim3((tw[i + 1] + PD_W - 1) / PD_W, (th[i + 1] + PD_H - 1) / PD_H), blk, 0, ctx->stream, v, (const int16_t*)G(i),
-                           (const float*)W(i), tw[i], th[i], G(i + 1), W(i + 1), tw[i + 1], th[i + 1]);
-    if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(1), dim3(1024), 0, ctx->stream, ft);
-    hipLaunchKernelGGL(feed_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft, v, view_ok, 0);
+    int rc = ensure_scratch(b, region ? region * n : 256);
+    if (rc != MIS_OK) return rc;
+    // levels `first` .. nb (each at most FEED_TAIL_PIXELS pixels) are built by the tail kernel, one workgroup per frame; the
+    // batch shares one split (the largest of the frames' own: either kernel computes the same values)
+    int first = 0;
+    for (int k = 0; k < n; k++) {
+        int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1];
+        tw[0] = fr[k].v.tw; th[0] = fr[k].v.th;
+        for (int i = 1; i <= nb; i++) { tw[i] = (tw[i - 1] + 1) / 2; th[i] = (th[i - 1] + 1) / 2; }
+        int f = nb + 1;
+        for (int i = nb; i >= 2 && (size_t)tw[i] * th[i] <= FEED_TAIL_PIXELS; i--) f = i;
+        if (f >= nb) f = nb + 1;     // a single level is not worth it
+        first = std::max(first, f);
+    }
+    lay.first = first;
+    for (int g0 = 0; g0 < n; g0 += FB_MAX) {
+        const int ng = std::min(FB_MAX, n - g0);
+        FeedBatch fb;
+        fb.n = ng;
+        int gtw = 0, gth = 0;
+        for (int k = 0; k < ng; k++) {
+            fb.v[k] = fr[g0 + k].v; fb.base[k] = (uint8_t*)b->scratch + (size_t)(g0 + k) * region;
+            gtw = std::max(gtw, fb.v[k].tw); gth = std::max(gth, fb.v[k].th);
+        }
+        for (int k = ng; k < FB_MAX; k++) { fb.v[k] = fb.v[0]; fb.base[k] = fb.base[0]; }
+        int lw = (gtw + 1) / 2, lh = (gth + 1) / 2;
+        hipLaunchKernelGGL(pyr_down_l1_batch_kernel, dim3((lw + PD_W - 1) / PD_W, (lh + PD_H - 1) / PD_H, ng), blk, 0, ctx->stream, fb, lay);
+        for (int i = 1; i < nb && i < first; i++) {   // G(first + 1 ..) are built by feed_tail_build_kernel
+            lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+            hipLaunchKernelGGL(pyr_down_level_batch_kernel, dim3((lw + PD_W - 1) / PD_W, (lh + PD_H - 1) / PD_H, ng), blk, 0, ctx->stream, fb, lay, i);
+        }
+        if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(ng), dim3(1024), 0, ctx->stream, fb, lay);
+    }
+    // every level of a frame is accumulated by one multi-level grid (feed_accumulate_kernel; level 0 reads the frame view)
+    for (int k = 0; k < n; k++) {
+        uint8_t* base = (uint8_t*)b->scratch + (size_t)k * region;
+        FeedTail ft;
+        ft.first = first; ft.nb = nb; ft.acc_first = 0;
+        int x_tl = fr[k].x_tl, y_tl = fr[k].y_tl, tw = fr[k].v.tw, th = fr[k].v.th;
+        for (int i = 0; i <= nb; i++) {
+            ft.tw[i] = tw; ft.th[i] = th;
+            ft.G[i] = i ? (int16_t*)(base + lay.goff[i]) : nullptr; ft.W[i] = i ? (float*)(base + lay.woff[i]) : nullptr;
+            ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
+            ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
+            x_tl /= 2; y_tl /= 2; tw = (tw + 1) / 2; th = (th + 1) / 2;
+        }
+        int nblk = 0;
+        for (int i = 0; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
+        ft.blk_off[nb + 1] = nblk;
+        hipLaunchKernelGGL(feed_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft, fr[k].v, fr[k].view_ok, 0);
+    }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -917,23 +996,29 @@ extern "C" int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const
     return MIS_OK;
 }
 
-extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisImage* mask, MisPoint tl) {
-    if (!b) return MIS_E_INVALID;
+static int feed_check(MisBlender* b, const MisImage* img, const MisImage* mask, MisPoint tl) {
     MisContext* ctx = b->ctx;
-    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "feed before prepare");
     MIS_CHECK(ctx, img && mask && img->dtype == MIS_S16 && img->channels == 3 && mask->dtype == MIS_U8 && mask->channels == 1,
               MIS_E_INVALID, "feed needs a 16SC3 image and an 8U mask");
     MIS_CHECK(ctx, img->width == mask->width && img->height == mask->height, MIS_E_INVALID, "image / mask size mismatch");
     MIS_CHECK(ctx, tl.x >= b->roi.x && tl.y >= b->roi.y && tl.x + img->width <= b->roi.x + b->fw && tl.y + img->height <= b->roi.y + b->fh,
               MIS_E_INVALID, "frame at (%d,%d) %dx%d lies outside the prepared roi", tl.x, tl.y, img->width, img->height);
     MIS_CHECK(ctx, img->stride % 2 == 0, MIS_E_INVALID, "16SC3 stride must be even");
+    return MIS_OK;
+}
+
+extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisImage* mask, MisPoint tl) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "feed before prepare");
+    int rc = feed_check(b, img, mask, tl);
+    if (rc != MIS_OK) return rc;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     DevImage di, dm;
-    int rc;
     if ((rc = mis_dev_image_in(ctx, img, &di)) != MIS_OK) return rc;
-    if ((rc = mis_dev_image_in(ctx, mask, &dm)) != MIS_OK) return rc;
+    if ((rc = mis_dev_image_in(ctx, mask, &dm)) != MIS_OK) { mis_dev_image_release(ctx, &di); return rc; }
     const int w = img->width, h = img->height;
-    if (b->type == MIS_BLEND_MULTI_BAND) rc = feed_multiband(b, di, dm, w, h, tl);
+    if (b->type == MIS_BLEND_MULTI_BAND) rc = feed_multiband_batch(b, img, &di, &dm, &tl, 1);
     else if (b->type == MIS_BLEND_FEATHER) rc = feed_feather(b, di, dm, w, h, tl);
     else {
         hipLaunchKernelGGL(feed_plain_kernel, grid2d(w, h), dim3(256), 0, ctx->stream, (const int16_t*)di.data, di.stride / 2,
@@ -942,6 +1027,35 @@ extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisIma
     }
     int r1 = mis_dev_image_release(ctx, &di), r2 = mis_dev_image_release(ctx, &dm);
     return rc != MIS_OK ? rc : (r1 != MIS_OK ? r1 : r2);
+}
+
+// n feeds in one call: same result as mis_blender_feed(imgs[0]) ... mis_blender_feed(imgs[n - 1]) in that order.  The multi-band
+// blender builds the frames' pyramids together (one launch per level for all frames); the other blenders loop.
+extern "C" int mis_blender_feed_batch(MisBlender* b, const MisImage* imgs, const MisImage* masks, const MisPoint* tls, int n) {
+    if (!b) return MIS_E_INVALID;
+    MisContext* ctx = b->ctx;
+    MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "feed before prepare");
+    MIS_CHECK(ctx, n >= 0 && (n == 0 || (imgs && masks && tls)), MIS_E_INVALID, "null argument");
+    if (n == 0) return MIS_OK;
+    if (b->type != MIS_BLEND_MULTI_BAND) {
+        for (int k = 0; k < n; k++) { int rc = mis_blender_feed(b, &imgs[k], &masks[k], tls[k]); if (rc != MIS_OK) return rc; }
+        return MIS_OK;
+    }
+    int rc = MIS_OK;
+    for (int k = 0; k < n; k++) if ((rc = feed_check(b, &imgs[k], &masks[k], tls[k])) != MIS_OK) return rc;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<DevImage> di(n), dm(n);
+    int got = 0;
+    for (; got < n && rc == MIS_OK; got++) {
+        if ((rc = mis_dev_image_in(ctx, &imgs[got], &di[got])) != MIS_OK) break;
+        if ((rc = mis_dev_image_in(ctx, &masks[got], &dm[got])) != MIS_OK) { mis_dev_image_release(ctx, &di[got]); break; }
+    }
+    if (rc == MIS_OK) rc = feed_multiband_batch(b, imgs, di.data(), dm.data(), tls, n);
+    for (int k = 0; k < got; k++) {
+        const int r1 = mis_dev_image_release(ctx, &di[k]), r2 = mis_dev_image_release(ctx, &dm[k]);
+        if (rc == MIS_OK) rc = r1 != MIS_OK ? r1 : r2;
+    }
+    return rc;
 }
 
 // The compositing loop of main() for n frames in one call (image_stitching.cpp:1154-1164 + :1218 per frame): fused warp
@@ -953,23 +1067,26 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
     MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "compose before prepare");
     MIS_CHECK(ctx, frames && Ks && Rs && rois && n >= 0, MIS_E_INVALID, "null argument");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < n; i++) {
+    // all warps into pool blocks of their own, then one batched feed (the frames' pyramids are built together)
+    std::vector<MisImage> imgs(n), msks(n);
+    std::vector<MisPoint> tls(n);
+    std::vector<std::pair<void*, size_t>> blocks;
+    int rc = MIS_OK;
+    for (int i = 0; i < n && rc == MIS_OK; i++) {
         const MisRect& r = rois[i];
-        MIS_CHECK(ctx, r.width > 0 && r.height > 0, MIS_E_INVALID, "frame %d: empty warp roi", i);
+        if (!(r.width > 0 && r.height > 0)) { rc = mis_set_error(ctx, MIS_E_INVALID, "frame %d: empty warp roi", i); break; }
         const size_t ipitch = mis_align_up((size_t)r.width * 6, 256), mpitch = mis_align_up((size_t)r.width, 256);
         const size_t ibytes = ipitch * r.height, mbytes = mpitch * r.height;
         void* blk = nullptr; size_t got = 0;
-        int rc = mis_pool_alloc(ctx, ibytes + mbytes, &blk, &got);
-        if (rc != MIS_OK) return rc;
-        MisImage img{blk, r.width, r.height, 3, ipitch, MIS_S16, MIS_MEM_DEVICE};
-        MisImage msk{(uint8_t*)blk + ibytes, r.width, r.height, 1, mpitch, MIS_U8, MIS_MEM_DEVICE};
-        MisPoint tl;
-        rc = mis_warp_spherical_fused_roi(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &r, &img, &msk, &tl);
-        if (rc == MIS_OK) rc = mis_blender_feed(b, &img, &msk, tl);
-        mis_pool_free(ctx, blk, got);   // stream-ordered reuse: the next frame's warp is enqueued behind this feed
-        if (rc != MIS_OK) return rc;
+        if ((rc = mis_pool_alloc(ctx, ibytes + mbytes, &blk, &got)) != MIS_OK) break;
+        blocks.emplace_back(blk, got);
+        imgs[i] = MisImage{blk, r.width, r.height, 3, ipitch, MIS_S16, MIS_MEM_DEVICE};
+        msks[i] = MisImage{(uint8_t*)blk + ibytes, r.width, r.height, 1, mpitch, MIS_U8, MIS_MEM_DEVICE};
+        rc = mis_warp_spherical_fused_roi(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &r, &imgs[i], &msks[i], &tls[i]);
     }
-    return MIS_OK;
+    if (rc == MIS_OK) rc = mis_blender_feed_batch(b, imgs.data(), msks.data(), tls.data(), n);
+    for (auto& bl : blocks) mis_pool_free(ctx, bl.first, bl.second);   // stream-ordered reuse
+    return rc;
 }
 
 // blend() restricted to the panorama columns x0 .. x1 - 1 (level 0, relative to the padded roi): normalise + collapse run on

@@ -378,8 +378,7 @@ struct TileTrig {
     float4 cs;      // {sin u0, cos u0, sin u1, cos u1}
     float4 rt[LROWS];   // per row {sin v, m1 cos v, m4 cos v, m7 cos v}
 };
-__device__ __forceinline__ void tile_trig(const WarpArgs& a, const float* __restrict__ tab, int tile, int ntx, int lane, TileTrig& g) {
-    const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
+__device__ __forceinline__ void tile_trig(const WarpArgs& a, const float* __restrict__ tab, int tx0, int ty0, int lane, TileTrig& g) {
     const int gxr = tx0 + 2 * (lane & 15), gy0 = ty0 + LROWS * (lane >> 4);
     const int gx = gxr < a.dw ? gxr : ((a.dw - 1) & ~1);
     g.cs = *reinterpret_cast<const float4*>(tab + 2 * gx);
@@ -388,8 +387,7 @@ __device__ __forceinline__ void tile_trig(const WarpArgs& a, const float* __rest
     for (int i = 0; i < LROWS; i++) g.rt[i] = rowtab[min(gy0 + i, a.dh - 1)];  // rows past the roi shadow the last one
 }
 
-__device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, int tile, int ntx, int lane, TileState& t) {
-    const int tx0 = (tile % ntx) * FT_W, ty0 = (tile / ntx) * FT_H;
+__device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, int tx0, int ty0, int lane, TileState& t) {
     const int lx = lane & 15, ly = lane >> 4;
     const int gxr = tx0 + 2 * lx, gy0 = ty0 + LROWS * ly;
     t.col_ok = gxr < a.dw; t.two = gxr + 1 < a.dw;
@@ -551,26 +549,56 @@ __device__ unsigned long long g_warp_stamps[16384 * 8];
 #define WV_TILE_WAVES 2
 #endif
 constexpr int TILE_WAVES = WV_TILE_WAVES;
+#ifndef WV_ORDER
+#define WV_ORDER 2
+#endif
+#ifndef WV_CH_W
+#define WV_CH_W 4
+#endif
+#ifndef WV_CH_H
+#define WV_CH_H 4
+#endif
+constexpr int CH_W = WV_CH_W, CH_H = WV_CH_H;   // chunk of tiles owned by one XCD (CH_W a multiple of TILE_WAVES)
+static_assert(CH_W % TILE_WAVES == 0, "chunk width must be a whole number of workgroups");
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
     const int ntx = (a.dw + FT_W - 1) / FT_W, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t* stage = stage_all[wave];
-    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2, so XCD j
-    // takes the j-th contiguous eighth of the raster-ordered tiles: neighbouring tiles, which share source rows and
-    // the 16-byte pieces at their box edges, hit the same L2 (PMC: L2 -> fabric fetch 64 MB -> 26 MB per 4K frame,
-    // = the frame itself; ~1 % slower than plain raster order, whose re-fetches are served by the Infinity Cache).
+    // Tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  The tile grid is cut into
+    // chunks of CH_W x CH_H tiles (CH_W / TILE_WAVES x CH_H workgroups); chunk k belongs to XCD k % 8 and an XCD walks its chunks in
+    // raster order: neighbouring tiles, which share source rows and the 16-byte pieces at their box edges, hit the same L2, and
+    // every XCD gets the same mix of cheap interior tiles and expensive border tiles (a contiguous eighth per XCD left the two
+    // XCDs that own the top and bottom bands 7 % more work: they finished 2.7 us after the others, tools/warp_stamps.py).
+    const int nty = (a.dh + FT_H - 1) / FT_H;
+#if WV_ORDER == 0
     const int nwg = gridDim.x, xcd = blockIdx.x & 7;
     const int wg = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3);
     const int tile = wg * TILE_WAVES + wave;
     if (tile >= ntiles) return;
+    const int tx = tile % ntx, ty = tile / ntx;
+#elif WV_ORDER == 1
+    const int tile = blockIdx.x * TILE_WAVES + wave;
+    if (tile >= ntiles) return;
+    const int tx = tile % ntx, ty = tile / ntx;
+#else
+    constexpr int WG_X = CH_W / TILE_WAVES, WG_PER_CHUNK = WG_X * CH_H;
+    const int nchx = (ntx + CH_W - 1) / CH_W;
+    const int i = blockIdx.x >> 3;
+    const int chunk = (i / WG_PER_CHUNK) * 8 + (blockIdx.x & 7), within = i % WG_PER_CHUNK;
+    const int chy = chunk / nchx, chx = chunk - chy * nchx;
+    const int tx = chx * CH_W + (within % WG_X) * TILE_WAVES + wave, ty = chy * CH_H + within / WG_X;
+    if (tx >= ntx || ty >= nty) return;
+    (void)ntiles;
+#endif
+    const int tx0 = tx * FT_W, ty0 = ty * FT_H;
     TileState cur;
     TileTrig trig;
 #ifdef WV_STAMPS   // diagnostics build (tools/warp_stamps.py): per-wave phase time stamps, shader clock and wall clock
     const unsigned long long r0 = wall_clock64(), s0 = __builtin_readcyclecounter();
-    tile_trig(a, tab, tile, ntx, lane, trig);
+    tile_trig(a, tab, tx0, ty0, lane, trig);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long s1 = __builtin_readcyclecounter();
-    tile_map(a, trig, tile, ntx, lane, cur);
+    tile_map(a, trig, tx0, ty0, lane, cur);
     const unsigned long long s2 = __builtin_readcyclecounter();
     tile_stage(a, cur, stage, lane);
     const unsigned long long s3 = __builtin_readcyclecounter();
@@ -579,13 +607,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const unsigned long long s4 = __builtin_readcyclecounter();
     tile_sample_store(a, cur, stage);
     const unsigned long long s5 = __builtin_readcyclecounter();
-    if (lane == 0 && tile < 16384) {
-        unsigned long long* o = g_warp_stamps + 8 * tile;
+    if (lane == 0 && ty * ntx + tx < 16384) {
+        unsigned long long* o = g_warp_stamps + 8 * (ty * ntx + tx);
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = r0; o[7] = wall_clock64();
     }
 #else
-    tile_trig(a, tab, tile, ntx, lane, trig);
-    tile_map(a, trig, tile, ntx, lane, cur);
+    tile_trig(a, tab, tx0, ty0, lane, trig);
+    tile_map(a, trig, tx0, ty0, lane, cur);
     tile_stage(a, cur, stage, lane);                       // asynchronous global -> LDS copies ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... have landed
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -733,6 +761,13 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
     float* tab = (float*)ctx->stage;
     hipLaunchKernelGGL(warp_trig_kernel, dim3((trig_cols(a.dw) + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
     const int ntiles = ((a.dw + FT_W - 1) / FT_W) * ((a.dh + FT_H - 1) / FT_H);
+#if WV_ORDER == 2
+    // whole chunks, a multiple of 8 of them (workgroups past the tile grid return at once)
+    const int nchunks = (((a.dw + FT_W - 1) / FT_W + CH_W - 1) / CH_W) * (((a.dh + FT_H - 1) / FT_H + CH_H - 1) / CH_H);
+    const int nwg = ((nchunks + 7) / 8) * 8 * (CH_W / TILE_WAVES) * CH_H;
+#else
+    const int nwg = (ntiles + TILE_WAVES - 1) / TILE_WAVES;
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (avg_us) {
         MIS_HIP(ctx, hipEventCreate(&e0));
@@ -740,7 +775,7 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
         MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
     for (int rep = 0; rep < repeats; rep++)
-        hipLaunchKernelGGL(warp_fused_kernel, dim3((ntiles + TILE_WAVES - 1) / TILE_WAVES), dim3(64 * TILE_WAVES), 0, ctx->stream, a, (const float*)tab, ntiles);
+        hipLaunchKernelGGL(warp_fused_kernel, dim3(nwg), dim3(64 * TILE_WAVES), 0, ctx->stream, a, (const float*)tab, ntiles);
     if (avg_us) {
         float ms = 0.f;
         MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));

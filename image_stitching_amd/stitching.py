@@ -380,6 +380,14 @@ class Blender:
         i, m = as_image(img), as_image(mask)
         self.ctx.check(self.ctx.lib.mis_blender_feed(self.h, C.byref(i), C.byref(m), capi.MisPoint(int(tl[0]), int(tl[1]))))
 
+    def feed_batch(self, imgs, masks, tls):
+        """n feeds in one call (mis_blender_feed_batch): the result of feed(imgs[0], ...) ... feed(imgs[n - 1], ...) in that order."""
+        n = len(imgs)
+        im = (capi.MisImage * n)(*[as_image(i) for i in imgs])
+        mk = (capi.MisImage * n)(*[as_image(m) for m in masks])
+        ts = (capi.MisPoint * n)(*[capi.MisPoint(int(t[0]), int(t[1])) for t in tls])
+        self.ctx.check(self.ctx.lib.mis_blender_feed_batch(self.h, im, mk, ts, n))
+
     def blend(self):
         w, h = self._size
         dst = _empty_image(self.ctx, h, w, 3, torch.int16)

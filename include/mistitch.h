@@ -276,6 +276,10 @@ int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const MisSize* s
 int mis_blender_num_bands(const MisBlender* b);
 /* blender->feed(img_warped_s [16SC3], mask_warped [8U], corners[i]) -- replaces :1218 */
 int mis_blender_feed(MisBlender* b, const MisImage* img_s16x3, const MisImage* mask_u8, MisPoint tl);
+/* the feeds of n frames of the loop :1086-1220 in one call: the result of mis_blender_feed(imgs[0], ...) ... mis_blender_feed(imgs[n-1], ...)
+ * in that order, bit for bit; the multi-band blender builds the frames' Gaussian pyramids together (one launch per level for all
+ * frames instead of one per level and frame) before it accumulates the Laplacians frame by frame */
+int mis_blender_feed_batch(MisBlender* b, const MisImage* imgs_s16x3, const MisImage* masks_u8, const MisPoint* tls, int n);
 /* blender->blend(result, result_mask) -- replaces :1225 */
 int mis_blender_blend(MisBlender* b, MisImage* dst_s16x3, MisImage* dst_mask);
 /* blend() for the panorama columns x0 .. x1 - 1 only (relative to the result roi; x1 is clipped to its width): the same values

@@ -151,3 +151,39 @@ def test_warp_then_blend_4k_pair_bit_exact(ctx, oracle_mod):
     _, bands, _ = oracle_mod.blend_config(oracle_mod.BLEND_MULTI_BAND, 5.0, x1 - x0, y1 - y0)
     pano = _run_both(ctx, oracle_mod, oracle_mod.BLEND_MULTI_BAND, items, bands=bands, check_levels=True)
     assert pano.shape[1] > 3840 and bands >= 6
+
+
+@pytest.mark.parametrize("n,bands", [(3, 4), (19, 3), (5, 0)])
+def test_feed_batch_equals_single_feeds(ctx, oracle_mod, n, bands):
+    """mis_blender_feed_batch (the frames' pyramids built together, > FB_MAX frames in two groups, frames of different sizes, one
+    with values outside 0..255) leaves every accumulator level and the blend identical to n single feeds -- and to the oracle."""
+    import torch
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(33 + n)
+    frames = _frames(rng, n, 150, 110)
+    wide = frames[1][0].copy(); wide[20:50, 30:70] = rng.integers(-5000, 5000, (30, 40, 3)).astype(np.int16)
+    frames[1] = (wide, frames[1][1], frames[1][2])
+    corners = [f[2] for f in frames]
+    sizes = [(f[0].shape[1], f[0].shape[0]) for f in frames]
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda(), f[2]) for f in frames]
+    single = isa.MultiBandBlender(ctx, bands); single.prepare(corners, sizes)
+    for img, mask, tl in dev:
+        single.feed(img, mask, tl)
+    batch = isa.MultiBandBlender(ctx, bands); batch.prepare(corners, sizes)
+    batch.feed_batch([d[0] for d in dev], [d[1] for d in dev], [d[2] for d in dev])
+    assert batch.numBands() == single.numBands()
+    for l in range(single.numBands() + 1):
+        sl, sw = single.level(l)
+        bl, bw = batch.level(l)
+        assert np.array_equal(bl, sl), "laplacian level %d" % l
+        assert np.array_equal(bw.view(np.uint32), sw.view(np.uint32)), "weight level %d" % l
+    s_out, s_mask = single.blend()
+    b_out, b_mask = batch.blend()
+    ctx.synchronize()
+    assert torch.equal(b_out, s_out) and torch.equal(b_mask, s_mask)
+    ob = oracle_mod.Blender(oracle_mod.BLEND_MULTI_BAND, bands, 0.0)
+    ob.prepare(corners, sizes)
+    for img, mask, tl in frames:
+        ob.feed(img, mask, tl)
+    oref, omask = ob.blend()
+    assert np.array_equal(b_out.cpu().numpy(), oref) and np.array_equal(b_mask.cpu().numpy(), omask)

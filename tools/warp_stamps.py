@@ -34,3 +34,21 @@ for tq in (2, 5, 8, 11, 14, 17, 20, 23):
     print("  t=%2d us: resident waves %d" % (tq, int(((start <= tq) & (end > tq)).sum())))
 st = np.sort(s[:, 0] - t0)
 print("wave start times: p10 %d p25 %d p50 %d p75 %d p90 %d max %d" % tuple(np.percentile(st, [10, 25, 50, 75, 90, 100])))
+# per-XCD balance (tile -> workgroup -> XCD as in warp_fused_kernel: XCD j owns the j-th contiguous eighth of the workgroups)
+TW = int(os.environ.get("WV_TILE_WAVES", "2"))
+nwg = (n + TW - 1) // TW
+wg = np.arange(n) // TW
+q, rem = nwg >> 3, nwg & 7
+bounds = [j * q + min(j, rem) for j in range(9)]
+xcd = np.searchsorted(np.array(bounds[1:]), wg, side="right")
+for j in range(8):
+    m = xcd == j
+    print("  xcd %d: tiles %5d  first start %6.2f  last end %6.2f us  sum lifetime %9.0f us  mean lifetime %5.2f us  p50 start %5.2f" %
+          (j, m.sum(), start[m].min(), end[m].max(), (end[m] - start[m]).sum(), (end[m] - start[m]).mean(), np.median(start[m])))
+late = start > 17
+print("tiles started after 17 us: %d, mean lifetime %.2f us; before: %.2f us" % (late.sum(), (end - start)[late].mean(), (end - start)[~late].mean()))
+ntx = (roi[2] + 31) // 32
+trow = np.arange(n) // ntx
+for r0 in range(0, trow.max() + 1, max(1, (trow.max() + 1) // 12)):
+    m = (trow >= r0) & (trow < r0 + max(1, (trow.max() + 1) // 12))
+    print("  tile rows %3d..: mean lifetime %5.2f us  mean start %5.2f  max end %5.2f" % (r0, (end - start)[m].mean(), start[m].mean(), end[m].max()))
