@@ -32,6 +32,7 @@ struct MisBlender {
     void* pano_mem = nullptr;
     size_t pano_bytes = 0;  // capacity kept across prepare() calls (grow-only)
     bool prepared = false;
+    bool fresh = false;       // the pyramids are all zero (nothing fed or added since prepare())
     // grow-only scratch of one feed: Gaussian pyramids of the frame (levels 1..nb) and of its weights
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -442,23 +443,11 @@ __global__ __launch_bounds__(256) void laplace_accumulate_kernel(FrameView v, co
     dwgt[o] += w;
 }
 
-// ---- the small levels of a feed in two launches ----
+// ---- the small levels of the frames' pyramids in one launch ----
 // From some level on a frame's pyramid has a few thousand pixels and every per-level launch costs more in launch-to-launch
-// latency than in work (a 4K frame at 8 bands: 15 launches of ~6 us for levels 4..8).  feed_tail_build_kernel builds all
-// the remaining Gaussian levels in ONE workgroup (a level depends on the previous one: __syncthreads between them;
-// the data goes through global memory, which a workgroup sees coherently), feed_accumulate_kernel adds the
-// Laplacians of all those levels to the panorama in one grid.  Arithmetic: that of the per-level kernels.
-struct FeedTail {
-    int first, nb;                                    // levels first + 1 .. nb are built by feed_tail_build_kernel (first >= 1; first > nb: none)
-    int acc_first;                                    // levels acc_first .. nb are accumulated by feed_accumulate_kernel
-    int tw[MIS_MAX_BANDS + 1], th[MIS_MAX_BANDS + 1]; // tile size per level
-    int16_t* G[MIS_MAX_BANDS + 1];                    // Gaussian levels of the frame (scratch), G[first] already built
-    float* W[MIS_MAX_BANDS + 1];
-    int16_t* lap[MIS_MAX_BANDS + 1];                  // panorama pyramids
-    float* wgt[MIS_MAX_BANDS + 1];
-    int pw[MIS_MAX_BANDS + 1], x_tl[MIS_MAX_BANDS + 1], y_tl[MIS_MAX_BANDS + 1];
-    int blk_off[MIS_MAX_BANDS + 2];                   // accumulate grid: first block of every level
-};
+// latency than in work.  feed_tail_build_kernel builds all the remaining Gaussian levels of a frame in ONE workgroup (a level
+// depends on the previous one: __syncthreads between them; the data goes through global memory, which a workgroup sees
+// coherently), one workgroup per frame of the batch.  Arithmetic: that of the per-level kernels.
 __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedBatch fb, FeedLayout lay) {   // one workgroup per frame
     const int f = blockIdx.x;
     uint8_t* base = fb.base[f];
@@ -494,96 +483,168 @@ __global__ __launch_bounds__(1024) void feed_tail_build_kernel(FeedBatch fb, Fee
         __syncthreads();
     }
 }
-// All levels of a feed in one grid (level 0 reads the frame view).  Below the last level a thread owns a 2 x 2 block (tile sizes
-// are even there): the four pixels share pyrUp's 3 x 3 coarse neighbourhood, and a row of the block is 12 contiguous bytes of
-// 16SC3 + 8 of f32 in the panorama pyramids -- read, modified and written as whole dwords (even level widths).  Pixels whose
-// weight is exactly 0 contribute nothing (`x + (short)(v * 0) = x`, `w + 0 = w`): blocks of four zero weights are skipped.
-__global__ __launch_bounds__(256) void feed_accumulate_kernel(FeedTail t, FrameView v, int view_ok, int blk_base) {
-    const int bid = (int)blockIdx.x + blk_base;      // block index in the grid over all levels (a launch may cover a part of it)
-    int l = t.acc_first;
-    while (l < t.nb && bid >= t.blk_off[l + 1]) l++;
-    const int tw = t.tw[l], th = t.th[l];
-    const int i = (bid - t.blk_off[l]) * 256 + threadIdx.x;
-    if (l < t.nb) {
-        const int cw = t.tw[l + 1], ch = t.th[l + 1];
-        if (i >= cw * ch) return;
-        const int Y = i / cw, X = i - Y * cw;
-        const bool view = l == 0;
-        float w[4];
-        int px[4][3];
-        // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
-        const int ix0 = 2 * X - v.left, iy0 = 2 * Y - v.top;
-        if (view) {
-            // weights = mask / 255 inside the image, 0 outside (copyMakeBorder CONSTANT)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int ix = ix0 + (k & 1), iy = iy0 + (k >> 1);
-                w[k] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)v.mask[(unsigned)iy * (unsigned)v.mstride + (unsigned)ix] * (float)(1. / 255.) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const float2 ww = *reinterpret_cast<const float2*>(t.W[l] + (size_t)(2 * Y + r) * tw + 2 * X);   // tw even, 2 X even
-                w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
-            }
-        }
-        if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) return;   // exact no-op contributions
-        int up[4][3];
-        pyr_up_block(t.G[l + 1], cw, ch, X, Y, (cw & 1) == 0, up);
-        if (view) {
-            // a pixel with a non-zero weight lies inside the image; the others contribute nothing, so their (reflected) values
-            // are never needed: clamp their coordinates instead of reflecting them
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int ix = min(max(ix0 + (k & 1), 0), v.w - 1), iy = min(max(iy0 + (k >> 1), 0), v.h - 1);
-                load_px3(v.img + (size_t)iy * v.istride, ix, view_ok && (iy + 1 < v.h || v.istride >= (size_t)3 * v.w + 1), px[k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) load_px3(t.G[l] + (size_t)(2 * Y + (k >> 1)) * tw * 3, 2 * X + (k & 1), true, px[k]);
-        }
-        const int pw = t.pw[l];
+// ---- the Laplacians of a batch of frames into the panorama pyramids: gather, not scatter ----
+// One grid over the bounding box of the batch's tiles in the PANORAMA pyramids, all levels.  A thread owns a 2 x 2 block of a
+// panorama level (levels < nb; tile corners are multiples of 2^nb, so panorama blocks are tile blocks) and walks the frames of
+// the batch in feed order: Laplacian = G_l - pyrUp(G_{l+1}) (saturating; the four pixels share pyrUp's 3 x 3 coarse
+// neighbourhood), times the weight, added to the block's sums in registers -- 16-bit sums wrap (any order gives the same bits),
+// the f32 weight sums are formed in frame order ((p + w_0) + w_1) + ..., exactly as n single feeds would.  The block is then
+// written ONCE: per frame-pixel read-modify-write traffic of the panorama (20 B, the bulk of a scatter feed: 146 of 318 MB per
+// 4K frame) becomes one 10 B write per panorama pixel -- or one read + one write when the pyramids are not known to be zero
+// (`fresh` = nothing was fed since prepare()).  Pixels whose weight is exactly 0 contribute nothing (`x + (short)(v * 0) = x`,
+// `w + 0 = w`): a block nobody touches is neither read nor written.  A row of a block is 12 contiguous bytes of 16SC3 + 8 of f32.
+struct FeedGather {
+    int n, nb, fresh;
+    int bx0, by0, bw, bh;                             // bounding box of the batch's tiles, level 0, relative to the padded roi (multiples of 2^nb)
+    int blk_off[MIS_MAX_BANDS + 2];                   // first workgroup of every level
+    int16_t* lap[MIS_MAX_BANDS + 1];                  // panorama pyramids
+    float* wgt[MIS_MAX_BANDS + 1];
+    int pw[MIS_MAX_BANDS + 1];
+    uint8_t* base[FB_MAX];                            // per frame: scratch region (FeedLayout), level-0 view, tile corner, 8-byte pixel loads allowed
+    FrameView v[FB_MAX];
+    int x_tl[FB_MAX], y_tl[FB_MAX], view_ok[FB_MAX];
+};
+constexpr int FG_BX = 32, FG_BY = 8;                  // blocks per workgroup (64 x 16 pixels of the level)
+__global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayout lay) {
+    const int bid = (int)blockIdx.x;
+    int l = 0;
+    while (l < a.nb && bid >= a.blk_off[l + 1]) l++;
+    const int rb = bid - a.blk_off[l];
+    const int pw = a.pw[l];
+    if (l < a.nb) {
+        const int gbw = a.bw >> (l + 1), gbh = a.bh >> (l + 1);                  // the box in blocks
+        const int nbx = (gbw + FG_BX - 1) / FG_BX;
+        const int wy = rb / nbx, wx = rb - wy * nbx;
+        const int X = wx * FG_BX + (int)(threadIdx.x & (FG_BX - 1)), Y = wy * FG_BY + (int)(threadIdx.x / FG_BX);
+        const bool live = X < gbw && Y < gbh;
+        const int rx0 = (a.bx0 >> l) + 2 * FG_BX * wx, ry0 = (a.by0 >> l) + 2 * FG_BY * wy;   // the workgroup's region of the level
+        const int px0 = (a.bx0 >> l) + 2 * X, py0 = (a.by0 >> l) + 2 * Y;                       // the thread's block
+        int acc[2][6];
+        float accw[2][2];
+        bool have = false;
+        uint3* dp[2]; float2* wp[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const float w0 = w[2 * r], w1 = w[2 * r + 1];
-            if (w0 == 0.f && w1 == 0.f) continue;
-            const size_t o = (size_t)(t.y_tl[l] + 2 * Y + r) * pw + (t.x_tl[l] + 2 * X);
-            int add[6];
+            const size_t o = (size_t)(py0 + r) * pw + px0;       // pw and px0 even: the six shorts start on a dword
+            dp[r] = reinterpret_cast<uint3*>(a.lap[l] + o * 3); wp[r] = reinterpret_cast<float2*>(a.wgt[l] + o);
+        }
+        for (int k = 0; k < a.n; k++) {
+            const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
+            const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
+            if (rx0 >= xt + tw || rx0 + 2 * FG_BX <= xt || ry0 >= yt + th || ry0 + 2 * FG_BY <= yt) continue;   // workgroup-uniform
+            const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
+            if (!live || tx < 0 || tx >= tw || ty < 0 || ty >= th) continue;
+            const FrameView& v = a.v[k];
+            const int16_t* Gl = (const int16_t*)(a.base[k] + lay.goff[l]);
+            const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
+            const bool view = l == 0;
+            float w[4];
+            // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
+            const int ix0 = tx - v.left, iy0 = ty - v.top;
+            if (view) {
+                // weights = mask / 255 inside the image, 0 outside (copyMakeBorder CONSTANT)
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) add[3 * q + c] = (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * w[2 * r + q]);
-            if ((pw & 1) == 0) {   // x_tl + 2 X is even: the six shorts start on a dword
-                uint3* dp = reinterpret_cast<uint3*>(t.lap[l] + o * 3);
-                uint3 d = *dp;
-                d.x = ((d.x + (unsigned)add[0]) & 0xffffu) | ((d.x + ((unsigned)add[1] << 16)) & 0xffff0000u);
-                d.y = ((d.y + (unsigned)add[2]) & 0xffffu) | ((d.y + ((unsigned)add[3] << 16)) & 0xffff0000u);
-                d.z = ((d.z + (unsigned)add[4]) & 0xffffu) | ((d.z + ((unsigned)add[5] << 16)) & 0xffff0000u);
-                *dp = d;
-                float2* wp = reinterpret_cast<float2*>(t.wgt[l] + o);
-                float2 ws = *wp;
-                ws.x += w0; ws.y += w1;
-                *wp = ws;
+                for (int q = 0; q < 4; q++) {
+                    const int ix = ix0 + (q & 1), iy = iy0 + (q >> 1);
+                    w[q] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)v.mask[(unsigned)iy * (unsigned)v.mstride + (unsigned)ix] * (float)(1. / 255.) : 0.f;
+                }
             } else {
-                int16_t* d = t.lap[l] + o * 3;
 #pragma unroll
-                for (int q = 0; q < 6; q++) d[q] = (int16_t)(d[q] + add[q]);
-                t.wgt[l][o] += w0; t.wgt[l][o + 1] += w1;
+                for (int r = 0; r < 2; r++) {
+                    const float2 ww = *reinterpret_cast<const float2*>(Wl + (size_t)(ty + r) * tw + tx);   // tw and tx even
+                    w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
+                }
             }
+            if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;   // exact no-op contributions
+            const int cw = (tw + 1) >> 1, ch = (th + 1) >> 1;
+            int up[4][3], px[4][3];
+            pyr_up_block((const int16_t*)(a.base[k] + lay.goff[l + 1]), cw, ch, tx >> 1, ty >> 1, (cw & 1) == 0, up);
+            if (view) {
+                // a pixel with a non-zero weight lies inside the image; the others contribute nothing, so their (reflected) values
+                // are never needed: clamp their coordinates instead of reflecting them
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ix = min(max(ix0 + (q & 1), 0), v.w - 1), iy = min(max(iy0 + (q >> 1), 0), v.h - 1);
+                    load_px3(v.img + (size_t)iy * v.istride, ix, a.view_ok[k] && (iy + 1 < v.h || v.istride >= (size_t)3 * v.w + 1), px[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) load_px3(Gl + (size_t)(ty + (q >> 1)) * tw * 3, tx + (q & 1), true, px[q]);
+            }
+            if (!have) {
+                have = true;
+                if (a.fresh) {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) acc[r][q] = 0;
+                        accw[r][0] = accw[r][1] = 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint3 d = *dp[r];
+                        acc[r][0] = (int)(d.x & 0xffffu); acc[r][1] = (int)(d.x >> 16); acc[r][2] = (int)(d.y & 0xffffu);
+                        acc[r][3] = (int)(d.y >> 16); acc[r][4] = (int)(d.z & 0xffffu); acc[r][5] = (int)(d.z >> 16);
+                        const float2 ws = *wp[r];
+                        accw[r][0] = ws.x; accw[r][1] = ws.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const float wq = w[2 * r + q];
+                    if (wq == 0.f) continue;        // `+ (short)(v * 0)` and `+ 0.f`: no-ops (also keeps a -0.f out of the sums)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[r][3 * q + c] += (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * wq);
+                    accw[r][q] += wq;
+                }
+            }
+        }
+        if (!have) return;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            uint3 d;
+            d.x = ((unsigned)acc[r][0] & 0xffffu) | ((unsigned)acc[r][1] << 16);
+            d.y = ((unsigned)acc[r][2] & 0xffffu) | ((unsigned)acc[r][3] << 16);
+            d.z = ((unsigned)acc[r][4] & 0xffffu) | ((unsigned)acc[r][5] << 16);
+            *dp[r] = d;
+            *wp[r] = make_float2(accw[r][0], accw[r][1]);
         }
         return;
     }
-    if (i >= tw * th) return;
-    const int y = i / tw, x = i - y * tw;
-    const float w = t.W[l][i];
-    if (w == 0.f) return;  // exact no-op contribution
-    const int16_t* p = t.G[l] + (size_t)i * 3;
-    const size_t o = (size_t)(t.y_tl[l] + y) * t.pw[l] + (t.x_tl[l] + x);
-    int16_t* d = t.lap[l] + o * 3;
-    d[0] = (int16_t)(d[0] + (int16_t)((float)p[0] * w));
-    d[1] = (int16_t)(d[1] + (int16_t)((float)p[1] * w));
-    d[2] = (int16_t)(d[2] + (int16_t)((float)p[2] * w));
-    t.wgt[l][o] += w;
+    // the last level: one pixel per thread, no pyrUp
+    const int gw = a.bw >> l, gh = a.bh >> l;
+    const int i = rb * 256 + (int)threadIdx.x;
+    if (i >= gw * gh) return;
+    const int y = i / gw, x = i - y * gw;
+    const int pxx = (a.bx0 >> l) + x, pyy = (a.by0 >> l) + y;
+    const size_t o = (size_t)pyy * pw + pxx;
+    int16_t* d = a.lap[l] + o * 3;
+    int acc3[3];
+    float accw1 = 0.f;
+    bool have = false;
+    for (int k = 0; k < a.n; k++) {
+        const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
+        const int tx = pxx - (a.x_tl[k] >> l), ty = pyy - (a.y_tl[k] >> l);
+        if (tx < 0 || tx >= tw || ty < 0 || ty >= th) continue;
+        const size_t e = (size_t)ty * tw + tx;
+        const float w = ((const float*)(a.base[k] + lay.woff[l]))[e];
+        if (w == 0.f) continue;  // exact no-op contribution
+        const int16_t* p = (const int16_t*)(a.base[k] + lay.goff[l]) + e * 3;
+        if (!have) {
+            have = true;
+            if (a.fresh) { acc3[0] = acc3[1] = acc3[2] = 0; accw1 = 0.f; }
+            else { acc3[0] = d[0]; acc3[1] = d[1]; acc3[2] = d[2]; accw1 = a.wgt[l][o]; }
+        }
+        acc3[0] += (int)(int16_t)((float)p[0] * w); acc3[1] += (int)(int16_t)((float)p[1] * w); acc3[2] += (int)(int16_t)((float)p[2] * w);
+        accw1 += w;
+    }
+    if (!have) return;
+    d[0] = (int16_t)acc3[0]; d[1] = (int16_t)acc3[1]; d[2] = (int16_t)acc3[2];
+    a.wgt[l][o] = accw1;
 }
 
 // ---- blend(): normalise by the weight sum, collapse the pyramid, emit the final image + mask ----
@@ -818,6 +879,7 @@ int feed_multiband_batch(MisBlender* b, const MisImage* imgs, const DevImage* di
     }
     dim3 blk(256);
     if (nb == 0) {
+        b->fresh = false;
         for (int k = 0; k < n; k++)
             hipLaunchKernelGGL((laplace_accumulate_kernel<true, true>), grid2d(fr[k].v.tw, fr[k].v.th), blk, 0, ctx->stream, fr[k].v, nullptr, nullptr, fr[k].v.tw, fr[k].v.th,
                                (const int16_t*)nullptr, 0, 0, b->lap[0], b->wgt[0], b->lw[0], fr[k].x_tl, fr[k].y_tl);
@@ -870,23 +932,29 @@ int feed_multiband_batch(MisBlender* b, const MisImage* imgs, const DevImage* di
         }
         if (first <= nb) hipLaunchKernelGGL(feed_tail_build_kernel, dim3(ng), dim3(1024), 0, ctx->stream, fb, lay);
     }
-    // every level of a frame is accumulated by one multi-level grid (feed_accumulate_kernel; level 0 reads the frame view)
-    for (int k = 0; k < n; k++) {
-        uint8_t* base = (uint8_t*)b->scratch + (size_t)k * region;
-        FeedTail ft;
-        ft.first = first; ft.nb = nb; ft.acc_first = 0;
-        int x_tl = fr[k].x_tl, y_tl = fr[k].y_tl, tw = fr[k].v.tw, th = fr[k].v.th;
-        for (int i = 0; i <= nb; i++) {
-            ft.tw[i] = tw; ft.th[i] = th;
-            ft.G[i] = i ? (int16_t*)(base + lay.goff[i]) : nullptr; ft.W[i] = i ? (float*)(base + lay.woff[i]) : nullptr;
-            ft.lap[i] = b->lap[i]; ft.wgt[i] = b->wgt[i]; ft.pw[i] = b->lw[i];
-            ft.x_tl[i] = x_tl; ft.y_tl[i] = y_tl;
-            x_tl /= 2; y_tl /= 2; tw = (tw + 1) / 2; th = (th + 1) / 2;
+    // the Laplacians of every group of frames are gathered into the panorama pyramids by one grid over the group's bounding box
+    for (int g0 = 0; g0 < n; g0 += FB_MAX) {
+        const int ng = std::min(FB_MAX, n - g0);
+        FeedGather ga;
+        ga.n = ng; ga.nb = nb; ga.fresh = b->fresh ? 1 : 0;
+        int x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
+        for (int k = 0; k < FB_MAX; k++) {
+            const Frame& f = fr[g0 + (k < ng ? k : 0)];
+            ga.base[k] = (uint8_t*)b->scratch + (size_t)(g0 + (k < ng ? k : 0)) * region;
+            ga.v[k] = f.v; ga.x_tl[k] = f.x_tl; ga.y_tl[k] = f.y_tl; ga.view_ok[k] = f.view_ok;
+            if (k < ng) { x0 = std::min(x0, f.x_tl); y0 = std::min(y0, f.y_tl); x1 = std::max(x1, f.x_tl + f.v.tw); y1 = std::max(y1, f.y_tl + f.v.th); }
         }
+        ga.bx0 = x0; ga.by0 = y0; ga.bw = x1 - x0; ga.bh = y1 - y0;
         int nblk = 0;
-        for (int i = 0; i <= nb; i++) { ft.blk_off[i] = nblk; nblk += ((i < nb ? ft.tw[i + 1] * ft.th[i + 1] : ft.tw[i] * ft.th[i]) + 255) / 256; }
-        ft.blk_off[nb + 1] = nblk;
-        hipLaunchKernelGGL(feed_accumulate_kernel, dim3(nblk), blk, 0, ctx->stream, ft, fr[k].v, fr[k].view_ok, 0);
+        for (int i = 0; i <= nb; i++) {
+            ga.lap[i] = b->lap[i]; ga.wgt[i] = b->wgt[i]; ga.pw[i] = b->lw[i];
+            ga.blk_off[i] = nblk;
+            if (i < nb) nblk += (((ga.bw >> (i + 1)) + FG_BX - 1) / FG_BX) * (((ga.bh >> (i + 1)) + FG_BY - 1) / FG_BY);
+            else nblk += ((ga.bw >> i) * (ga.bh >> i) + 255) / 256;
+        }
+        ga.blk_off[nb + 1] = nblk;
+        hipLaunchKernelGGL(feed_gather_kernel, dim3(nblk), blk, 0, ctx->stream, ga, lay);
+        b->fresh = false;
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -993,6 +1061,7 @@ extern "C" int mis_blender_prepare(MisBlender* b, const MisPoint* corners, const
     }
     b->dst_mask = b->type == MIS_BLEND_NO ? (uint8_t*)b->pano_mem + moff : nullptr;
     b->prepared = true;
+    b->fresh = true;
     return MIS_OK;
 }
 
@@ -1018,6 +1087,7 @@ extern "C" int mis_blender_feed(MisBlender* b, const MisImage* img, const MisIma
     if ((rc = mis_dev_image_in(ctx, img, &di)) != MIS_OK) return rc;
     if ((rc = mis_dev_image_in(ctx, mask, &dm)) != MIS_OK) { mis_dev_image_release(ctx, &di); return rc; }
     const int w = img->width, h = img->height;
+    if (b->type != MIS_BLEND_MULTI_BAND) b->fresh = false;
     if (b->type == MIS_BLEND_MULTI_BAND) rc = feed_multiband_batch(b, img, &di, &dm, &tl, 1);
     else if (b->type == MIS_BLEND_FEATHER) rc = feed_feather(b, di, dm, w, h, tl);
     else {
@@ -1174,6 +1244,7 @@ __global__ __launch_bounds__(256) void rect_exchange_kernel(RectBatch rb, uint8_
 }
 
 static int rect_exchange(MisBlender* b, const MisLevelRect* rects, int n, void* buf, size_t bytes, int mode) {
+    if (b && mode == 1) b->fresh = false;
     if (!b) return MIS_E_INVALID;
     MisContext* ctx = b->ctx;
     MIS_CHECK(ctx, b->prepared && b->type != MIS_BLEND_NO, MIS_E_STATE, "no prepared accumulator pyramids");
@@ -1219,5 +1290,6 @@ extern "C" int mis_blender_level_info(const MisBlender* b, int level, int* width
     if (height) *height = b->lh[level];
     if (lap_dev) *lap_dev = b->lap[level];
     if (weight_dev) *weight_dev = b->wgt[level];
+    if (lap_dev || weight_dev) const_cast<MisBlender*>(b)->fresh = false;   // the caller may write through these pointers
     return MIS_OK;
 }
