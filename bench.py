@@ -282,12 +282,13 @@ def measure_roofline(ctx, job, frames, cams, launches):
     t_f, t_b = min(t_f, t_f2), min(t_b, t_b2)
     with torch.cuda.stream(side):
         job.stage_compose_prepare(list(range(job.n)))
-    t_f1 = _events_ms(side, feeds_single) * 1e-3   # the same frames through n separate mis_blender_feed calls
+    # the same frames through n separate mis_blender_feed calls (skipped under the PMC passes, which average per kernel name)
+    t_f1 = _events_ms(side, feeds_single) * 1e-3 if not os.environ.get("MIS_ROOFLINE_BATCH_ONLY") else float("nan")
     nmine = len(mine)
     parts["feed"] = {"kernels": "pyr_down_l1_batch / pyr_down_level_batch / feed_tail_build / feed_accumulate (mis_blender_feed_batch, as in mis_compose_frames)", "achieved": round(algo_f / t_f / 1e9, 1),
                      "frac": round(algo_f / t_f / 8e12, 4), "algorithmic_bytes": algo_f, "frames": nmine, "num_bands": bands,
                      "padded_tile_px_per_frame": pb_total // nmine, "us_per_frame": round(t_f / nmine * 1e6, 2),
-                     "us_per_frame_single_feeds": round(t_f1 / nmine * 1e6, 2),
+                     "us_per_frame_single_feeds": round(t_f1 / nmine * 1e6, 2) if t_f1 == t_f1 else None,
                      "traffic_per_frame": pmc["feed"]["traffic_bytes_per_frame"] if pmc else None}
     parts["finalize"] = {"kernels": "normalize / collapse2x2 / finalize (mis_blender_blend)", "achieved": round(algo_b / t_b / 1e9, 1),
                          "frac": round(algo_b / t_b / 8e12, 4), "algorithmic_bytes": algo_b, "padded_pano_px": p_pano,

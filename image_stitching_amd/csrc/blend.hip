@@ -85,15 +85,20 @@ __device__ __forceinline__ float view_w(const FrameView& v, int tx, int ty) {
 // Pixel p of a row is shorts 3p .. 3p+2: with a 4-byte aligned row start they lie inside the 8 bytes at short (3p & ~1),
 // shifted by one short when p is odd.  `ok` = the row start is 4-byte aligned and reading one short past the pixel stays inside
 // the allocation; otherwise three 2-byte loads.
-__device__ __forceinline__ void load_px3(const int16_t* __restrict__ row, int p, bool ok, int* c) {
-    if (ok) {
+template <bool OK>
+__device__ __forceinline__ void load_px3_t(const int16_t* __restrict__ row, int p, int* c) {
+    if (OK) {
         const int e = 3 * p;
         const uint2 d = *reinterpret_cast<const uint2*>(row + (e & ~1));
-        const unsigned long long q = (((unsigned long long)d.y << 32) | d.x) >> (16 * (e & 1));
-        c[0] = (int)(int16_t)(unsigned short)q; c[1] = (int)(int16_t)(unsigned short)(q >> 16); c[2] = (int)(int16_t)(unsigned short)(q >> 32);
+        const unsigned sh = (unsigned)(e & 1) << 4;
+        const unsigned lo = __builtin_amdgcn_alignbit(d.y, d.x, sh);     // shorts e, e + 1 (a 64-bit shift costs four times this)
+        c[0] = (int)(int16_t)(unsigned short)lo; c[1] = (int)lo >> 16; c[2] = (int)(int16_t)(unsigned short)(d.y >> sh);
     } else {
         c[0] = row[3 * p]; c[1] = row[3 * p + 1]; c[2] = row[3 * p + 2];
     }
+}
+__device__ __forceinline__ void load_px3(const int16_t* __restrict__ row, int p, bool ok, int* c) {
+    if (ok) load_px3_t<true>(row, p, c); else load_px3_t<false>(row, p, c);
 }
 
 // ---- pyrDown, 5-tap [1 4 6 4 1], BORDER_REFLECT_101 ----
@@ -392,16 +397,17 @@ __device__ __forceinline__ void pyr_up_at(const int16_t* c, int cw, int ch, int 
 
 // pyrUp of a coarse level at the 2 x 2 fine block of coarse pixel (X, Y): up[k][c], k = (fy & 1) * 2 + (fx & 1).  The four pixels share
 // the 3 x 3 coarse neighbourhood (9 pixel loads per block); per pixel the sums are those of pyr_up_at.  `ok`: see load_px3.
-__device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int cw, int ch, int X, int Y, bool ok, int (*up)[3]) {
+template <bool OK>
+__device__ __forceinline__ void pyr_up_block(const int16_t* __restrict__ c, int cw, int ch, int X, int Y, int (*up)[3]) {
     const int xm = X > 0 ? X - 1 : (cw > 1 ? 1 : 0), xp = X + 1 < cw ? X + 1 : cw - 1;
     const int ym = Y > 0 ? Y - 1 : (ch > 1 ? 1 : 0), yp = Y + 1 < ch ? Y + 1 : ch - 1;
     const int rows[3] = {ym, Y, yp};
     int he[3][3], ho[3][3];   // [row][channel]: horizontal sums for an even / odd fine column
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const int16_t* p = c + (size_t)rows[r] * cw * 3;
+        const int16_t* p = c + (unsigned)(rows[r] * cw) * 3u;   // a level of a frame's pyramid is far below 2^32 bytes
         int a[3], b[3], d[3];
-        load_px3(p, xm, ok, a); load_px3(p, X, ok, b); load_px3(p, xp, ok, d);
+        load_px3_t<OK>(p, xm, a); load_px3_t<OK>(p, X, b); load_px3_t<OK>(p, xp, d);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             he[r][q] = a[q] + b[q] * 6 + d[q];
@@ -504,6 +510,67 @@ struct FeedGather {
     FrameView v[FB_MAX];
     int x_tl[FB_MAX], y_tl[FB_MAX], view_ok[FB_MAX];
 };
+// One frame's contribution to a thread's 2 x 2 block (levels < nb): returns whether the block was touched.  VIEW: level 0 (the frame
+// view); FAST: the frame's / coarse level's rows allow 8-byte pixel loads.  All loads of a phase are unconditional, so that they
+// are in flight together: the four weights, then (if any is non-zero) the 3 x 3 coarse pixels and the four pixels of the block.
+template <bool VIEW, bool FAST>
+__device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayout& lay, int k, int l, int px0, int py0, bool live, int (*acc)[6], float (*accw)[2]) {
+    const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
+    const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
+    const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
+    if (!live || tx < 0 || tx >= tw || ty < 0 || ty >= th) return false;
+    const FrameView& v = a.v[k];
+    float w[4];
+    // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
+    const int ix0 = tx - v.left, iy0 = ty - v.top;
+    int cx[2], cy[2];
+    if (VIEW) {
+        // weights = mask / 255 inside the image, 0 outside (copyMakeBorder CONSTANT); loads at clamped coordinates, then a select
+        cx[0] = min(max(ix0, 0), v.w - 1); cx[1] = min(max(ix0 + 1, 0), v.w - 1);
+        cy[0] = min(max(iy0, 0), v.h - 1); cy[1] = min(max(iy0 + 1, 0), v.h - 1);
+        unsigned m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[q] = v.mask[(unsigned)cy[q >> 1] * (unsigned)v.mstride + (unsigned)cx[q & 1]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ix = ix0 + (q & 1), iy = iy0 + (q >> 1);
+            w[q] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)m[q] * (float)(1. / 255.) : 0.f;
+        }
+    } else {
+        const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float2 ww = *reinterpret_cast<const float2*>(Wl + (unsigned)((ty + r) * tw + tx));   // tw and tx even
+            w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
+        }
+    }
+    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) return false;   // exact no-op contributions
+    const int cw = (tw + 1) >> 1, ch = (th + 1) >> 1;
+    int up[4][3], px[4][3];
+    pyr_up_block<FAST>((const int16_t*)(a.base[k] + lay.goff[l + 1]), cw, ch, tx >> 1, ty >> 1, up);
+    if (VIEW) {
+        // a pixel with a non-zero weight lies inside the image; the others contribute nothing, so their (reflected) values
+        // are never needed: clamped coordinates instead of reflected ones
+#pragma unroll
+        for (int q = 0; q < 4; q++) load_px3_t<FAST>(v.img + (size_t)cy[q >> 1] * v.istride, cx[q & 1], px[q]);
+    } else {
+        const int16_t* Gl = (const int16_t*)(a.base[k] + lay.goff[l]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) load_px3_t<true>(Gl + (unsigned)((ty + (q >> 1)) * tw) * 3u, tx + (q & 1), px[q]);   // tw even: rows start on a dword
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float wq = w[2 * r + q];
+            if (wq == 0.f) continue;        // `+ (short)(v * 0)` and `+ 0.f`: no-ops
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[r][3 * q + c] += (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * wq);
+            accw[r][q] += wq;
+        }
+    }
+    return true;
+}
 constexpr int FG_BX = 32, FG_BY = 8;                  // blocks per workgroup (64 x 16 pixels of the level)
 __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayout lay) {
     const int bid = (int)blockIdx.x;
@@ -528,79 +595,39 @@ __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayo
             const size_t o = (size_t)(py0 + r) * pw + px0;       // pw and px0 even: the six shorts start on a dword
             dp[r] = reinterpret_cast<uint3*>(a.lap[l] + o * 3); wp[r] = reinterpret_cast<float2*>(a.wgt[l] + o);
         }
-        for (int k = 0; k < a.n; k++) {
-            const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
-            const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
-            if (rx0 >= xt + tw || rx0 + 2 * FG_BX <= xt || ry0 >= yt + th || ry0 + 2 * FG_BY <= yt) continue;   // workgroup-uniform
-            const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
-            if (!live || tx < 0 || tx >= tw || ty < 0 || ty >= th) continue;
-            const FrameView& v = a.v[k];
-            const int16_t* Gl = (const int16_t*)(a.base[k] + lay.goff[l]);
-            const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
-            const bool view = l == 0;
-            float w[4];
-            // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
-            const int ix0 = tx - v.left, iy0 = ty - v.top;
-            if (view) {
-                // weights = mask / 255 inside the image, 0 outside (copyMakeBorder CONSTANT)
+        // the frames whose tile meets the workgroup's region: lane k of a wave tests frame k, a ballot collects the (workgroup-uniform)
+        // set -- walking all FB_MAX frames with scalar loads of their rectangles cost as many scalar as vector instructions
+        unsigned long long todo;
+        {
+            const int kk = (int)(threadIdx.x & (FB_MAX - 1));
+            const int xt = a.x_tl[kk] >> l, yt = a.y_tl[kk] >> l;
+            const int tw = level_dim(a.v[kk].tw, l), th = level_dim(a.v[kk].th, l);
+            const bool meets = kk < a.n && !(rx0 >= xt + tw || rx0 + 2 * FG_BX <= xt || ry0 >= yt + th || ry0 + 2 * FG_BY <= yt);
+            todo = __ballot(meets) & ((1ull << FB_MAX) - 1ull);
+        }
+        if (!todo) return;
+        // the sums start from the panorama's values, or from zero when the pyramids are known to be zero (no read at all)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int ix = ix0 + (q & 1), iy = iy0 + (q >> 1);
-                    w[q] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)v.mask[(unsigned)iy * (unsigned)v.mstride + (unsigned)ix] * (float)(1. / 255.) : 0.f;
-                }
+        for (int r = 0; r < 2; r++) {
+            uint3 d = make_uint3(0u, 0u, 0u);
+            float2 ws = make_float2(0.f, 0.f);
+            if (!a.fresh && live) { d = *dp[r]; ws = *wp[r]; }
+            acc[r][0] = (int)(d.x & 0xffffu); acc[r][1] = (int)(d.x >> 16); acc[r][2] = (int)(d.y & 0xffffu);
+            acc[r][3] = (int)(d.y >> 16); acc[r][4] = (int)(d.z & 0xffffu); acc[r][5] = (int)(d.z >> 16);
+            accw[r][0] = ws.x; accw[r][1] = ws.y;
+        }
+        while (todo) {
+            const int k = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+            todo &= todo - 1ull;
+            const bool cok = (level_dim(a.v[k].tw, l + 1) & 1) == 0;     // even coarse width: its rows start on a dword
+            // one instantiation per combination of (level 0 reads the frame view, 8-byte pixel loads allowed): a run-time flag inside
+            // the pixel loads turns every one of them into a branch of its own and the 13 loads of a block into 13 round trips
+            if (l == 0) {
+                if (a.view_ok[k] && cok) have |= gather_frame<true, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                else have |= gather_frame<true, false>(a, lay, k, l, px0, py0, live, acc, accw);
             } else {
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const float2 ww = *reinterpret_cast<const float2*>(Wl + (size_t)(ty + r) * tw + tx);   // tw and tx even
-                    w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
-                }
-            }
-            if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;   // exact no-op contributions
-            const int cw = (tw + 1) >> 1, ch = (th + 1) >> 1;
-            int up[4][3], px[4][3];
-            pyr_up_block((const int16_t*)(a.base[k] + lay.goff[l + 1]), cw, ch, tx >> 1, ty >> 1, (cw & 1) == 0, up);
-            if (view) {
-                // a pixel with a non-zero weight lies inside the image; the others contribute nothing, so their (reflected) values
-                // are never needed: clamp their coordinates instead of reflecting them
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int ix = min(max(ix0 + (q & 1), 0), v.w - 1), iy = min(max(iy0 + (q >> 1), 0), v.h - 1);
-                    load_px3(v.img + (size_t)iy * v.istride, ix, a.view_ok[k] && (iy + 1 < v.h || v.istride >= (size_t)3 * v.w + 1), px[q]);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++) load_px3(Gl + (size_t)(ty + (q >> 1)) * tw * 3, tx + (q & 1), true, px[q]);
-            }
-            if (!have) {
-                have = true;
-                if (a.fresh) {
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-#pragma unroll
-                        for (int q = 0; q < 6; q++) acc[r][q] = 0;
-                        accw[r][0] = accw[r][1] = 0.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint3 d = *dp[r];
-                        acc[r][0] = (int)(d.x & 0xffffu); acc[r][1] = (int)(d.x >> 16); acc[r][2] = (int)(d.y & 0xffffu);
-                        acc[r][3] = (int)(d.y >> 16); acc[r][4] = (int)(d.z & 0xffffu); acc[r][5] = (int)(d.z >> 16);
-                        const float2 ws = *wp[r];
-                        accw[r][0] = ws.x; accw[r][1] = ws.y;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const float wq = w[2 * r + q];
-                    if (wq == 0.f) continue;        // `+ (short)(v * 0)` and `+ 0.f`: no-ops (also keeps a -0.f out of the sums)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) acc[r][3 * q + c] += (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * wq);
-                    accw[r][q] += wq;
-                }
+                if (cok) have |= gather_frame<false, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                else have |= gather_frame<false, false>(a, lay, k, l, px0, py0, live, acc, accw);
             }
         }
         if (!have) return;
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(256) void collapse2x2_kernel(int16_t* __restrict__ 
     const int X = cx0 + blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= cx1 || Y >= ch) return;
     int up[4][3];
-    pyr_up_block(coarse, cw, ch, X, Y, (cw & 1) == 0, up);
+    if ((cw & 1) == 0) pyr_up_block<true>(coarse, cw, ch, X, Y, up); else pyr_up_block<false>(coarse, cw, ch, X, Y, up);   // uniform
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const size_t o = (size_t)(2 * Y + (k >> 1)) * fw + 2 * X + (k & 1);
@@ -687,7 +714,7 @@ __global__ __launch_bounds__(256) void collapse2x2_final_kernel(const int16_t* _
     const int ox = 2 * X - xoff;                      // output column of the block's left pixel
     if (ox + 1 < 0 || ox >= ow || 2 * Y >= oh) return;
     int up[4][3];
-    pyr_up_block(coarse, cw, ch, X, Y, (cw & 1) == 0, up);
+    if ((cw & 1) == 0) pyr_up_block<true>(coarse, cw, ch, X, Y, up); else pyr_up_block<false>(coarse, cw, ch, X, Y, up);   // uniform
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int y = 2 * Y + r;
@@ -874,7 +901,8 @@ int feed_multiband_batch(MisBlender* b, const MisImage* imgs, const DevImage* di
         const int bottom = bny - tls[k].y - h, right = bnx - tls[k].x - w;
         MIS_CHECK(ctx, v.left >= 0 && v.top >= 0 && bottom >= 0 && right >= 0, MIS_E_INVALID, "frame %d does not fit the prepared panorama roi", k);
         fr[k].x_tl = tnx - R.x; fr[k].y_tl = tny - R.y;
-        fr[k].view_ok = ((uintptr_t)v.img & 3) == 0 && (v.istride & 1) == 0;   // rows of the frame start on a dword: 8-byte pixel loads
+        // rows of the frame start on a dword and one short past the last pixel of a row is readable: 8-byte pixel loads
+        fr[k].view_ok = ((uintptr_t)v.img & 3) == 0 && (v.istride & 1) == 0 && v.istride >= (size_t)3 * w + 1;
         mtw = std::max(mtw, width); mth = std::max(mth, height);
     }
     dim3 blk(256);
@@ -1145,7 +1173,7 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
     for (int i = 0; i < n && rc == MIS_OK; i++) {
         const MisRect& r = rois[i];
         if (!(r.width > 0 && r.height > 0)) { rc = mis_set_error(ctx, MIS_E_INVALID, "frame %d: empty warp roi", i); break; }
-        const size_t ipitch = mis_align_up((size_t)r.width * 6, 256), mpitch = mis_align_up((size_t)r.width, 256);
+        const size_t ipitch = mis_align_up((size_t)r.width * 6 + 2, 256), mpitch = mis_align_up((size_t)r.width, 256);   // + 2: see view_ok
         const size_t ibytes = ipitch * r.height, mbytes = mpitch * r.height;
         void* blk = nullptr; size_t got = 0;
         if ((rc = mis_pool_alloc(ctx, ibytes + mbytes, &blk, &got)) != MIS_OK) break;

@@ -14,5 +14,5 @@ if [ "$1" != "quick" ]; then
   run write WRITE_SIZE
 fi
 cd $R
-K="-k=pyr_down -k=feed_accumulate -k=feed_tail -k=collapse2x2 -k=finalize_kernel -k=laplace -k=feed_level"
+K="-k=pyr_down -k=feed_gather -k=feed_tail -k=collapse2x2 -k=finalize_kernel -k=laplace"
 python3 tools/pmc_summary.py gpurun_out/pmcf_inst gpurun_out/pmcf_wait $( [ "$1" != "quick" ] && echo gpurun_out/pmcf_fetch gpurun_out/pmcf_write ) $K
