@@ -117,6 +117,7 @@ PROTOTYPES = {
     "mis_matches_free": (_i, [_P(MisMatchesInfo), _i]),
     "mis_match_sequence": (C.c_longlong, [_vp]),
     "mis_match_knn_fence": (_i, [_vp, _vp, C.c_longlong, _i]),
+    "mis_match_on_enqueued": (_i, [_vp, _vp, _vp]),
     "mis_knn2": (_i, [_vp, _P(MisFeatures), _P(MisFeatures), _vp, _vp]),
     "mis_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _P(_i)]),
     "mis_leave_biggest_component": (_i, [_P(MisMatchesInfo), _i, _f, _vp, _P(_i)]),

@@ -31,6 +31,7 @@ The orchestration is engine-agnostic: `HipEngine` (the product) drives libmistit
 the CPU tests inject an engine of their own to exercise the sharding / collective logic under gloo.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -293,6 +294,17 @@ class HipEngine:
     def match_fence_target(self):
         """Sequence number the NEXT matcher call of this engine will carry (see compose_after_knn)."""
         return int(self.ctx.lib.mis_match_sequence(self.ctx.h)) + 1
+
+    def on_match_enqueued(self, fn):
+        """fn() runs inside this engine's NEXT matcher call, on the calling thread, once that call's device work is enqueued
+        (mis_match_on_enqueued): the thread is idle from there until the device finishes.  fn=None clears a pending hook."""
+        if fn is None:
+            self._enqueued_cb = None
+            self.ctx.lib.mis_match_on_enqueued(self.ctx.h, None, None)
+            return
+        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())
+        self._enqueued_cb = cb          # alive until it has run
+        self.ctx.check(self.ctx.lib.mis_match_on_enqueued(self.ctx.h, C.cast(cb, C.c_void_p), None))
 
     def compose_after_knn(self, target_seq):
         """Queue the compose stream behind the 2-NN pass of matcher call `target_seq` (made by another thread): that
@@ -601,6 +613,11 @@ class StitchJob:
             return self.stage_compose(frames, indices, prepared)
 
     def run(self, frames):
+        marks = self.marks = [("start", time.perf_counter())] if os.environ.get("MIS_JOB_TRACE") else None   # host time stamps (diagnostics)
+
+        def mark(name):
+            if marks is not None:
+                marks.append((name, time.perf_counter()))
         refine = self.cfg.ba_cost_func != "no"
         # refined cameras or a seam-scale step (which needs the kept set): compose must wait for the matcher
         spec = getattr(self.engine, "speculative_compose", False) and not refine and not self.seam_needed
@@ -615,6 +632,7 @@ class StitchJob:
             with torch.cuda.stream(self.engine.compose_stream):
                 prepared = self.stage_compose_prepare(list(range(self.n)))
         feats = self.stage_gather(self.stage_features(frames))
+        mark("features")
         if spec:
             # Speculation: almost always every frame survives the pruning, and warp + blend do not depend on the
             # matches otherwise (the cameras are inputs).  Compose for ALL frames on the second stream from a helper
@@ -632,19 +650,36 @@ class StitchJob:
                 try:
                     if fence is not None:
                         self.engine.compose_after_knn(fence)
+                    mark("compose: fence passed")
                     box["r"] = self._compose_on_side_stream(frames, everyone, prepared)
+                    mark("compose: enqueued")
                     if solo:
                         with torch.cuda.stream(self.engine.compose_stream):
                             box["f"] = self.stage_finalize()
+                    mark("compose: finalise enqueued")
                 except BaseException as e:   # re-raised on the caller's thread
                     box["e"] = e
-            th = threading.Thread(target=work)
-            th.start()
-            try:
-                pm, conf = self.stage_match(feats)
+            if hasattr(self.engine, "on_match_enqueued"):
+                # no second thread: the composition is enqueued from inside the matcher call, by the thread that would otherwise
+                # only wait there for the device (a helper thread cost 0.1 ms to start and contended for the interpreter lock)
+                self.engine.on_match_enqueued(work)
+                try:
+                    pm, conf = self.stage_match(feats)
+                finally:
+                    self.engine.on_match_enqueued(None)
+                mark("match returned")
+                if not box:
+                    work()              # a matcher call without pairs returns before its hook
                 indices = self.stage_prune(conf)
-            finally:
-                th.join()
+                mark("pruned")
+            else:
+                th = threading.Thread(target=work)
+                th.start()
+                try:
+                    pm, conf = self.stage_match(feats)
+                    indices = self.stage_prune(conf)
+                finally:
+                    th.join()
             if "e" in box:
                 raise box["e"]
             if indices == everyone and "f" in box:
@@ -671,6 +706,7 @@ class StitchJob:
             btype, bands = self._compose_on_side_stream(frames, indices)     # (torch allocations of the seam step on the library's stream)
             pano, mask = self.stage_exchange_finalize()
         self.engine.sync()      # the job's results are complete when run() returns
+        mark("synchronised")
         return {"pano": pano, "mask": mask, "indices": indices, "confidence": conf, "matches": pm, "features": feats,
                 "pano_size": self.engine.pano_size, "num_bands": bands}
 

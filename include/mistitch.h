@@ -159,6 +159,11 @@ int mis_matches_free(MisMatchesInfo* m, int count);
  * makes `stream` wait for the end of that call's 2-NN pass (the one phase of the matcher that fills the device). */
 long long mis_match_sequence(MisContext* ctx);
 int mis_match_knn_fence(MisContext* ctx, void* stream, long long target_seq, int timeout_ms);
+/* The same without a second host thread: a one-shot hook of this context's NEXT matcher call.  fn(user) runs on the thread that
+ * calls mis_match_all_pairs / mis_match_pairs_sharded, once all of the call's device work is enqueued and before the call waits
+ * for the device (the ~5 ms in which that thread is idle); inside it mis_match_knn_fence(ctx, stream, mis_match_sequence(ctx), 0)
+ * returns at once and queues `stream` behind the 2-NN pass.  The hook is not called when the matcher call fails earlier. */
+int mis_match_on_enqueued(MisContext* ctx, void (*fn)(void*), void* user);
 /* exact 2-NN (distance, trainIdx) for one direction; results in host memory (stage test hook) */
 int mis_knn2(MisContext* ctx, const MisFeatures* query, const MisFeatures* train, int* idx2_host, float* dist2_host);
 /* cv::findHomography(src, dst, mask, RANSAC, thresh, max_iters, confidence) on host point lists */
