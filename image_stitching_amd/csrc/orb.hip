@@ -676,6 +676,75 @@ __global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* 
     desc[(size_t)i * 32 + b] = (uint8_t)val;
 }
 
+// The same descriptors without blurring the pyramid: only the 512 sample points of a keypoint are ever read from the blurred
+// image, so one wave stages the keypoint's (2 (R + 3) + 1)^2 source patch in LDS and evaluates the 7 x 7 Gaussian at its samples
+// directly -- sum_j k[j] (sum_i k[i] p[y+j][x+i]), the separable filter's own integers (row sums <= 65280 fit the 16 bits
+// the two-pass form keeps) -- 25 k multiply-adds per keypoint instead of 14 per pixel of every level (84 us of blur_kernel per
+// 4K frame for 4000 keypoints' worth of samples).  R = the largest rounded pattern coordinate (28 for patchSize 40); samples
+// inside the level are blurred (their taps may reach into the reflected border ring), samples in the ring are not: the reference
+// blurs the level's ROI of the bordered pyramid only.
+constexpr int DD_R = 28, DD_P = DD_R + 3, DD_N = 2 * DD_P + 1, DD_ROW_DW = (DD_N + 3 + 3) / 4, DD_PITCH = 4 * DD_ROW_DW + 4;
+__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, const MisKeyPoint* kps, const uint32_t* kp_lxy,
+                                                              const int* n_ptr, const int8_t* pattern, uint8_t* desc) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4][DD_N * DD_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= *n_ptr) return;   // wave-uniform: no workgroup barrier below
+    const MisKeyPoint kp = kps[i];
+    const LevelDesc& d = L.d[kp.octave];
+    const float inv = 1.f / d.scale;
+    const int cx = mis_round_f(kp.x * inv), cy = mis_round_f(kp.y * inv);
+    float ang = kp.angle * (float)(3.14159265358979323846 / 180.f);
+    float sa, ca;
+    mis_sincosf(ang, &sa, &ca);
+    const int pp = d.pp;
+    const uint8_t* org = pad + d.pad_off + (size_t)(cy + ORB_BORDER - DD_P) * pp + (cx + ORB_BORDER - DD_P);
+    const int shift = (int)((uintptr_t)org & 3);
+    const uint8_t* abase = org - shift;   // rows are copied as aligned dwords; the patch starts `shift` bytes into an LDS row
+    uint8_t* P = patch[wave];
+    for (int k = lane; k < DD_N * DD_ROW_DW; k += 64) {
+        const int r = k / DD_ROW_DW, c = k - r * DD_ROW_DW;
+        reinterpret_cast<unsigned*>(P + r * DD_PITCH)[c] = *reinterpret_cast<const unsigned*>(abase + (size_t)r * pp + 4 * c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lanes of one wave execute their LDS instructions in order
+    __builtin_amdgcn_wave_barrier();
+    const int b = lane & 31, h = lane >> 5;                  // lane b (and b + 32) of the wave builds byte b: four tests each
+    const int8_t* pat = pattern + b * 32 + h * 16;
+    // a row's seven taps are bytes a .. a + 6 of three aligned LDS dwords: two funnel shifts bring them into two dwords, two
+    // v_dot4_u32_u8 against the packed kernel (18 34 48 56 | 48 34 18 0) give the row sum
+    const unsigned* P32 = reinterpret_cast<const unsigned*>(P);
+    const int c0 = DD_P * DD_PITCH + DD_P + shift;               // byte offset of the keypoint's pixel
+    auto blurred = [&](int ix, int iy) {
+        const int a = c0 + (iy - 3) * DD_PITCH + (ix - 3);       // first tap of the first row
+        // keypoints may sit 3 pixels from the edge (edgeThreshold 1): a sample outside the level reads the un-blurred border ring
+        const bool inside = (unsigned)(cx + ix) < (unsigned)d.w && (unsigned)(cy + iy) < (unsigned)d.h;
+        const unsigned* q = P32 + (a >> 2);
+        const unsigned sh = (unsigned)(a & 3) << 3;
+        const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
+        unsigned acc = 0, centre = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const unsigned d0 = q[j * (DD_PITCH / 4)], d1 = q[j * (DD_PITCH / 4) + 1], d2 = q[j * (DD_PITCH / 4) + 2];
+            const unsigned lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const unsigned hs = __builtin_amdgcn_udot4(lo, 0x38302212u, __builtin_amdgcn_udot4(hi, 0x00122230u, 0u, false), false);
+            acc += (unsigned)kq[j] * hs;
+            if (j == 3) centre = lo >> 24;                       // tap 3 of row 3: the sample's own pixel
+        }
+        return inside ? (int)((acc + (1u << 15)) >> 16) : (int)centre;
+    };
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+        float x0 = (float)pat[4 * bit], y0 = (float)pat[4 * bit + 1], x1 = (float)pat[4 * bit + 2], y1 = (float)pat[4 * bit + 3];
+        int ix0 = mis_round_f(x0 * ca - y0 * sa), iy0 = mis_round_f(x0 * sa + y0 * ca);
+        int ix1 = mis_round_f(x1 * ca - y1 * sa), iy1 = mis_round_f(x1 * sa + y1 * ca);
+        const int t0 = blurred(ix0, iy0), t1 = blurred(ix1, iy1);
+        val |= (t0 < t1) << (bit + 4 * h);
+    }
+    val |= __shfl_xor(val, 32);
+    if (h == 0) desc[(size_t)i * 32 + b] = (uint8_t)val;
+}
+
 // the keypoint counts of a batch and the lanes' overflow flags, gathered into one host-visible (pinned, mapped) array:
 // one kernel instead of one small device-to-host copy per frame at the end of the feature stage
 constexpr int ORB_GATHER_MAX = 96;
@@ -706,6 +775,7 @@ struct MisOrb {
     std::vector<hipEvent_t> helper_done;
     hipEvent_t fork_event = nullptr;
     bool is_helper = false;
+    bool direct_describe = false;   // the pattern's reach fits describe_direct_kernel's patch: no blurred pyramid
 };
 
 namespace {
@@ -834,9 +904,14 @@ int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* ou
     int* n_dev = feat_count(out, o->out_cap);
     hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax,
                        out->keypoints, lxy, n_dev, o->out_cap);
-    hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, L.n), dim3(256), 0, st, L, W.pad, W.blur);
-    hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur, out->keypoints, lxy, n_dev, W.pattern,
-                       (uint8_t*)out->descriptors);
+    if (o->direct_describe) {
+        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4), dim3(256), 0, st, L, W.pad, out->keypoints, lxy, n_dev, W.pattern,
+                           (uint8_t*)out->descriptors);
+    } else {
+        hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, L.n), dim3(256), 0, st, L, W.pad, W.blur);
+        hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur, out->keypoints, lxy, n_dev, W.pattern,
+                           (uint8_t*)out->descriptors);
+    }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -914,6 +989,14 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
         auto next = [&]() { state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32); return (uint32_t)state; };
         int hp = p->patch_size / 2;
         for (int i = 0; i < 1024; i++) pat[i] = (int8_t)(int)(next() % (uint32_t)(2 * hp + 1) + (uint32_t)(-hp));
+    }
+    {
+        int max_sq = 0;
+        for (int i = 0; i < 512; i++) max_sq = std::max(max_sq, (int)pat[2 * i] * pat[2 * i] + (int)pat[2 * i + 1] * pat[2 * i + 1]);
+        // |round(x cos - y sin)| <= round(|(x, y)|); the patch must also stay inside the padded level (border ring of ORB_BORDER)
+        const int reach = (int)floor(sqrt((double)max_sq) + 0.5);
+        // FAST keypoints keep 3 pixels from the edge, the level carries a border ring of ORB_BORDER: the patch stays inside the padded level
+        o->direct_describe = reach <= DD_R && 3 + ORB_BORDER >= DD_P && getenv("MIS_ORB_FULL_BLUR") == nullptr;
     }
     hipMemcpyAsync(W.umax, umax, sizeof(umax), hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(W.pattern, pat, sizeof(pat), hipMemcpyHostToDevice, ctx->stream);
@@ -1013,11 +1096,14 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
             for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
         }
     }
+    const bool trace = getenv("MIS_ORB_TRACE") != nullptr;
+    const auto t_enq0 = std::chrono::steady_clock::now();
     for (int i = 0; i < n; i++) {
         MisOrb* lane = lanes[i % lanes.size()];
         if ((rc = enqueue_detect(lane, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK)
             return lane == o ? rc : mis_set_error(ctx, rc, "helper finder: %s", lane->ctx->err.c_str());
     }
+    if (trace) fprintf(stderr, "orb batch: %d frames enqueued in %.0f us\n", n, (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_enq0).count());
     // join: the context's stream continues after every helper chain
     for (size_t k = 0; k + 1 < lanes.size(); k++) {
         MIS_HIP(ctx, hipEventRecord(o->helper_done[k], lanes[k + 1]->ctx->stream));
@@ -1118,7 +1204,13 @@ extern "C" int mis_orb_debug_level(MisOrb* o, int level, int which, uint8_t* hos
         hipLaunchKernelGGL(nms_raster_kernel, dim3(256), dim3(64), 0, ctx->stream, d, o->w.tile_cnt, o->w.surv_xy, o->w.surv_sc, o->w.nms);
         src = o->w.nms + d.map_off; pitch = d.sp;
     }
-    else { src = o->w.blur + d.pad_off; pitch = d.pp; }
+    else {
+        if (o->direct_describe) {   // the detector no longer blurs the pyramid (describe_direct_kernel): this view computes it on demand
+            const int pw0 = o->L.d[0].w + 2 * ORB_BORDER, ph0 = o->L.d[0].h + 2 * ORB_BORDER;
+            hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, o->L.n), dim3(256), 0, ctx->stream, o->L, o->w.pad, o->w.blur);
+        }
+        src = o->w.blur + d.pad_off; pitch = d.pp;
+    }
     MIS_HIP(ctx, hipMemcpy2DAsync(host_out, w, src, pitch, w, h, hipMemcpyDeviceToHost, ctx->stream));
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MIS_OK;
