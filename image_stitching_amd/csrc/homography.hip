@@ -541,6 +541,9 @@ __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, con
 
 // ---------------------------------------------------------------- scan_tail_kernel -------------
 #ifdef MIS_TAIL_PROF
+__device__ unsigned long long g_jac_prof[8];    // shader cycles: pivot search, math, rotation, index update (summed over rotations)
+#define JP_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define JP_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_jac_prof[i], (b) - (a)); } while (0)
 __device__ unsigned long long g_tail_prof[8];   // jacobi ticks, rotations, normal_eq ticks, LM iterations, dlt ticks, tail ticks, tails, max tail ticks
 #define PROF_T0(v) unsigned long long v = wall_clock64()
 #define PROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_tail_prof[i], wall_clock64() - (v)); } while (0)
@@ -549,6 +552,8 @@ __device__ unsigned long long g_tail_prof[8];   // jacobi ticks, rotations, norm
 #define PROF_T0(v)
 #define PROF_ADD(i, v)
 #define PROF_INC(i, n)
+#define JP_T(v)
+#define JP_ADD(i, a, b)
 #endif
 struct TailShared {
     double A[81], V[81], W[9];
@@ -577,9 +582,10 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
         const double eps = DBL_EPSILON;
         int i, k, l, m;
         double mv;
+        double Wt = 0;   // lane t < n keeps W[t] in a register: W[k], W[l] of a step are two lane reads, not an LDS round trip
         if (t < n) {
             for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
-            W[t] = A[(n + 1) * t];
+            Wt = A[(n + 1) * t];
             k = t;
             if (k < n - 1) {
                 for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
@@ -599,6 +605,7 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
         wave_sync();
         const int maxIters = n * n * 30;
         if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
+            JP_T(j0);
             // pivot search of the serial loop: all index loads, then all value loads, then the compare chain -- with n a
             // template parameter the loops unroll and the (broadcast) LDS reads go out back to back
             int ir[n], ic[n];
@@ -608,11 +615,12 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
 #pragma unroll
             for (i = 1; i < n; i++) ic[i] = S.indC[i];
 #pragma unroll
-            for (i = 0; i < n - 1; i++) rv[i] = fabs(A[n * i + ir[i]]);
+            for (i = 0; i < n - 1; i++) rv[i] = A[n * i + ir[i]];
 #pragma unroll
-            for (i = 1; i < n; i++) cv[i] = fabs(A[n * ic[i] + i]);
+            for (i = 1; i < n; i++) cv[i] = A[n * ic[i] + i];
             // "first maximum" of the serial scan = a tournament in which the earlier candidate wins ties: depth 4-5
             // instead of a chain of 16 dependent f64 compares.  Candidate order: rows 0 .. n-2, then columns 1 .. n-1.
+            // The candidates carry their signed value: the winner's is the pivot p (no further read).
             double cand_v[2 * n - 2];
             int cand_k[2 * n - 2], cand_l[2 * n - 2];
 #pragma unroll
@@ -623,61 +631,77 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
             for (int width = 1; width < 2 * n - 2; width *= 2) {
 #pragma unroll
                 for (i = 0; i + width < 2 * n - 2; i += 2 * width) {
-                    const bool right = cand_v[i] < cand_v[i + width];   // strictly greater: the later candidate must beat the earlier
+                    const bool right = fabs(cand_v[i]) < fabs(cand_v[i + width]);   // strictly greater: the later candidate must beat the earlier
                     cand_v[i] = right ? cand_v[i + width] : cand_v[i];
                     cand_k[i] = right ? cand_k[i + width] : cand_k[i];
                     cand_l[i] = right ? cand_l[i + width] : cand_l[i];
                 }
             }
-            k = cand_k[0]; l = cand_l[0];
-            const double p = A[n * k + l];
-            if (fabs(p) <= eps) break;  // uniform: every lane reads the same LDS words
+            k = __builtin_amdgcn_readfirstlane(cand_k[0]); l = __builtin_amdgcn_readfirstlane(cand_l[0]);   // uniform: every lane read the same LDS words
+            const double p = cand_v[0];
+            if (fabs(p) <= eps) break;
             PROF_INC(1, 1);
-            const double y = (W[l] - W[k]) * 0.5;
+            JP_T(j1);
+            const double Wk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Wt), k), __builtin_amdgcn_readlane(__double2loint(Wt), k));
+            const double Wl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Wt), l), __builtin_amdgcn_readlane(__double2loint(Wt), l));
+            const double y = (Wl - Wk) * 0.5;
             double tt = fabs(y) + cv_hypot(p, y);
             double sn = cv_hypot(p, tt);
             const double c = tt / sn;
             sn = p / sn; tt = (p / tt) * p;
             if (y < 0) sn = -sn, tt = -tt;
+#ifdef MIS_TAIL_PROF
+            asm volatile("" :: "v"(c), "v"(sn), "v"(tt));
+#endif
+            JP_T(j2);
             wave_sync();  // all pivot inputs read before anything is rewritten
-            if (t == 0) { A[n * k + l] = 0; W[k] -= tt; W[l] += tt; }
-            if (t < n) {
-                double a0, b0;
-#define MIS_ROT(X, Y) a0 = X, b0 = Y, X = a0 * c - b0 * sn, Y = a0 * sn + b0 * c
-                if (t < k) MIS_ROT(A[n * t + k], A[n * t + l]);
-                else if (t > k && t < l) MIS_ROT(A[n * k + t], A[n * t + l]);
-                else if (t > l) MIS_ROT(A[n * k + t], A[n * l + t]);
-                MIS_ROT(V[n * k + t], V[n * l + t]);
-#undef MIS_ROT
+            if (t == k) Wt -= tt;
+            if (t == l) Wt += tt;
+            {
+                // lane t rotates the pair of A that involves row / column t and the pair of V in column t: one address computation
+                // for all cases of the serial loops (t < k: (A[t][k], A[t][l]); k < t < l: (A[k][t], A[t][l]); l < t: (A[k][t], A[l][t])),
+                // one batch of loads, one of stores
+                const bool va = t < n, aa = va && t != k && t != l;
+                const int tc = va ? t : 0;
+                double* X = A + (tc < k ? n * tc + k : n * k + tc);
+                double* Y = A + (tc < l ? n * tc + l : n * l + tc);
+                double* VX = V + n * k + tc;
+                double* VY = V + n * l + tc;
+                const double a0 = *X, b0 = *Y, va0 = *VX, vb0 = *VY;
+                const double xa = a0 * c - b0 * sn, ya = a0 * sn + b0 * c, xv = va0 * c - vb0 * sn, yv = va0 * sn + vb0 * c;
+                if (aa) { *X = xa; *Y = ya; }
+                if (va) { *VX = xv; *VY = yv; }
+                if (t == 0) A[n * k + l] = 0;
             }
             wave_sync();
+            JP_T(j3);
             if (t < 4) {
+                // indR[k], indC[k], indR[l], indC[l] by four lanes, one code path: lane j scans the row (even j) or the column
+                // (odd j) of idx = k (j < 2) or l; fixed-count loop with a predicate, values loaded up front
                 const int idx = t < 2 ? k : l;
-                if ((t & 1) == 0) {
-                    if (idx < n - 1) {
-                        // row idx, columns idx+1 .. n-1: fixed-count loop with a predicate (values loaded up front)
-                        double vals[n];
+                const bool row = (t & 1) == 0;
+                const bool need = row ? idx < n - 1 : idx > 0;
+                double vals[n - 1];
 #pragma unroll
-                        for (i = 1; i < n; i++) vals[i] = fabs(A[n * idx + min(max(i, idx + 1), n - 1)]);
-                        m = idx + 1; mv = -1.;
-#pragma unroll
-                        for (i = 1; i < n; i++)
-                            if (i > idx && mv < vals[i]) mv = vals[i], m = i;
-                        S.indR[idx] = m;
-                    }
-                } else if (idx > 0) {
-                    double vals[n];
-#pragma unroll
-                    for (i = 0; i < n - 1; i++) vals[i] = fabs(A[n * min(i, idx - 1) + idx]);
-                    m = 0; mv = -1.;
-#pragma unroll
-                    for (i = 0; i < n - 1; i++)
-                        if (i < idx && mv < vals[i]) mv = vals[i], m = i;
-                    S.indC[idx] = m;
+                for (i = 0; i < n - 1; i++) {
+                    // step i visits column idx + 1 + i of the row (while < n) / row i of the column (while < idx)
+                    const int q = row ? min(idx + 1 + i, n - 1) : min(i, max(idx - 1, 0));
+                    vals[i] = fabs(A[row ? n * idx + q : n * q + idx]);
                 }
+                m = row ? idx + 1 : 0; mv = -1.;
+#pragma unroll
+                for (i = 0; i < n - 1; i++) {
+                    const int q = row ? idx + 1 + i : i;
+                    const bool valid = row ? q < n : q < idx;
+                    if (valid && mv < vals[i]) mv = vals[i], m = q;
+                }
+                if (need) { if (row) S.indR[idx] = m; else S.indC[idx] = m; }
             }
             wave_sync();
+            JP_T(j4);
+            JP_ADD(0, j0, j1); JP_ADD(1, j1, j2); JP_ADD(2, j2, j3); JP_ADD(3, j3, j4);
         }
+        if (t < n) W[t] = Wt;
         wave_sync();
         if (t == 0) {
             for (k = 0; k < n - 1; k++) {
@@ -1087,6 +1111,12 @@ extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(unsigned long long) * 8);
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
+    return 0;
+}
+extern "C" int mis_debug_jac_prof(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jac_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_jac_prof), z, sizeof(z)); }
     return 0;
 }
 #endif
