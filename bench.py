@@ -198,8 +198,9 @@ def _events_ms(stream, fn, reps=1):
 def measure_roofline(ctx, job, frames, cams, launches):
     """algorithmic bytes of K10-K14 / their summed device time, each leg alone on the device and timed with
     HIP events on the stream its kernels are launched on.
-      warp (K10):      (3 S + 7 P) per frame / average duration of `launches` back-to-back launches of warp_fused_kernel
-                       for one frame, enqueued from inside the library (mis_warp_spherical_fused_timed);
+      warp (K10):      (3 S + 7 P) per frame / duration of warp_fused_batch_kernel -- this rank's frames in one grid, as
+                       mis_compose_frames launches them -- per frame, back-to-back passes enqueued from inside the library
+                       (mis_warp_spherical_fused_batch_timed); the one-frame-per-launch figure of warp_fused_kernel beside it;
       feed (K12-K13):  sum over this rank's frames of 7 P_i + 2 (6 + 4) (4/3) P_b,i / the time of their mis_blender_feed_batch
                        call (P_b,i = the feed's padded tile, mis_blender_feed_rect); the time of n single feeds beside it;
       finalise (K14):  44.3 B per padded panorama pixel / the time of mis_blender_blend.
@@ -219,8 +220,19 @@ def measure_roofline(ctx, job, frames, cams, launches):
     dst, msk = warper.alloc_fused(roi)
     warper.warp_fused_timed(frames[i], cam["K"], cam["R"], roi, dst, msk, launches)        # warm-up
     us = sum(warper.warp_fused_timed(frames[i], cam["K"], cam["R"], roi, dst, msk, launches) for _ in range(3)) / 3.0
-    t_w = us * 1e-6
+    t_w1 = us * 1e-6          # one frame per launch
     del dst, msk
+    # the form mis_compose_frames runs: all of this rank's frames in one grid per 16 frames (mis_warp_spherical_fused_batch)
+    b_rois = isa.stitching.warp_rois(ctx, job.scale, (cam["width"], cam["height"]), [cams[k] for k in mine])
+    b_out = [warper.alloc_fused(r) for r in b_rois]
+    b_args = ([frames[k] for k in mine], [cams[k] for k in mine], b_rois, [o[0] for o in b_out], [o[1] for o in b_out])
+    reps = max(1, launches // max(len(mine), 1))
+    warper.warp_fused_batch_timed(*b_args, reps)                                           # warm-up
+    us_b = sum(warper.warp_fused_batch_timed(*b_args, reps) for _ in range(3)) / 3.0
+    algo_w_batch = sum(3 * S + 7 * r[2] * r[3] for r in b_rois)
+    t_wb = us_b * 1e-6         # one pass over all frames
+    del b_out, b_args
+    t_w = t_wb * algo_w / algo_w_batch      # the measured frame's share of the batch (by bytes)
     # HBM traffic from the PMC passes of profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as
     # the gfx950 note of MI355X_MICROARCH.md prescribes): counters cannot be collected from inside this process, so the committed
     # summary of the same kernels is read when it belongs to this frame size (tools/profile_round2.sh, tools/collect_profiles.py).
@@ -236,6 +248,8 @@ def measure_roofline(ctx, job, frames, cams, launches):
         pmc = None
     parts = {"warp": {"kernel": "warp_fused_kernel", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
                       "algorithmic_bytes_per_launch": algo_w, "avg_launch_us": round(t_w * 1e6, 2), "launches": launches,
+                      "launch": "mis_warp_spherical_fused_batch: %d frames in one grid, %.1f us per pass, %d passes x 3; avg_launch_us = the pass / frames (by bytes)" % (len(mine), us_b, reps),
+                      "single_frame_launch_us": round(t_w1 * 1e6, 2), "single_frame_launch_frac": round(algo_w / t_w1 / 8e12, 4),
                       "traffic": traffic}}
     # ---- feed + finalise legs: this rank's frames through the job's own blender, stage by stage ----
     cctx, side = eng.cctx, eng.compose_stream

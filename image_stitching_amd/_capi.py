@@ -128,6 +128,9 @@ PROTOTYPES = {
     "mis_warp_spherical": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _i, _i, _P(MisImage), _P(MisPoint)]),
     "mis_warp_roi_batch": (_i, [_vp, _f, _i, _i, _i, _vp, _vp, _P(MisRect)]),
     "mis_warp_spherical_fused_roi": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisRect), _P(MisImage), _P(MisImage), _P(MisPoint)]),
+    "mis_warp_spherical_fused_batch": (_i, [_vp, _P(MisImage), _i, C.c_float, _P(C.c_float), _P(C.c_float), _P(MisRect), _P(MisImage), _P(MisImage), _P(MisPoint)]),
+    "mis_warp_spherical_fused_batch_timed": (_i, [_vp, _P(MisImage), _i, C.c_float, _P(C.c_float), _P(C.c_float), _P(MisRect), _P(MisImage), _P(MisImage), _P(MisPoint), _i,
+                                               _P(C.c_float)]),
     "mis_warp_spherical_fused": (_i, [_vp, _P(MisImage), _f, _vp, _vp, _P(MisImage), _P(MisImage), _P(MisPoint)]),
     "mis_resize_linear_exact": (_i, [_vp, _P(MisImage), _i, _i, C.c_double, C.c_double, _P(MisImage)]),
     "mis_rotate": (_i, [_vp, _P(MisImage), _i, _P(MisImage)]),

@@ -1165,7 +1165,7 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
     MIS_CHECK(ctx, b->prepared, MIS_E_STATE, "compose before prepare");
     MIS_CHECK(ctx, frames && Ks && Rs && rois && n >= 0, MIS_E_INVALID, "null argument");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    // all warps into pool blocks of their own, then one batched feed (the frames' pyramids are built together)
+    // all warps into pool blocks of their own (one grid for up to 16 frames), then one batched feed (the frames' pyramids are built together)
     std::vector<MisImage> imgs(n), msks(n);
     std::vector<MisPoint> tls(n);
     std::vector<std::pair<void*, size_t>> blocks;
@@ -1180,8 +1180,8 @@ extern "C" int mis_compose_frames(MisBlender* b, const MisImage* frames, int n, 
         blocks.emplace_back(blk, got);
         imgs[i] = MisImage{blk, r.width, r.height, 3, ipitch, MIS_S16, MIS_MEM_DEVICE};
         msks[i] = MisImage{(uint8_t*)blk + ibytes, r.width, r.height, 1, mpitch, MIS_U8, MIS_MEM_DEVICE};
-        rc = mis_warp_spherical_fused_roi(ctx, &frames[i], scale, Ks + 9 * i, Rs + 9 * i, &r, &imgs[i], &msks[i], &tls[i]);
     }
+    if (rc == MIS_OK && n > 0) rc = mis_warp_spherical_fused_batch(ctx, frames, n, scale, Ks, Rs, rois, imgs.data(), msks.data(), tls.data());
     if (rc == MIS_OK) rc = mis_blender_feed_batch(b, imgs.data(), msks.data(), tls.data(), n);
     for (auto& bl : blocks) mis_pool_free(ctx, bl.first, bl.second);   // stream-ordered reuse
     return rc;

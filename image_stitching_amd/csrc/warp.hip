@@ -560,8 +560,8 @@ constexpr int TILE_WAVES = WV_TILE_WAVES;
 #endif
 constexpr int CH_W = WV_CH_W, CH_H = WV_CH_H;   // chunk of tiles owned by one XCD (CH_W a multiple of TILE_WAVES)
 static_assert(CH_W % TILE_WAVES == 0, "chunk width must be a whole number of workgroups");
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
+// bid / nwg: the workgroup's index in its frame's grid and the size of that grid
+__device__ __forceinline__ void warp_fused_body(const WarpArgs& a, const float* __restrict__ tab, int ntiles, int bid, int nwg_frame, uint8_t (*stage_all)[STAGE_BYTES]) {
     const int ntx = (a.dw + FT_W - 1) / FT_W, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t* stage = stage_all[wave];
     // Tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  The tile grid is cut into
@@ -571,20 +571,22 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     // XCDs that own the top and bottom bands 7 % more work: they finished 2.7 us after the others, tools/warp_stamps.py).
     const int nty = (a.dh + FT_H - 1) / FT_H;
 #if WV_ORDER == 0
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
-    const int wg = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3);
+    const int nwg = nwg_frame, xcd = bid & 7;
+    const int wg = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (bid >> 3);
     const int tile = wg * TILE_WAVES + wave;
     if (tile >= ntiles) return;
     const int tx = tile % ntx, ty = tile / ntx;
 #elif WV_ORDER == 1
-    const int tile = blockIdx.x * TILE_WAVES + wave;
+    const int tile = bid * TILE_WAVES + wave;
     if (tile >= ntiles) return;
     const int tx = tile % ntx, ty = tile / ntx;
+    (void)nwg_frame;
 #else
     constexpr int WG_X = CH_W / TILE_WAVES, WG_PER_CHUNK = WG_X * CH_H;
     const int nchx = (ntx + CH_W - 1) / CH_W;
-    const int i = blockIdx.x >> 3;
-    const int chunk = (i / WG_PER_CHUNK) * 8 + (blockIdx.x & 7), within = i % WG_PER_CHUNK;
+    const int i = bid >> 3;
+    const int chunk = (i / WG_PER_CHUNK) * 8 + (bid & 7), within = i % WG_PER_CHUNK;
+    (void)nwg_frame;
     const int chy = chunk / nchx, chx = chunk - chy * nchx;
     const int tx = chx * CH_W + (within % WG_X) * TILE_WAVES + wave, ty = chy * CH_H + within / WG_X;
     if (tx >= ntx || ty >= nty) return;
@@ -619,6 +621,42 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     tile_sample_store(a, cur, stage);
 #endif
+}
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
+    warp_fused_body(a, tab, ntiles, (int)blockIdx.x, (int)gridDim.x, stage_all);
+}
+// The frames of a compositing loop in ONE grid (y = frame): a 4K frame is 2.8 generations of resident workgroups, so a launch of
+// its own spends a quarter of its time filling and draining the device (tools/warp_stamps.py: the last workgroups start at 19 us of
+// 24); in a common grid the next frame's tiles take the slots the previous frame's stragglers free.
+constexpr int WB_MAX = 16;
+struct WarpBatch {
+    WarpArgs a[WB_MAX];
+    const float* tab[WB_MAX];
+    int ntiles[WB_MAX], nwg[WB_MAX];
+};
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_batch_kernel(WarpBatch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
+    const int f = blockIdx.y;
+    if ((int)blockIdx.x >= b.nwg[f]) return;      // the grid covers the largest frame of the batch
+    const WarpArgs a = b.a[f];
+    warp_fused_body(a, b.tab[f], b.ntiles[f], (int)blockIdx.x, b.nwg[f], stage_all);
+}
+__global__ __launch_bounds__(256) void warp_trig_batch_kernel(WarpBatch b) {
+    const int f = blockIdx.y;
+    const WarpArgs& a = b.a[f];
+    float* tab = const_cast<float*>(b.tab[f]);
+    const int i = blockIdx.x * 256 + threadIdx.x, ncol = trig_cols(a.dw);
+    if (i < ncol) {
+        float u = (float)(a.tlx + i) / a.scale;
+        mis_sincosf(u, &tab[2 * i], &tab[2 * i + 1]);
+    } else if (i < ncol + a.dh) {
+        const int r = i - ncol;
+        float v = (float)(a.tly + r) / a.scale, s, c;
+        mis_sincosf(MIS_PI_F - v, &s, &c);
+        float* t = tab + 2 * ncol + 4 * r;
+        t[0] = s; t[1] = a.m[1] * c; t[2] = a.m[4] * c; t[3] = a.m[7] * c;
+    }
 }
 
 // General warp (seam-scale path and plain masks): u8 with CN channels, one column per lane.
@@ -735,6 +773,7 @@ extern "C" int mis_warp_spherical(MisContext* ctx, const MisImage* src, float sc
     return MIS_OK;
 }
 
+static int grid_of(const WarpArgs& a, int* ntiles);
 static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, const float K[9], const float R[9],
                            MisImage* dst, MisImage* dmask, MisPoint* tl, int repeats, float* avg_us, const MisRect* known_roi = nullptr) {
     if (!ctx) return MIS_E_INVALID;
@@ -760,14 +799,8 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
     }
     float* tab = (float*)ctx->stage;
     hipLaunchKernelGGL(warp_trig_kernel, dim3((trig_cols(a.dw) + a.dh + 255) / 256), dim3(256), 0, ctx->stream, a, tab);
-    const int ntiles = ((a.dw + FT_W - 1) / FT_W) * ((a.dh + FT_H - 1) / FT_H);
-#if WV_ORDER == 2
-    // whole chunks, a multiple of 8 of them (workgroups past the tile grid return at once)
-    const int nchunks = (((a.dw + FT_W - 1) / FT_W + CH_W - 1) / CH_W) * (((a.dh + FT_H - 1) / FT_H + CH_H - 1) / CH_H);
-    const int nwg = ((nchunks + 7) / 8) * 8 * (CH_W / TILE_WAVES) * CH_H;
-#else
-    const int nwg = (ntiles + TILE_WAVES - 1) / TILE_WAVES;
-#endif
+    int ntiles;
+    const int nwg = grid_of(a, &ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (avg_us) {
         MIS_HIP(ctx, hipEventCreate(&e0));
@@ -803,6 +836,108 @@ extern "C" int mis_warp_spherical_fused_roi(MisContext* ctx, const MisImage* src
     if (!ctx) return MIS_E_INVALID;
     MIS_CHECK(ctx, roi && roi->width > 0 && roi->height > 0, MIS_E_INVALID, "empty roi");
     return warp_fused_impl(ctx, src, scale, K, R, dst, dmask, tl, 1, nullptr, roi);
+}
+
+static int grid_of(const WarpArgs& a, int* ntiles) {
+    *ntiles = ((a.dw + FT_W - 1) / FT_W) * ((a.dh + FT_H - 1) / FT_H);
+#if WV_ORDER == 2
+    // whole chunks, a multiple of 8 of them (workgroups past the tile grid return at once)
+    const int nchunks = (((a.dw + FT_W - 1) / FT_W + CH_W - 1) / CH_W) * (((a.dh + FT_H - 1) / FT_H + CH_H - 1) / CH_H);
+    return ((nchunks + 7) / 8) * 8 * (CH_W / TILE_WAVES) * CH_H;
+#else
+    return (*ntiles + TILE_WAVES - 1) / TILE_WAVES;
+#endif
+}
+
+// n fused warps (the loop of image_stitching.cpp:1154-1164 for all frames) in one grid per WB_MAX frames; the results are those of
+// n mis_warp_spherical_fused_roi calls.  repeats / avg_us: the batch launched `repeats` times back to back between two HIP events
+// (avg_us = the average duration of one pass over all n frames), for the roofline measurement.
+static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois,
+                                 MisImage* dsts, MisImage* dmasks, MisPoint* tls, int repeats, float* avg_us) {
+    MIS_CHECK(ctx, srcs && Ks && Rs && rois && dsts && dmasks && n >= 1, MIS_E_INVALID, "null argument");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<WarpArgs> args((size_t)n);
+    std::vector<DevImage> din((size_t)n), dout((size_t)n), dm((size_t)n);
+    std::vector<size_t> tab_off((size_t)n);
+    size_t tab_total = 0;
+    int rc = MIS_OK, got = 0;
+    for (; got < n; got++) {
+        const int i = got;
+        WarpArgs& a = args[i];
+        int brx, bry;
+        MIS_CHECK(ctx, rois[i].width > 0 && rois[i].height > 0, MIS_E_INVALID, "frame %d: empty roi", i);
+        if ((rc = setup(ctx, &srcs[i], scale, Ks + 9 * i, Rs + 9 * i, &a, &brx, &bry, &rois[i])) != MIS_OK) break;
+        if (srcs[i].channels != 3) { rc = mis_set_error(ctx, MIS_E_UNSUPPORTED, "fused warp needs an 8UC3 source"); break; }
+        if ((rc = mis_dev_image_in(ctx, &srcs[i], &din[i])) != MIS_OK) break;
+        if ((rc = mis_dev_image_out(ctx, &dsts[i], a.dw, a.dh, 3, MIS_S16, &dout[i])) != MIS_OK) break;
+        if ((rc = mis_dev_image_out(ctx, &dmasks[i], a.dw, a.dh, 1, MIS_U8, &dm[i])) != MIS_OK) break;
+        if (!(dout[i].stride % 4 == 0 && dm[i].stride % 2 == 0 && ((uintptr_t)dout[i].data % 4) == 0 && ((uintptr_t)dm[i].data % 2) == 0)) {
+            rc = mis_set_error(ctx, MIS_E_INVALID, "fused warp outputs need 4-byte (image) / 2-byte (mask) aligned rows"); break;
+        }
+        a.src = (const uint8_t*)din[i].data; a.sstride = din[i].stride;
+        a.dst = dout[i].data; a.dstride = dout[i].stride; a.mask = (uint8_t*)dm[i].data; a.mstride = dm[i].stride;
+        tab_off[i] = tab_total;
+        tab_total += mis_align_up(sizeof(float) * trig_table_floats(a.dw, a.dh), 256);
+    }
+    if (rc != MIS_OK) return rc;
+    if (ctx->stage_bytes < tab_total) {
+        if (ctx->stage) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+        MIS_HIP(ctx, hipMalloc(&ctx->stage, tab_total * 2 + 4096));
+        ctx->stage_bytes = tab_total * 2 + 4096;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<WarpBatch> batches;
+    std::vector<dim3> grids;
+    for (int g0 = 0; g0 < n; g0 += WB_MAX) {
+        const int ng = std::min(WB_MAX, n - g0);
+        WarpBatch b;
+        int max_wg = 0, max_trig = 0;
+        for (int k = 0; k < WB_MAX; k++) {
+            const int i = g0 + (k < ng ? k : 0);
+            b.a[k] = args[i]; b.tab[k] = (const float*)((uint8_t*)ctx->stage + tab_off[i]);
+            b.nwg[k] = grid_of(args[i], &b.ntiles[k]);
+            if (k < ng) { max_wg = std::max(max_wg, b.nwg[k]); max_trig = std::max(max_trig, (trig_cols(args[i].dw) + args[i].dh + 255) / 256); }
+        }
+        hipLaunchKernelGGL(warp_trig_batch_kernel, dim3(max_trig, ng), dim3(256), 0, ctx->stream, b);
+        batches.push_back(b); grids.push_back(dim3(max_wg, ng));
+    }
+    if (avg_us) {
+        MIS_HIP(ctx, hipEventCreate(&e0));
+        MIS_HIP(ctx, hipEventCreate(&e1));
+        MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    for (int rep = 0; rep < repeats; rep++)
+        for (size_t g = 0; g < batches.size(); g++)
+            hipLaunchKernelGGL(warp_fused_batch_kernel, grids[g], dim3(64 * TILE_WAVES), 0, ctx->stream, batches[g]);
+    if (avg_us) {
+        float ms = 0.f;
+        MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        MIS_HIP(ctx, hipEventSynchronize(e1));
+        MIS_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = ms * 1000.f / (float)repeats;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    for (int i = 0; i < n; i++) {
+        int r1 = mis_dev_image_commit(ctx, &dsts[i], &dout[i]), r2 = mis_dev_image_commit(ctx, &dmasks[i], &dm[i]), r3 = mis_dev_image_release(ctx, &din[i]);
+        if (rc == MIS_OK) rc = r1 != MIS_OK ? r1 : (r2 != MIS_OK ? r2 : r3);
+        if (tls) { tls[i].x = args[i].tlx; tls[i].y = args[i].tly; }
+    }
+    return rc;
+}
+
+extern "C" int mis_warp_spherical_fused_batch(MisContext* ctx, const MisImage* srcs, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois,
+                                              MisImage* dsts, MisImage* dmasks, MisPoint* tls) {
+    if (!ctx) return MIS_E_INVALID;
+    if (n == 0) return MIS_OK;
+    return warp_fused_batch_impl(ctx, srcs, n, scale, Ks, Rs, rois, dsts, dmasks, tls, 1, nullptr);
+}
+
+extern "C" int mis_warp_spherical_fused_batch_timed(MisContext* ctx, const MisImage* srcs, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois,
+                                                    MisImage* dsts, MisImage* dmasks, MisPoint* tls, int repeats, float* avg_us) {
+    if (!ctx) return MIS_E_INVALID;
+    MIS_CHECK(ctx, repeats >= 1 && avg_us && n >= 1, MIS_E_INVALID, "repeats must be >= 1, n >= 1 and avg_us non-null");
+    return warp_fused_batch_impl(ctx, srcs, n, scale, Ks, Rs, rois, dsts, dmasks, tls, repeats, avg_us);
 }
 
 extern "C" int mis_warp_roi_batch(MisContext* ctx, float scale, int w, int h, int n, const float* Ks, const float* Rs, MisRect* rois) {

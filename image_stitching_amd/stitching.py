@@ -184,6 +184,23 @@ class SphericalWarper:
                                                                  C.byref(mimg), C.byref(tl)))
         return (tl.x, tl.y)
 
+    def warp_fused_batch_timed(self, imgs, cameras, rois, dsts, masks, repeats):
+        """mis_warp_spherical_fused_batch_timed: the fused warps of all frames in one grid per 16 frames, launched `repeats` times
+        back to back between two HIP events on the context's stream -> average microseconds of one pass over all frames."""
+        n = len(imgs)
+        im = (capi.MisImage * n)(*[as_image(i) for i in imgs])
+        ds = (capi.MisImage * n)(*[as_image(d) for d in dsts])
+        ms = (capi.MisImage * n)(*[as_image(m) for m in masks])
+        Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cameras]))
+        Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cameras]))
+        rs = (capi.MisRect * n)(*[capi.MisRect(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in rois])
+        tls = (capi.MisPoint * n)()
+        us = C.c_float()
+        fp = C.POINTER(C.c_float)
+        self.ctx.check(self.ctx.lib.mis_warp_spherical_fused_batch_timed(self.ctx.h, im, n, float(self.scale), Ks.ctypes.data_as(fp), Rs.ctypes.data_as(fp), rs, ds, ms, tls,
+                                                                        int(repeats), C.byref(us)))
+        return us.value
+
     def warp_fused_timed(self, src_bgr, K, R, roi, dst, msk, repeats):
         """Average duration (us) of the fused warp kernel over `repeats` back-to-back launches (HIP events)."""
         simg, dimg, mimg = as_image(src_bgr), as_image(dst), as_image(msk)

@@ -209,6 +209,14 @@ int mis_warp_spherical_fused(MisContext* ctx, const MisImage* src_bgr, float sca
  * source size): skips the border walk the reference repeats inside warp() -- the compose loop's form (:1138 then :1154). */
 int mis_warp_spherical_fused_roi(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
                                  const MisRect* roi, MisImage* dst_s16x3, MisImage* dst_mask, MisPoint* tl);
+/* the fused warps of n frames (the loop :1086-1220 for all of them) in one grid per 16 frames: the results of n
+ * mis_warp_spherical_fused_roi calls (dsts[i] / dmasks[i]: caller's buffers or NULL data as there), without a launch of its own per
+ * frame -- a 4K frame alone fills and drains the device for a quarter of its launch */
+int mis_warp_spherical_fused_batch(MisContext* ctx, const MisImage* srcs_u8x3, int n, float scale, const float* Ks, const float* Rs, const MisRect* rois,
+                                   MisImage* dsts_s16x3, MisImage* dmasks_u8, MisPoint* tls);
+/* measurement aid (bench.py): the batch launched `repeats` times between two HIP events on the context's stream; *avg_us = one pass */
+int mis_warp_spherical_fused_batch_timed(MisContext* ctx, const MisImage* srcs_u8x3, int n, float scale, const float* Ks, const float* Rs,
+                                         const MisRect* rois, MisImage* dsts_s16x3, MisImage* dmasks_u8, MisPoint* tls, int repeats, float* avg_us);
 /* measurement aid: the same warp with the main kernel launched `repeats` times back to back on the context's
  * stream between two HIP events; *avg_us = average kernel duration (bench.py's roofline leg: no host gaps). */
 int mis_warp_spherical_fused_timed(MisContext* ctx, const MisImage* src_bgr, float scale, const float K[9], const float R[9],
