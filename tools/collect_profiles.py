@@ -22,8 +22,10 @@ b = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()
 cfg = b["config"]
 out = {"version": ver, "frame_size": cfg["frame_size"], "workload": cfg["workload"],
        "correction": feed["correction"] + " -- calibrated for wide (16 B per lane) streaming reads only; the blend kernels read dwords / 8-byte pixels, so their doubled FETCH_SIZE is an upper estimate",
-       "warp": {"kernel": "warp_fused_kernel", "traffic_bytes_per_launch": warp["kernels"]["warp_fused_kernel"]["traffic_bytes_per_dispatch"],
-                "FETCH_SIZE_KiB": warp["kernels"]["warp_fused_kernel"]["FETCH_SIZE_KiB_per_dispatch"], "WRITE_SIZE_KiB": warp["kernels"]["warp_fused_kernel"]["WRITE_SIZE_KiB_per_dispatch"]},
+       "warp": {"kernel": "warp_fused_kernel (one frame per launch; warp_fused_batch_kernel moves the same bytes per frame: see batch_16_frames)",
+                "traffic_bytes_per_launch": warp["kernels"]["warp_fused_kernel"]["traffic_bytes_per_dispatch"],
+                "FETCH_SIZE_KiB": warp["kernels"]["warp_fused_kernel"]["FETCH_SIZE_KiB_per_dispatch"], "WRITE_SIZE_KiB": warp["kernels"]["warp_fused_kernel"]["WRITE_SIZE_KiB_per_dispatch"],
+                "batch_16_frames": warp["kernels"].get("warp_fused_batch_kernel")},
        "feed": {"traffic_bytes_per_frame": feed["traffic_bytes_per_unit"], "kernels": feed["kernels"]},
        "finalize": {"traffic_bytes_per_panorama": fin["traffic_bytes_per_unit"], "kernels": fin["kernels"]}}
 json.dump(out, open(os.path.join(dst, "r02_traffic_pmc.json"), "w"), indent=1)

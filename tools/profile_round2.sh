@@ -12,10 +12,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -o b -- python3 $R/bench.py --roofline-only > $O/roofline.log 2>&1
 cd $R
 # PMC passes (feed_only.py runs the roofline legs: 16 feeds x 2 passes + 2 finalises; warp 3 x 200 + warm-up launches)
-bash tools/pmc_feed.sh > $O/feed_pmc_summary.txt 2>&1
-python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/feed_pmc.json 32 pyr_down_view_kernel feed_accumulate_kernel feed_tail_build_kernel > /dev/null
+# (MIS_ROOFLINE_BATCH_ONLY: the feed leg through mis_blender_feed_batch only -- the counters are averaged per kernel name)
+MIS_ROOFLINE_BATCH_ONLY=1 bash tools/pmc_feed.sh > $O/feed_pmc_summary.txt 2>&1
+python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/feed_pmc.json 32 pyr_down_l1_batch_kernel pyr_down_level_batch_kernel feed_tail_build_kernel feed_gather_kernel > /dev/null
 python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/finalize_pmc.json 2 normalize_kernel collapse2x2_kernel collapse2x2_final_kernel finalize_kernel > /dev/null
-python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/warp_pmc_raw.json 1 warp_fused_kernel > /dev/null
+python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/warp_pmc_raw.json 1 warp_fused_kernel warp_fused_batch_kernel > /dev/null
 python3 bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
 python3 bench.py --workload config4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4_1gpu.json 2> $O/bench_config4_1gpu.err
 tail -1 $O/bench.json | cut -c1-300
