@@ -52,10 +52,13 @@ class Comm:
     """Thin wrapper over torch.distributed (nccl = RCCL on GPUs, gloo on CPU); identity when world = 1.
     With the gloo backend device tensors are staged through host memory (rehearsals of the N > 1 path on one GPU)."""
 
-    def __init__(self, rank=0, world=1, group=None):
+    def __init__(self, rank=0, world=1, group=None, always_collective=False):
         self.rank, self.world, self.group = rank, world, group
         self._stage = False
-        if world > 1:
+        # always_collective: issue the collectives even in a group of one rank (a one-GPU rehearsal of the RCCL calls of the N > 1 path:
+        # dtypes, split sizes, stream ordering); needs an initialised process group
+        self._solo = world == 1 and not always_collective
+        if not self._solo:
             import torch.distributed as dist
             self._stage = dist.get_backend(group) == "gloo"
 
@@ -63,7 +66,7 @@ class Comm:
         return t.cpu() if (self._stage and t.is_cuda) else t
 
     def all_gather(self, t):
-        if self.world == 1:
+        if self._solo:
             return t.unsqueeze(0)
         import torch.distributed as dist
         src = self._h(t).contiguous()
@@ -72,7 +75,7 @@ class Comm:
         return out.to(t.device)
 
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if not self._solo:
             import torch.distributed as dist
             h = self._h(t)
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -83,7 +86,7 @@ class Comm:
     def all_to_all_bytes(self, send, recv_sizes):
         """send: list of world 1-D uint8 tensors (send[k] goes to rank k) -> list of world tensors (recv[r] came from rank r,
         recv_sizes[r] bytes).  One collective (NCCL / RCCL all_to_all_single with split sizes); isend / irecv pairs under gloo."""
-        if self.world == 1:
+        if self._solo:
             return [send[0]]
         import torch.distributed as dist
         dev = send[0].device
@@ -114,7 +117,7 @@ class Comm:
 
     def all_gather_objects(self, obj):
         """Small host-side records of every rank (pickled by torch.distributed) -> list in rank order."""
-        if self.world == 1:
+        if self._solo:
             return [obj]
         import torch.distributed as dist
         out = [None] * self.world
@@ -123,7 +126,7 @@ class Comm:
 
     def gather_to_root(self, t):
         """Equal-sized 1-D tensors -> list of world tensors on rank 0 (None elsewhere)."""
-        if self.world == 1:
+        if self._solo:
             return [t]
         import torch.distributed as dist
         h = self._h(t)
@@ -403,14 +406,14 @@ class HipEngine:
 class StitchJob:
     """The hot-path sequence of main() (image_stitching.cpp:567-1228) for one panorama, sharded."""
 
-    def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False):
+    def __init__(self, ctx, frame_size, cameras, rank=0, world_size=1, group=None, engine=None, config=None, force_collectives=False, always_collective=False):
         self.cfg = config or st.StitchConfig.hot_path()
         st.check_seam_config(self.cfg)
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
         self.n = len(cameras)
         self.rank, self.world = rank, world_size
-        self.comm = Comm(rank, world_size, group)
+        self.comm = Comm(rank, world_size, group, always_collective)
         self.my_frames = frame_block(self.n, rank, world_size)
         self.frame_size = frame_size
         self.scale = st.Stitcher.warped_image_scale(cameras)

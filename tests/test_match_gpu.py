@@ -264,3 +264,33 @@ def test_three_chain_matcher_flow_gives_identical_results(tmp_path):
         assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
         ran += k.startswith("n") and int(a[k]) > 0
     assert ran >= 10      # adjacent frames do have inliers: the second estimation was exercised
+
+
+def test_enqueue_hook_runs_once_inside_the_next_call(ctx, oracle_mod):
+    """mis_match_on_enqueued: the hook runs on the calling thread of the next matcher call (after its work is enqueued), once;
+    a cleared hook does not run; the matches are those of a call without a hook."""
+    import ctypes as C
+    import threading
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    w, h = 480, 270
+    cams = [synth.make_camera(w, h, 60.0, 14.0 * i - 14.0, 0.0, 0.0) for i in range(3)]
+    finder = isa.OrbFeatureFinder(ctx, (w, h))
+    feats = [isa.computeImageFeatures(finder, torch.from_numpy(synth.render_frame(c)).cuda(), i) for i, c in enumerate(cams)]
+    matcher = isa.BestOf2NearestMatcher(ctx, 0.32)
+    ref = matcher(feats)
+    seen = []
+    cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _u: seen.append((threading.get_ident(), int(ctx.lib.mis_match_sequence(ctx.h)))))
+    seq0 = int(ctx.lib.mis_match_sequence(ctx.h))
+    ctx.check(ctx.lib.mis_match_on_enqueued(ctx.h, C.cast(cb, C.c_void_p), None))
+    a = matcher(feats)
+    b = matcher(feats)                      # the hook was one-shot
+    assert seen == [(threading.get_ident(), seq0 + 1)]
+    ctx.check(ctx.lib.mis_match_on_enqueued(ctx.h, C.cast(cb, C.c_void_p), None))
+    ctx.check(ctx.lib.mis_match_on_enqueued(ctx.h, None, None))
+    matcher(feats)
+    assert len(seen) == 1
+    for x, y, z in zip(ref, a, b):
+        assert np.array_equal(x.matches, y.matches) and np.array_equal(x.matches, z.matches)
+        assert x.confidence == y.confidence == z.confidence

@@ -93,3 +93,38 @@ def test_warp_full_size_properties(ctx):
     _, wb, _ = warper.warp_fused(b, K, R)
     _, wab, _ = warper.warp_fused(a + b, K, R)
     assert int((wa.int() + wb.int() - wab.int()).abs().max()) <= 1
+
+
+def test_fused_batch_equals_single_launches(ctx):
+    """mis_warp_spherical_fused_batch (all frames in one grid per 16 frames; 18 frames = two grids, two frame sizes' worth of
+    rois) writes what 18 mis_warp_spherical_fused_roi calls write."""
+    import ctypes as C
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    from image_stitching_amd import _capi as capi
+    from image_stitching_amd.stitching import as_image
+    w, h = 640, 360
+    cams = [synth.make_camera(w, h, 60.0, 9.0 * i - 70.0, 0.6 * ((i % 3) - 1), 0.5 * ((i % 2) - 0.5)) for i in range(18)]
+    frames = [torch.from_numpy(synth.render_frame(c)).cuda() for c in cams]
+    scale = isa.Stitcher.warped_image_scale(cams)
+    warper = isa.SphericalWarper(ctx, scale)
+    rois = isa.stitching.warp_rois(ctx, scale, (w, h), cams)
+    single = [warper.warp_fused(f, c["K"], c["R"], r) for f, c, r in zip(frames, cams, rois)]
+    outs = [warper.alloc_fused(r) for r in rois]
+    for o in outs:
+        o[0].fill_(-7); o[1].fill_(9)
+    n = len(cams)
+    im = (capi.MisImage * n)(*[as_image(f) for f in frames])
+    ds = (capi.MisImage * n)(*[as_image(o[0]) for o in outs])
+    ms = (capi.MisImage * n)(*[as_image(o[1]) for o in outs])
+    Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cams]))
+    Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cams]))
+    rr = (capi.MisRect * n)(*[capi.MisRect(*[int(v) for v in r]) for r in rois])
+    tls = (capi.MisPoint * n)()
+    fp = C.POINTER(C.c_float)
+    ctx.check(ctx.lib.mis_warp_spherical_fused_batch(ctx.h, im, n, float(scale), Ks.ctypes.data_as(fp), Rs.ctypes.data_as(fp), rr, ds, ms, tls))
+    ctx.synchronize()
+    for (tl, img, msk), (bi, bm), t, r in zip(single, outs, tls, rois):
+        assert (t.x, t.y) == tuple(tl) == (r[0], r[1])
+        assert torch.equal(bi, img) and torch.equal(bm, msk)
