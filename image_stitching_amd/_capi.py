@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmistitch.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mistitch.h")
 
 MIS_OK = 0
+MIS_FENCE_TIMEOUT = 1
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, S16, F32 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1

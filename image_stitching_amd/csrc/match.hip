@@ -715,7 +715,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // pinned host mirror of everything that comes back
     Carver hc;
     const size_t h_in = hc.take(sizeof(FeatDev) * n + sizeof(PairDesc) * np + sizeof(HmFrame) * n + 1024), h_nm = hc.take(sizeof(int) * np), h_out = hc.take(sizeof(PairOut) * np),
-                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total);
+                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total), h_bad = hc.take(256);
     MIS_HIP(ctx, ws->pinned.reserve(hc.off));
     uint8_t* Hh = (uint8_t*)ws->pinned.p;
     memcpy(Hh + h_in, fd.data(), sizeof(FeatDev) * n);
@@ -723,7 +723,9 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     memcpy(h_pairs, pairs.data(), sizeof(PairDesc) * np);
     MIS_HIP(ctx, hipMemcpyAsync(d_feats, Hh + h_in, sizeof(FeatDev) * n, hipMemcpyHostToDevice, st));
     MIS_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(PairDesc) * np, hipMemcpyHostToDevice, st));
-    int l2_bad = 0;
+    // flag of the L2 path (non-integer descriptors), copied into the pinned arena: an early return never leaves a copy aimed at this frame
+    volatile int& l2_bad = *reinterpret_cast<volatile int*>(Hh + h_bad);
+    l2_bad = 0;
     static const bool hm_scalar = getenv("MIS_KNN_SCALAR") != nullptr;     // diagnostics: the vector-pipe kernel
     if (!use_l2 && (maxq > HM_MAX_TRAINS || hm_scalar)) {
         hipLaunchKernelGGL(knn2_hamming_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, d_idx, d_dist);
@@ -764,7 +766,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             l2_knn2_launch(st, ctx->num_cu, A, B, L + o_part, d_idx + 2 * pd.knn_off12, d_dist + 2 * pd.knn_off12);
             l2_knn2_launch(st, ctx->num_cu, B, A, L + o_part, d_idx + 2 * pd.knn_off21, d_dist + 2 * pd.knn_off21);
         }
-        MIS_HIP(ctx, hipMemcpyAsync(&l2_bad, L + o_bad, 4, hipMemcpyDeviceToHost, st));
+        MIS_HIP(ctx, hipMemcpyAsync(Hh + h_bad, L + o_bad, 4, hipMemcpyDeviceToHost, st));
     }
     // the 2-NN pass fills the device on its own; what follows are latency-bound chains.  Work that wants to share the
     // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
@@ -783,6 +785,9 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     }
     const double rt = p->ransac_thresh, cf = p->confidence;
     bool early_lists = false;
+    // everything between the forks to the auxiliary streams and their joins runs inside one scope: an error in there must not
+    // leave those streams with work pending (they are the context's, shared with the feature finders) or a copy in flight
+    auto enqueue_chains = [&]() -> int {
     static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 3;   // 2: the two-chain flow below
     if (chains != 3) {
     // first estimation, phase 0 up to the replay's verdict (pairs with a clear overlap finish here)
@@ -847,6 +852,14 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_third_done, 0));
     }
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_side_done, 0));
+    return MIS_OK;
+    };
+    if ((rc = enqueue_chains()) != MIS_OK) {
+        if (ws->side) hipStreamSynchronize(ws->side);
+        if (ws->third) hipStreamSynchronize(ws->third);
+        hipStreamSynchronize(st);
+        return rc;
+    }
     MIS_HIP(ctx, hipGetLastError());
     int* nm = (int*)(Hh + h_nm);
     PairOut* po = (PairOut*)(Hh + h_out);
@@ -979,7 +992,7 @@ extern "C" int mis_match_knn_fence(MisContext* ctx, void* stream, long long targ
     MIS_CHECK(ctx, ws, MIS_E_STATE, "mis_match_sequence must have been called on this context first");
     const auto t0 = std::chrono::steady_clock::now();
     while (ws->knn_seq.load() < target_seq) {
-        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return MIS_OK;
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return MIS_FENCE_TIMEOUT;   // not an error: `stream` was not queued behind anything
         std::this_thread::yield();
     }
     if (stream && ws->ev_knn && hipStreamWaitEvent((hipStream_t)stream, ws->ev_knn, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");

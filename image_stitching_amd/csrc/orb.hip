@@ -1082,11 +1082,22 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
         for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
     }
     std::vector<DevImage> dimg(n);
+    for (int i = 0; i < n; i++) memset(&out[i], 0, sizeof(MisFeatures));
+    // an error after the fork must not leave the helper streams (the context's auxiliary streams) with work pending, nor leak the
+    // outputs / staged inputs of the frames already set up
+    auto fail = [&](int code) {
+        for (MisOrb* hlp : o->helpers) hipStreamSynchronize(hlp->ctx->stream);
+        hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i < n; i++) {
+            if (out[i].keypoints || out[i].descriptors) mis_features_free(ctx, &out[i]);
+            if (dimg[i].data) mis_dev_image_release(ctx, &dimg[i]);
+        }
+        return code;
+    };
     for (int i = 0; i < n; i++) {
-        memset(&out[i], 0, sizeof(MisFeatures));
         out[i].img_idx = i; out[i].img_w = imgs[i].width; out[i].img_h = imgs[i].height;
-        if ((rc = alloc_features(ctx, o->out_cap, 32, MIS_U8, &out[i])) != MIS_OK) return rc;
-        if ((rc = mis_dev_image_in(ctx, &imgs[i], &dimg[i])) != MIS_OK) return rc;
+        if ((rc = alloc_features(ctx, o->out_cap, 32, MIS_U8, &out[i])) != MIS_OK) return fail(rc);
+        if ((rc = mis_dev_image_in(ctx, &imgs[i], &dimg[i])) != MIS_OK) return fail(rc);
     }
     if (n > 1) {   // staged host inputs were copied on the context's stream after the fork event: fork again behind them
         bool staged = false;
@@ -1101,7 +1112,7 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
     for (int i = 0; i < n; i++) {
         MisOrb* lane = lanes[i % lanes.size()];
         if ((rc = enqueue_detect(lane, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK)
-            return lane == o ? rc : mis_set_error(ctx, rc, "helper finder: %s", lane->ctx->err.c_str());
+            return fail(lane == o ? rc : mis_set_error(ctx, rc, "helper finder: %s", lane->ctx->err.c_str()));
     }
     if (trace) fprintf(stderr, "orb batch: %d frames enqueued in %.0f us\n", n, (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_enq0).count());
     // join: the context's stream continues after every helper chain

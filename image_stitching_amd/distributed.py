@@ -314,7 +314,12 @@ class HipEngine:
         pass fills the device, the RANSAC chains after it do not -- composing from there on costs the matcher nothing
         (measured: 0.5 ms per 16 x 4K step against starting at once)."""
         import os
-        self.ctx.check(self.ctx.lib.mis_match_knn_fence(self.ctx.h, None if os.environ.get('MIS_COMPOSE_GPU_FENCE') == '0' else self._compose_stream_handle, target_seq, 50))
+        rc = self.ctx.lib.mis_match_knn_fence(self.ctx.h, None if os.environ.get('MIS_COMPOSE_GPU_FENCE') == '0' else self._compose_stream_handle, target_seq, 50)
+        if rc == 1:      # MIS_FENCE_TIMEOUT: the matcher call did not show up (a first call that allocates its arenas can take longer)
+            # no fence, only less overlap control: the frames' producer was ordered before the compose stream at run() entry
+            self.fence_timeouts = getattr(self, "fence_timeouts", 0) + 1
+        elif rc != 0:
+            self.ctx.check(rc)
 
     def warp_feed_many(self, frames, cams, rois):
         """warp_feed for a list of frames in one library call (no interpreter work between the launches: the thread that

@@ -34,6 +34,7 @@ extern "C" {
 #define MIS_E_OVERFLOW (-4)    /* an internal candidate buffer was too small for the input */
 #define MIS_E_STATE (-5)       /* call order violated (e.g. feed before prepare) */
 #define MIS_E_UNSUPPORTED (-6)
+#define MIS_FENCE_TIMEOUT 1     /* mis_match_knn_fence only, not an error: the matcher call did not show up within the timeout, nothing was queued */
 
 enum { MIS_MEM_HOST = 0, MIS_MEM_DEVICE = 1 };
 enum { MIS_U8 = 0, MIS_S16 = 1, MIS_F32 = 2 };
