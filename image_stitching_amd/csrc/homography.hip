@@ -525,18 +525,39 @@ __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, con
     double H[9];
     const CSlot s{sl + t};
     int ok = dlt4_compact(ms1, ms2, s, H);
-    int cnt = 0;
     if (ok) {
-        float Hf[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) Hf[i] = (float)H[i];
-        for (int i = 0; i < c.n; i++) cnt += is_inlier(Hf, c.src[2 * i], c.src[2 * i + 1], c.dst[2 * i], c.dst[2 * i + 1], thr);
         double* o = Hc + ((size_t)b * max_iters + k) * 9;
 #pragma unroll
         for (int i = 0; i < 9; i++) o[i] = H[i];
     }
     valid[(size_t)b * max_iters + k] = ok;
-    good[(size_t)b * max_iters + k] = cnt;
+    (void)good; (void)thr;     // the inlier counts are hyp_count_kernel's
+}
+
+// findInliers of every hypothesis of hyp_kernel: one wave per hypothesis, lanes over the points (the per-thread loop over all
+// matches was a third of hyp_kernel's latency for a well-matched pair: 1500 points x 30 instructions behind the Jacobi solve)
+__global__ __launch_bounds__(256) void hyp_count_kernel(const HomoCall* calls, const RansacState* states, const double* Hc, const int* valid, int* good, int lo,
+                                                        int max_iters, float thr) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const RansacState st = states[b];
+    if (st.mode != 2 || st.done) return;
+    const int limit = min(st.n_sub, st.niters);
+    const int k = lo + blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (k >= limit) return;      // wave-uniform
+    const size_t e = (size_t)b * max_iters + k;
+    int cnt = 0;
+    if (valid[e]) {
+        const HomoCall c = calls[b];
+        float Hf[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Hf[i] = (float)Hc[e * 9 + i];
+        for (int i0 = 0; i0 < c.n; i0 += 64) {
+            const int i = i0 + lane;
+            const int f = i < c.n ? is_inlier(Hf, c.src[2 * i], c.src[2 * i + 1], c.dst[2 * i], c.dst[2 * i + 1], thr) : 0;
+            cnt += __popcll(__ballot(f));
+        }
+    }
+    if (lane == 0) good[e] = cnt;
 }
 
 // ---------------------------------------------------------------- scan_tail_kernel -------------
@@ -1163,6 +1184,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
         hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
+        hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
                            max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0);
     }
@@ -1178,6 +1200,8 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
+        hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
+                           max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
                            max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0);
     }
