@@ -19,3 +19,11 @@ e1.record(); torch.cuda.synchronize()
 print("roi", roi, "avg us (host-paced launches)", e0.elapsed_time(e1) / n * 1e3)
 for _ in range(3):
     print("back-to-back kernel avg us", w.warp_fused_timed(frame, cam["K"], cam["R"], roi, dst, msk, 200))
+# the compose loop's form: all 16 frames in one grid (mis_warp_spherical_fused_batch)
+rois = isa.stitching.warp_rois(ctx, scale, (3840, 2160), cams)
+fr = [synth.render_frame_gpu(c) for c in cams]
+outs = [w.alloc_fused(r) for r in rois]
+args = (fr, cams, rois, [o[0] for o in outs], [o[1] for o in outs])
+w.warp_fused_batch_timed(*args, 5)
+for _ in range(3):
+    print("batched grid avg us per frame", w.warp_fused_batch_timed(*args, 12) / len(cams))
