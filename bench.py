@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, help="config2 | config3 | config4 (default: config3, config4 when --gpus > 1)")
     ap.add_argument("--features", default=None, help="orb | sift (default: orb; sift for config5, BASELINE.json configs[4])")
+    ap.add_argument("--pipeline", default="hot_path", choices=["hot_path", "reference_default"],
+                    help="hot_path (the north star: no exposure / seam step) | reference_default (gain_blocks compensator + dp_color seams, rows N1b; not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
     ap.add_argument("--no-single-base", action="store_true", help="N > 1: skip the unsharded run of the same workload on rank 0")
@@ -80,7 +82,8 @@ def main():
     W, H = cams[0]["width"], cams[0]["height"]
     ctx = isa.Context(local_rank)
     features = args.features or ("sift" if workload == "config5" else "orb")
-    cfg = isa.StitchConfig.hot_path(features_type=features)   # the north-star path: no exposure / seam step (SURVEY rows N1b are "next")
+    # the north-star path: no exposure / seam step (SURVEY rows N1b are "next"); --pipeline reference_default times the job with them
+    cfg = isa.StitchConfig.hot_path(features_type=features) if args.pipeline == "hot_path" else isa.StitchConfig(features_type=features)
     job = misdist.StitchJob(ctx, (W, H), cams, rank=rank, world_size=world, group=pg, config=cfg)
     # synthetic frames of this rank's shard, rendered straight into HBM
     frames = {i: synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in job.my_frames}
@@ -157,7 +160,7 @@ def main():
     cpu = None
     if rank == 0:
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
-        if not args.no_cpu_baseline and features == "orb" and world == 1:     # the CPU baseline is an N = 1 item
+        if not args.no_cpu_baseline and features == "orb" and world == 1 and args.pipeline == "hot_path":     # the CPU baseline is an N = 1 item
             cpu = cpu_baseline(cams, workload, frames)
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
@@ -168,6 +171,7 @@ def main():
                                    % (workload, n, W, H, "SIFT (128-D f32, L2 on fp16 MFMA)" if features == "sift" else "ORB 4000"),
                        "frames": n, "frame_size": [W, H], "pairs": n * (n - 1) // 2, "pano_size": list(out["pano_size"]),
                        "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world),
+                       "pipeline": args.pipeline,
                        "warp_roi": "computed inside every timed step (mis_warp_roi_batch: one kernel for all frames, nothing cached)"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -34,9 +34,12 @@ struct MisContext {
     // pinned, device-visible host block of mis_warp_roi_batch (jobs in, extremes out)
     void* roi_pinned = nullptr;
     size_t roi_pinned_bytes = 0;
+    void* host_stage = nullptr;      // pinned host scratch of host-logic entries (mis_seam_dp): grow-only, see mis_host_stage
+    size_t host_stage_bytes = 0;
 };
 
 int mis_set_error(MisContext* ctx, int code, const char* fmt, ...);
+int mis_host_stage(MisContext* ctx, size_t bytes, void** out);   // pinned scratch of at least `bytes` (valid until the next call)
 int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got);
 int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out);   // k = 0, 1
 void mis_pool_free(MisContext* ctx, void* p, size_t bytes);

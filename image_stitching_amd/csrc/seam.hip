@@ -10,6 +10,9 @@
 #include "common.h"
 #include "dev_math.h"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -19,6 +22,8 @@
 #include <vector>
 
 namespace {
+static std::atomic<long long> g_seam_ns[8];   // MIS_SEAM_TRACE: setup, components, edges, tips, estimate, update labels, rescan, masks
+struct SeamTimer { int i; std::chrono::steady_clock::time_point t0; explicit SeamTimer(int i_) : i(i_), t0(std::chrono::steady_clock::now()) {} ~SeamTimer() { g_seam_ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 
 struct Pt { int x, y; };
 inline bool operator==(const Pt& a, const Pt& b) { return a.x == b.x && a.y == b.y; }
@@ -108,13 +113,14 @@ struct DpPair {
 
     // DpSeamFinder::findEdges: components that touch (4-neighbourhood) are joined by an edge in both directions
     void find_edges() {
-        std::map<std::pair<int, int>, int> wedges;
+        // (a ncomps x ncomps table instead of an ordered map touched once per contour pixel)
+        std::vector<uint8_t> touchm((size_t)ncomps * ncomps, 0);
         for (int ci = 0; ci < ncomps; ci++)
             for (const Pt& p : contours[ci]) {
                 const int x = p.x, y = p.y, l = ci + 1;
                 auto touch = [&](int yy, int xx) {
                     const int o = labels(yy, xx);
-                    if (o && o != l) { wedges[std::make_pair(ci, o - 1)]++; wedges[std::make_pair(o - 1, ci)]++; }
+                    if (o && o != l) { touchm[(size_t)ci * ncomps + (o - 1)] = 1; touchm[(size_t)(o - 1) * ncomps + ci] = 1; }
                 };
                 if (x > 0) touch(y, x - 1);
                 if (y > 0) touch(y - 1, x);
@@ -122,8 +128,9 @@ struct DpPair {
                 if (y < uh - 1) touch(y + 1, x);
             }
         edges.clear();
-        for (const auto& e : wedges)
-            if (e.second > 0) edges.insert(e.first);
+        for (int a = 0; a < ncomps; a++)
+            for (int b = 0; b < ncomps; b++)
+                if (touchm[(size_t)a * ncomps + b]) edges.insert(std::make_pair(a, b));
     }
 
     bool has_only_one_neighbor(int comp) const {
@@ -384,15 +391,20 @@ struct DpPair {
                 states[c1] = states[c2] == FIRST ? INTERS_SECOND : INTERS_FIRST;
             } else {
                 Pt p1, p2;
-                if (get_seam_tips(c1, c2, &p1, &p2)) {
+                bool tips;
+                { SeamTimer tm(3); tips = get_seam_tips(c1, c2, &p1, &p2); }
+                if (tips) {
                     std::vector<Pt> seam;
                     bool horizontal = false;
-                    if (estimate_seam(im1, im2, tl1, tl2, c1, p1, p2, seam, &horizontal)) update_labels_using_seam(c1, c2, seam, horizontal);
+                    bool est;
+                    { SeamTimer tm(4); est = estimate_seam(im1, im2, tl1, tl2, c1, p1, p2, seam, &horizontal); }
+                    if (est) { SeamTimer tm(5); update_labels_using_seam(c1, c2, seam, horizontal); }
                 }
                 states[c1] = states[c2] == FIRST ? INTERS_SECOND : INTERS_FIRST;
             }
             // box and contour of both components again (scanned inside their previous boxes, as the reference does)
             const int c[2] = {c1, c2}, l[2] = {l1, l2};
+            SeamTimer tm_rescan(6);
             for (int i = 0; i < 2; i++) {
                 const int x0 = tls[c[i]].x, x1 = brs[c[i]].x, y0 = tls[c[i]].y, y1 = brs[c[i]].y;
                 tls[c[i]] = Pt{INT_MAX, INT_MAX};
@@ -429,6 +441,7 @@ struct DpPair {
         const Pt itl{std::max(tl1.x, tl2.x), std::max(tl1.y, tl2.y)};
         const Pt ibr{std::min(tl1.x + im1.w, tl2.x + im2.w), std::min(tl1.y + im1.h, tl2.y + im2.h)};
         if (itl.x >= ibr.x || itl.y >= ibr.y) return;   // no overlap: no conflicts
+        SeamTimer tm_setup(0);
         union_tl = Pt{std::min(tl1.x, tl2.x), std::min(tl1.y, tl2.y)};
         union_br = Pt{std::max(tl1.x + im1.w, tl2.x + im2.w), std::max(tl1.y + im1.h, tl2.y + im2.h)};
         uw = union_br.x - union_tl.x; uh = union_br.y - union_tl.y;
@@ -446,8 +459,8 @@ struct DpPair {
                 if (edge(mask1, y, x)) contour1(y, x) = 255;
                 if (edge(mask2, y, x)) contour2(y, x) = 255;
             }
-        find_components();
-        find_edges();
+        { SeamTimer tm(1); find_components(); }
+        { SeamTimer tm(2); find_edges(); }
         resolve_conflicts(im1, im2, tl1, tl2, m1, m2);
     }
 };
@@ -463,24 +476,58 @@ extern "C" int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisIm
     MIS_CHECK(ctx, cost_func == MIS_SEAM_DP_COLOR, MIS_E_UNSUPPORTED, "DpSeamFinder: only the COLOR cost (the reference's \"dp_color\") is implemented");
     if (n == 0) return MIS_OK;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (getenv("MIS_SEAM_TRACE")) { const auto t_e = std::chrono::steady_clock::now(); hipStreamSynchronize(ctx->stream); fprintf(stderr, "dp seams: entry sync %.2f ms\n", std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_e).count() / 1e3); }
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<HostImage> im((size_t)n);
     std::vector<Grid<uint8_t>> mk((size_t)n);
-    std::vector<uint8_t> tmp;
+    // device images and masks come over in one go: every copy into a pinned staging buffer, ONE synchronisation (a pageable
+    // destination made each of the 3 n small 2-D copies a synchronous 0.8 ms affair: 39 of the finder's 52 ms)
+    size_t stage_total = 0;
+    std::vector<size_t> ioff((size_t)n), moff((size_t)n);
     for (int i = 0; i < n; i++) {
         const MisImage& I = images[i];
         const MisImage& M = masks[i];
         MIS_CHECK(ctx, I.data && M.data && I.dtype == MIS_U8 && I.channels == 3 && M.dtype == MIS_U8 && M.channels == 1 && I.width == M.width && I.height == M.height &&
                            I.width > 0 && I.height > 0, MIS_E_INVALID, "image %d: need an 8UC3 image and an 8U mask of the same size", i);
-        im[i].w = I.width; im[i].h = I.height; im[i].px.resize((size_t)I.width * I.height * 3);
-        tmp.resize((size_t)I.width * I.height * 3);
-        if (I.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(tmp.data(), (size_t)I.width * 3, I.data, I.stride, (size_t)I.width * 3, I.height, hipMemcpyDeviceToHost, ctx->stream));
-        else for (int y = 0; y < I.height; y++) memcpy(tmp.data() + (size_t)y * I.width * 3, (const uint8_t*)I.data + (size_t)y * I.stride, (size_t)I.width * 3);
-        mk[i].create(M.width, M.height, 0);
-        if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(mk[i].v.data(), M.width, M.data, M.stride, M.width, M.height, hipMemcpyDeviceToHost, ctx->stream));
-        else for (int y = 0; y < M.height; y++) memcpy(mk[i].v.data() + (size_t)y * M.width, (const uint8_t*)M.data + (size_t)y * M.stride, M.width);
-        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t k = 0; k < tmp.size(); k++) im[i].px[k] = (float)tmp[k];     // convertTo(CV_32F), image_stitching.cpp:992-994
+        ioff[i] = stage_total; stage_total += mis_align_up((size_t)I.width * I.height * 3, 256);
+        moff[i] = stage_total; stage_total += mis_align_up((size_t)M.width * M.height, 256);
     }
+    uint8_t* stage = nullptr;
+    { void* sp = nullptr; int rc = mis_host_stage(ctx, stage_total, &sp); if (rc != MIS_OK) return rc; stage = (uint8_t*)sp; }
+    // device inputs are gathered into one device block first (device-to-device copies are cheap launches) and cross the bus in ONE
+    // copy: 3 n separate device-to-host copies of ~0.1 MB took 1 ms each on the stream of a second context, 31 of the finder's 52 ms
+    bool any_dev = false;
+    for (int i = 0; i < n; i++) any_dev |= images[i].mem == MIS_MEM_DEVICE || masks[i].mem == MIS_MEM_DEVICE;
+    void* dblk = nullptr; size_t dgot = 0;
+    if (any_dev) { int rc = mis_pool_alloc(ctx, stage_total, &dblk, &dgot); if (rc != MIS_OK) return rc; }
+    uint8_t* dstage = (uint8_t*)dblk;
+    for (int i = 0; i < n; i++) {
+        const MisImage& I = images[i];
+        const MisImage& M = masks[i];
+        if (I.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(dstage + ioff[i], (size_t)I.width * 3, I.data, I.stride, (size_t)I.width * 3, I.height, hipMemcpyDeviceToDevice, ctx->stream));
+        if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(dstage + moff[i], M.width, M.data, M.stride, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (any_dev) MIS_HIP(ctx, hipMemcpyAsync(stage, dstage, stage_total, hipMemcpyDeviceToHost, ctx->stream));
+    const auto t_issued = std::chrono::steady_clock::now();
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_synced = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; i++) {   // host inputs go into their slots of the staging buffer directly
+        const MisImage& I = images[i];
+        const MisImage& M = masks[i];
+        if (I.mem != MIS_MEM_DEVICE) for (int y = 0; y < I.height; y++) memcpy(stage + ioff[i] + (size_t)y * I.width * 3, (const uint8_t*)I.data + (size_t)y * I.stride, (size_t)I.width * 3);
+        if (M.mem != MIS_MEM_DEVICE) for (int y = 0; y < M.height; y++) memcpy(stage + moff[i] + (size_t)y * M.width, (const uint8_t*)M.data + (size_t)y * M.stride, M.width);
+    }
+    for (int i = 0; i < n; i++) {
+        const MisImage& I = images[i];
+        im[i].w = I.width; im[i].h = I.height;
+        const size_t np3 = (size_t)I.width * I.height * 3;
+        im[i].px.resize(np3);
+        const uint8_t* sp = stage + ioff[i];
+        for (size_t k = 0; k < np3; k++) im[i].px[k] = (float)sp[k];     // convertTo(CV_32F), image_stitching.cpp:992-994
+        mk[i].w = I.width; mk[i].h = I.height;
+        mk[i].v.assign(stage + moff[i], stage + moff[i] + (size_t)I.width * I.height);
+    }
+    const auto t_loaded = std::chrono::steady_clock::now();
     struct PairD { int d, i, j; };
     std::vector<PairD> pairs;
     for (int i = 0; i + 1 < n; i++)
@@ -490,14 +537,60 @@ extern "C" int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisIm
         }
     std::stable_sort(pairs.begin(), pairs.end(), [](const PairD& a, const PairD& b) { return a.d < b.d; });
     std::reverse(pairs.begin(), pairs.end());
-    DpPair dp;
-    for (const PairD& p : pairs)
+    // A pair reads its two images and reads / writes its two masks, nothing else: pairs without a common image commute.  The
+    // pairs keep the reference's order wherever it matters -- a pair waits for every earlier pair that shares an image with it --
+    // and otherwise run side by side on host threads (level = 1 + the highest level among those earlier pairs).  Pairs whose
+    // images do not overlap change nothing and are dropped first.
+    std::vector<PairD> work;
+    for (const PairD& p : pairs) {
+        const int x0 = std::max(corners[p.i].x, corners[p.j].x), y0 = std::max(corners[p.i].y, corners[p.j].y);
+        const int x1 = std::min(corners[p.i].x + im[p.i].w, corners[p.j].x + im[p.j].w), y1 = std::min(corners[p.i].y + im[p.i].h, corners[p.j].y + im[p.j].h);
+        if (x0 < x1 && y0 < y1) work.push_back(p);
+    }
+    std::vector<int> level(work.size(), 0), last((size_t)n, 0);
+    int nlevels = 0;
+    for (size_t k = 0; k < work.size(); k++) {
+        level[k] = std::max(last[work[k].i], last[work[k].j]) + 1;
+        last[work[k].i] = last[work[k].j] = level[k];
+        nlevels = std::max(nlevels, level[k]);
+    }
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto run_pair = [&](const PairD& p) {
+        DpPair dp;
         dp.process(im[p.i], im[p.j], Pt{corners[p.i].x, corners[p.i].y}, Pt{corners[p.j].x, corners[p.j].y}, mk[p.i], mk[p.j]);
+    };
+    for (int lv = 1; lv <= nlevels; lv++) {
+        std::vector<size_t> ids;
+        for (size_t k = 0; k < work.size(); k++) if (level[k] == lv) ids.push_back(k);
+        if (ids.size() == 1 || hw == 1) { for (size_t k : ids) run_pair(work[k]); continue; }
+        std::atomic<size_t> next{0};
+        auto worker = [&]() { for (size_t q = next++; q < ids.size(); q = next++) run_pair(work[ids[q]]); };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < std::min<size_t>(hw, ids.size()); t++) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    }
+    const auto t_solved = std::chrono::steady_clock::now();
     for (int i = 0; i < n; i++) {
         const MisImage& M = masks[i];
-        if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(M.data, M.stride, mk[i].v.data(), M.width, M.width, M.height, hipMemcpyHostToDevice, ctx->stream));
+        if (M.mem == MIS_MEM_DEVICE) memcpy(stage + moff[i], mk[i].v.data(), (size_t)M.width * M.height);
         else for (int y = 0; y < M.height; y++) memcpy((uint8_t*)M.data + (size_t)y * M.stride, mk[i].v.data() + (size_t)y * M.width, M.width);
     }
+    if (any_dev) {
+        MIS_HIP(ctx, hipMemcpyAsync(dstage, stage, stage_total, hipMemcpyHostToDevice, ctx->stream));   // (the image slots travel back unused: one copy)
+        for (int i = 0; i < n; i++) {
+            const MisImage& M = masks[i];
+            if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(M.data, M.stride, dstage + moff[i], M.width, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        mis_pool_free(ctx, dblk, dgot);
+    }
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("MIS_SEAM_TRACE")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration_cast<std::chrono::microseconds>(b - a).count() / 1e3; };
+        fprintf(stderr, "dp seams wall: load %.2f ms (issue %.2f, sync %.2f, convert %.2f), pairs %.2f ms, store %.2f ms\n", ms(t_begin, t_loaded), ms(t_begin, t_issued), ms(t_issued, t_synced), ms(t_synced, t_loaded), ms(t_loaded, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
+        fprintf(stderr, "dp seams: %zu overlapping pairs in %d levels; ms (summed over threads): setup+all %.2f components %.2f edges %.2f tips %.2f estimate %.2f labels %.2f rescan %.2f\n", work.size(), nlevels,
+                g_seam_ns[0] / 1e6, g_seam_ns[1] / 1e6, g_seam_ns[2] / 1e6, g_seam_ns[3] / 1e6, g_seam_ns[4] / 1e6, g_seam_ns[5] / 1e6, g_seam_ns[6] / 1e6);
+        for (auto& v : g_seam_ns) v = 0;
+    }
     return MIS_OK;
 }

@@ -260,6 +260,17 @@ class HipEngine:
         """Gains and seam masks from every kept frame's seam-scale image (same inputs on every rank: same result)."""
         self._seam = st.seam_solve(self.cctx, self.cfg, corners, images, masks)
 
+    def warp_feed_seam_many(self, frames, cams, rois, ks):
+        """warp_feed_seam for a list of frames (ks: their indices among the kept frames): one batched warp, gains and seam mask per
+        frame, one batched feed -- the same accumulators as the per-frame sequence."""
+        warped = self.warper.warp_fused_batch(frames, cams, rois)
+        compensator, seam_masks = self._seam
+        for (tl, img_s, mask), k in zip(warped, ks):
+            if compensator is not None:
+                compensator.apply(k, tl, img_s, mask)
+            st.seam_mask_apply(self.cctx, seam_masks[k], mask)
+        self.blender.feed_batch([w[1] for w in warped], [w[2] for w in warped], [w[0] for w in warped])
+
     def warp_feed_seam(self, frame, cam, roi, k):
         """warp -> gains of image k -> seam mask of image k -> feed (image_stitching.cpp:1154-1171, :1218)."""
         tl, img_s, mask = self.warper.warp_fused(frame, cam["K"], cam["R"], roi)
@@ -475,8 +486,11 @@ class StitchJob:
         mine = [i for i in self.my_frames if i in rois]
         if self.seam_needed:
             self.stage_seam(frames, indices)
-            for i in mine:
-                eng.warp_feed_seam(frames[i], self.cams[i], rois[i], indices.index(i))
+            if hasattr(eng, "warp_feed_seam_many"):
+                eng.warp_feed_seam_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine], [indices.index(i) for i in mine])
+            else:
+                for i in mine:
+                    eng.warp_feed_seam(frames[i], self.cams[i], rois[i], indices.index(i))
             return btype, bands
         if hasattr(eng, "warp_feed_many"):
             eng.warp_feed_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine])

@@ -184,6 +184,22 @@ class SphericalWarper:
                                                                  C.byref(mimg), C.byref(tl)))
         return (tl.x, tl.y)
 
+    def warp_fused_batch(self, imgs, cameras, rois):
+        """mis_warp_spherical_fused_batch: the compose-scale step of main() for all frames (one grid per 16 frames)
+        -> [(tl, img_warped_s, mask_warped)], the results of warp_fused per frame."""
+        n = len(imgs)
+        outs = [self.alloc_fused(r) for r in rois]
+        im = (capi.MisImage * n)(*[as_image(i) for i in imgs])
+        ds = (capi.MisImage * n)(*[as_image(o[0]) for o in outs])
+        ms = (capi.MisImage * n)(*[as_image(o[1]) for o in outs])
+        Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cameras]))
+        Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cameras]))
+        rs = (capi.MisRect * n)(*[capi.MisRect(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in rois])
+        tls = (capi.MisPoint * n)()
+        fp = C.POINTER(C.c_float)
+        self.ctx.check(self.ctx.lib.mis_warp_spherical_fused_batch(self.ctx.h, im, n, float(self.scale), Ks.ctypes.data_as(fp), Rs.ctypes.data_as(fp), rs, ds, ms, tls))
+        return [((t.x, t.y), o[0], o[1]) for t, o in zip(tls, outs)]
+
     def warp_fused_batch_timed(self, imgs, cameras, rois, dsts, masks, repeats):
         """mis_warp_spherical_fused_batch_timed: the fused warps of all frames in one grid per 16 frames, launched `repeats` times
         back to back between two HIP events on the context's stream -> average microseconds of one pass over all frames."""
