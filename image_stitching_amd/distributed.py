@@ -485,7 +485,12 @@ class StitchJob:
         rois = self._compose_rois
         mine = [i for i in self.my_frames if i in rois]
         if self.seam_needed:
+            marks = getattr(self, "marks", None)
+            if marks is not None:
+                marks.append(("compose: sized", time.perf_counter()))
             self.stage_seam(frames, indices)
+            if marks is not None:
+                marks.append(("compose: seams solved", time.perf_counter()))
             if hasattr(eng, "warp_feed_seam_many"):
                 eng.warp_feed_seam_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine], [indices.index(i) for i in mine])
             else:
@@ -505,6 +510,8 @@ class StitchJob:
         eng = self.engine
         mine = [i for i in self.my_frames if i in indices]
         local = eng.seam_local([frames[i] for i in mine], [self.cams[i] for i in mine], self.scale)
+        if getattr(self, "marks", None) is not None:
+            self.marks.append(("compose: seam-scale warps enqueued", time.perf_counter()))
         if self.world == 1 and not self.force_collectives:
             items = local
         else:

@@ -8,7 +8,8 @@ import image_stitching_amd as isa
 from image_stitching_amd import distributed as misdist
 cams = synth.workload("config3")
 ctx = isa.Context(0)
-job = misdist.StitchJob(ctx, (3840, 2160), cams)
+cfg = isa.StitchConfig() if os.environ.get("MIS_PIPELINE") == "reference_default" else isa.StitchConfig.hot_path()
+job = misdist.StitchJob(ctx, (3840, 2160), cams, config=cfg)
 frames = {i: synth.render_frame_gpu(cams[i]) for i in job.my_frames}
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6

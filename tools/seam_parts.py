@@ -35,3 +35,15 @@ with torch.cuda.stream(eng.compose_stream):
     timed("  warp linear", lambda: w2.warp(img, K, R, capi.INTER_LINEAR, capi.BORDER_REFLECT))
     timed("  torch.full", lambda: torch.full((img.shape[0], img.shape[1]), 255, dtype=torch.uint8, device=ctx.device))
     timed("  torch.empty", lambda: torch.empty((229, 384, 3), dtype=torch.uint8, device=ctx.device))
+frames = [synth.render_frame_gpu(c) for c in cams]
+torch.cuda.synchronize()
+with torch.cuda.stream(eng.compose_stream):
+    for rep in range(2):
+        ts = []
+        keep = []
+        for fr, c in zip(frames, cams):
+            t0 = time.perf_counter()
+            keep.append(st.seam_scale_warp(eng.cctx, cfg, (3840, 2160), fr, c, scale))
+            ts.append((time.perf_counter() - t0) * 1e6)
+        t0 = time.perf_counter(); torch.cuda.synchronize(); tsync = (time.perf_counter() - t0) * 1e6
+        print("per-frame host us:", " ".join("%.0f" % t for t in ts), "| final sync %.0f us" % tsync)
