@@ -183,6 +183,7 @@ struct MisCompensator {
     std::vector<std::vector<float>> maps;
     std::vector<int> mw, mh;
     float* dev_maps = nullptr;         // all maps back to back
+    size_t dev_maps_cap = 0;           // floats allocated
     std::vector<size_t> dev_ofs;
 };
 
@@ -318,11 +319,19 @@ extern "C" int mis_compensator_feed(MisCompensator* c, const MisPoint* corners, 
         total += m.size();
         c->maps[i] = std::move(m);
     }
-    if (c->dev_maps) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(c->dev_maps)); c->dev_maps = nullptr; }
-    MIS_HIP(ctx, hipMalloc(&c->dev_maps, total * sizeof(float)));
-    for (int i = 0; i < n; i++)
-        MIS_HIP(ctx, hipMemcpyAsync(c->dev_maps + c->dev_ofs[i], c->maps[i].data(), c->maps[i].size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the device copy of the maps is grow-only (a free + malloc per feed synchronises the device twice) and filled by ONE copy
+    // from the context's pinned staging
+    if (c->dev_maps_cap < total) {
+        if (c->dev_maps) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(c->dev_maps)); c->dev_maps = nullptr; c->dev_maps_cap = 0; }
+        MIS_HIP(ctx, hipMalloc(&c->dev_maps, (total + total / 2) * sizeof(float)));
+        c->dev_maps_cap = total + total / 2;
+    }
+    void* hs = nullptr;
+    int rcs = mis_host_stage(ctx, total * sizeof(float), &hs);
+    if (rcs != MIS_OK) return rcs;
+    for (int i = 0; i < n; i++) memcpy((float*)hs + c->dev_ofs[i], c->maps[i].data(), c->maps[i].size() * sizeof(float));
+    MIS_HIP(ctx, hipMemcpyAsync(c->dev_maps, hs, total * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is reusable when this returns
     return MIS_OK;
 }
 
