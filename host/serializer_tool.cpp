@@ -2,9 +2,12 @@
 //   serializer_tool copy-cams IN OUT        read cams.data text IN, write it back to OUT
 //   serializer_tool copy-indices IN OUT
 //   serializer_tool matrix "<text>"          deserializeMatrix + print rows x cols and the float values (%.9g)
+//   serializer_tool exif FILE.jpg            the EXIF ImageDescription of a JPEG file (exit code 3 when it has none)
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <string>
+#include "exif.hpp"
 #include "serializer.hpp"
 
 int main(int argc, char** argv) {
@@ -18,10 +21,16 @@ int main(int argc, char** argv) {
             std::printf("\n");
             return 0;
         }
+        if (argc == 3 && !std::strcmp(argv[1], "exif")) {
+            std::string d;
+            if (!mis::exifImageDescriptionFile(argv[2], &d)) return 3;
+            std::fwrite(d.data(), 1, d.size(), stdout);
+            return 0;
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 2;
     }
-    std::fprintf(stderr, "usage: serializer_tool copy-cams IN OUT | copy-indices IN OUT | matrix TEXT\n");
+    std::fprintf(stderr, "usage: serializer_tool copy-cams IN OUT | copy-indices IN OUT | matrix TEXT | exif FILE.jpg\n");
     return 1;
 }

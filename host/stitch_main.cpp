@@ -11,6 +11,7 @@
 #include <iostream>
 #include <sstream>
 #include "stitcher.hpp"
+#include "exif.hpp"
 #include "serializer.hpp"
 
 int main(int argc, char** argv) {
@@ -55,12 +56,18 @@ int main(int argc, char** argv) {
         std::vector<mis::CameraParams> cams;
         for (auto& name : img_names) {
             frames.push_back(mis::readPPM(name));
-            std::ifstream f(fs::path(name).replace_extension(".txt"));
-            if (!f) { std::cout << "Can't open camera description for " << name << "\n"; return -1; }
-            std::stringstream ss;
-            ss << f.rdbuf();
+            // the camera: the EXIF ImageDescription of "<k>.jpg" beside the frame when there is one (the reference's source,
+            // image_stitching.cpp:344-347, :411-417; the pixels still come from the .ppm: no JPEG decoder here), else "<k>.txt"
+            std::string desc;
+            if (!mis::exifImageDescriptionFile(fs::path(name).replace_extension(".jpg").string(), &desc)) {
+                std::ifstream f(fs::path(name).replace_extension(".txt"));
+                if (!f) { std::cout << "Can't open camera description for " << name << "\n"; return -1; }
+                std::stringstream ss;
+                ss << f.rdbuf();
+                desc = ss.str();
+            }
             bool portrait = false;
-            cams.push_back(mis::cameraFromImageDescription(ss.str(), &portrait));
+            cams.push_back(mis::cameraFromImageDescription(desc, &portrait));
         }
         mis::Stitcher st(0, cfg);
         mis::StitchResult r = st.stitch(frames, cams);

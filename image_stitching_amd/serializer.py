@@ -78,3 +78,66 @@ def camera_from_checkpoint(c, width, height):
     """checkpoint entry -> the camera dict the warp / blend stages take (K from focal, aspect, ppx, ppy)."""
     K = np.array([[c["focal"], 0, c["ppx"]], [0, c["focal"] * c["aspect"], c["ppy"]], [0, 0, 1]], np.float64)
     return dict(width=width, height=height, K=K, R=np.asarray(c["R"], np.float64), focal=c["focal"])
+
+
+def exif_image_description(data):
+    """EXIF ImageDescription (tag 0x010E, ASCII) of a JPEG file's bytes, or None -- the tag walk of the reference's camera loader
+    (image_stitching.cpp:344-347, :411-417) without libexif; host/exif.cpp is the C++ twin.  IFD0, IFD1, then the Exif sub-IFD; the
+    last occurrence wins; cut to 1022 characters as exif_entry_get_value(ee, buf, 1023) does."""
+    d = bytes(data)
+    n = len(d)
+    if n < 4 or d[0] != 0xFF or d[1] != 0xD8:
+        return None
+    o = 2
+    while o + 4 <= n:
+        if d[o] != 0xFF:
+            return None
+        m = d[o + 1]
+        if m == 0xFF:
+            o += 1
+            continue
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+            o += 2
+            continue
+        if m in (0xD9, 0xDA):
+            return None
+        ln = (d[o + 2] << 8) | d[o + 3]
+        if ln < 2 or o + 2 + ln > n:
+            return None
+        if m == 0xE1 and ln >= 16 and d[o + 4:o + 10] == b"Exif\0\0":
+            t = d[o + 10:o + 2 + ln]
+            if len(t) < 8 or t[:2] not in (b"II", b"MM"):
+                return None
+            bo = "little" if t[:2] == b"II" else "big"
+            u16 = lambda p: int.from_bytes(t[p:p + 2], bo)
+            u32 = lambda p: int.from_bytes(t[p:p + 4], bo)
+            if u16(2) != 42:
+                return None
+            found = [None]
+
+            def walk(off, want_exif):
+                if not off or off + 2 > len(t):
+                    return 0, 0
+                cnt = u16(off)
+                if off + 2 + cnt * 12 + 4 > len(t):
+                    return 0, 0
+                exif = 0
+                for i in range(cnt):
+                    e = off + 2 + i * 12
+                    tag, typ, count = u16(e), u16(e + 2), u32(e + 4)
+                    if tag == 0x8769 and want_exif:
+                        exif = u32(e + 8)
+                    if tag != 0x010E or typ != 2:
+                        continue
+                    vo = e + 8 if count <= 4 else u32(e + 8)
+                    if vo + count > len(t):
+                        continue
+                    v = t[vo:vo + count].split(b"\0")[0][:1022]
+                    found[0] = v.decode("latin-1")
+                return exif, u32(off + 2 + cnt * 12)
+            exif, nxt = walk(u32(4), True)
+            walk(nxt, False)
+            walk(exif, False)
+            return found[0]
+        o += 2 + ln
+    return None

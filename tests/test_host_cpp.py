@@ -328,3 +328,60 @@ def test_crop_known_answers_and_cross_language(tmp_path):
     codes = dict(top=0, bottom=0, left=0, right=0)
     assert crp.checkInteriorExterior(m, (0, 0, 30, 20), codes) is False and codes == dict(top=1, bottom=0, left=0, right=0)
     assert crp.compareX((1, 9), (2, 0)) and not crp.compareY((1, 9), (2, 0))
+
+
+def _jpeg_with_description(desc, order="II", inline_pad=False, in_exif_ifd=False):
+    """A JPEG header: SOI, APP0 (JFIF), APP1 "Exif" with a TIFF block whose IFD0 (or Exif sub-IFD) carries ImageDescription, then
+    a quantisation-table segment and SOS -- no image data is needed to read the tag."""
+    import struct
+    E = "<" if order == "II" else ">"
+    val = desc.encode("latin-1") + b"\0"
+    def ifd(entries, next_off=0):
+        return struct.pack(E + "H", len(entries)) + b"".join(entries) + struct.pack(E + "I", next_off)
+    def entry(tag, typ, count, value_or_off):
+        return struct.pack(E + "HHI", tag, typ, count) + value_or_off
+    head = order.encode() + struct.pack(E + "HI", 42, 8)
+    if in_exif_ifd:
+        ifd0_len = 2 + 12 * 2 + 4
+        exif_off = 8 + ifd0_len
+        sub_len = 2 + 12 + 4
+        data_off = exif_off + sub_len
+        ifd0 = ifd([entry(0x0112, 3, 1, struct.pack(E + "HH", 1, 0)), entry(0x8769, 4, 1, struct.pack(E + "I", exif_off))])
+        sub = ifd([entry(0x010E, 2, len(val), struct.pack(E + "I", data_off))])
+        tiff = head + ifd0 + sub + val
+    else:
+        ifd0_len = 2 + 12 * 2 + 4
+        data_off = 8 + ifd0_len
+        v = (val + b"\0\0\0\0")[:4] if len(val) <= 4 else struct.pack(E + "I", data_off)
+        ifd0 = ifd([entry(0x010E, 2, len(val), v), entry(0x0112, 3, 1, struct.pack(E + "HH", 1, 0))])
+        tiff = head + ifd0 + (val if len(val) > 4 else b"")
+    app1 = b"Exif\0\0" + tiff
+    app0 = b"JFIF\0\x01\x01\0\0\x01\0\x01\0\0"
+    seg = lambda m, body: b"\xff" + bytes([m]) + struct.pack(">H", len(body) + 2) + body
+    return b"\xff\xd8" + seg(0xE0, app0) + seg(0xE1, app1) + seg(0xDB, b"\0" * 65) + seg(0xDA, b"\0" * 6) + b"\x12\x34\xff\xd9"
+
+
+def test_exif_image_description_cpp_and_python_twins(tmp_path):
+    """Row N4's tag walk (the reference reads the camera string from EXIF ImageDescription through libexif): both byte orders, a
+    value stored inline (<= 4 bytes), the tag in the Exif sub-IFD, truncation to 1022 characters as the reference's buffer does,
+    files without the tag; then the string feeds cameraFromImageDescription's format."""
+    from image_stitching_amd import serializer as ser
+    host = os.path.join(ROOT, "host")
+    subprocess.check_call(["make", "-s", "-C", host, "serializer_tool"])
+    tool = os.path.join(host, "serializer_tool")
+    m4 = "[" + ",".join(str(0.125 * i - 1) for i in range(16)) + "]"
+    desc = "0;12.5;%s;%s;%s;[1000,0,960,0,1000,540,0,0,1]" % (m4, m4, m4)
+    long_desc = desc + ";" + "x" * 1500
+    cases = [(desc, "II", False), (desc, "MM", False), ("abc", "II", False), (desc, "MM", True), (long_desc, "II", False)]
+    for k, (d, order, sub) in enumerate(cases):
+        blob = _jpeg_with_description(d, order, in_exif_ifd=sub)
+        path = tmp_path / ("c%d.jpg" % k)
+        path.write_bytes(blob)
+        want = d[:1022]
+        assert ser.exif_image_description(blob) == want
+        assert subprocess.check_output([tool, "exif", str(path)]).decode("latin-1") == want
+    for bad in (b"", b"\xff\xd8\xff\xd9", b"\x89PNG\r\n", _jpeg_with_description(desc)[:40], b"\xff\xd8" + b"\xff\xe0\x00\x04\x00\x00" + b"\xff\xda\x00\x02"):
+        path = tmp_path / "bad.jpg"
+        path.write_bytes(bad)
+        assert ser.exif_image_description(bad) is None
+        assert subprocess.call([tool, "exif", str(path)]) == 3
