@@ -648,8 +648,11 @@ class StitchJob:
             if marks is not None:
                 marks.append((name, time.perf_counter()))
         refine = self.cfg.ba_cost_func != "no"
-        # refined cameras or a seam-scale step (which needs the kept set): compose must wait for the matcher
-        spec = getattr(self.engine, "speculative_compose", False) and not refine and not self.seam_needed
+        # refined cameras: compose must wait for the matcher.  A seam-scale step needs the kept set too, but on a single rank it is
+        # speculated like the composition itself (all frames kept is the rule; redone when the pruning drops one): its ~30 ms of
+        # host work (DP seams) and small kernels then run under the matcher's 5 ms instead of behind them
+        solo_rank = self.world == 1 and not self.force_collectives
+        spec = getattr(self.engine, "speculative_compose", False) and not refine and (not self.seam_needed or solo_rank)
         prepared = None
         side = getattr(self.engine, "compose_stream", None)
         if side is not None:

@@ -286,11 +286,15 @@ class BlocksGainCompensator:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self.ctx.h:   # a destroyed context already released the device (the C object points into it)
             self.ctx.lib.mis_compensator_destroy(self.h)
-            self.h = None
+        self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def feed(self, corners, images, masks):
         n = len(images)
