@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <set>
 #include <utility>
@@ -47,16 +48,28 @@ struct HostImage {   // CV_32FC3 view of a seam-scale image (the reference conve
 void flood_fill(Grid<int>& g, int sx, int sy, int new_val) {
     const int old = g(sy, sx);
     if (old == new_val) return;
-    std::vector<Pt> stack;
-    stack.push_back(Pt{sx, sy});
-    g(sy, sx) = new_val;
+    // scanline form: a stack of row spans instead of single pixels (the filled set is the 4-connected region either way)
+    struct Span { int y, x0, x1; };
+    static thread_local std::vector<Span> stack;
+    stack.clear();
+    auto fill_row = [&](int y, int x) {       // fills the run of `old` through (x, y), returns it
+        int* row = &g(y, 0);
+        int a = x, b = x;
+        while (a > 0 && row[a - 1] == old) a--;
+        while (b + 1 < g.w && row[b + 1] == old) b++;
+        for (int i = a; i <= b; i++) row[i] = new_val;
+        return Span{y, a, b};
+    };
+    stack.push_back(fill_row(sy, sx));
     while (!stack.empty()) {
-        const Pt p = stack.back();
+        const Span s = stack.back();
         stack.pop_back();
-        static const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
-        for (int k = 0; k < 4; k++) {
-            const int x = p.x + dx[k], y = p.y + dy[k];
-            if (x >= 0 && x < g.w && y >= 0 && y < g.h && g(y, x) == old) { g(y, x) = new_val; stack.push_back(Pt{x, y}); }
+        for (int dy = -1; dy <= 1; dy += 2) {
+            const int y = s.y + dy;
+            if (y < 0 || y >= g.h) continue;
+            const int* row = &g(y, 0);
+            for (int x = s.x0; x <= s.x1; x++)
+                if (row[x] == old) { const Span t = fill_row(y, x); stack.push_back(t); x = t.x1; }
         }
     }
 }
@@ -84,31 +97,36 @@ struct DpPair {
         ncomps = 0;
         labels.create(uw, uh);
         states.clear(); tls.clear(); brs.clear(); contours.clear();
-        for (int y = 0; y < uh; y++)
+        for (int y = 0; y < uh; y++) {
+            const uint8_t* a = &mask1(y, 0);
+            const uint8_t* b = &mask2(y, 0);
+            int* lr = &labels(y, 0);
+            for (int x = 0; x < uw; x++) lr[x] = a[x] ? (b[x] ? INT_MAX : INT_MAX - 1) : (b[x] ? INT_MAX - 2 : 0);
+        }
+        for (int y = 0; y < uh; y++) {
+            int* lr = &labels(y, 0);
+            const int* up = y > 0 ? &labels(y - 1, 0) : nullptr;
+            const int* dn = y < uh - 1 ? &labels(y + 1, 0) : nullptr;
             for (int x = 0; x < uw; x++) {
-                if (mask1(y, x) && mask2(y, x)) labels(y, x) = INT_MAX;
-                else if (mask1(y, x)) labels(y, x) = INT_MAX - 1;
-                else if (mask2(y, x)) labels(y, x) = INT_MAX - 2;
-                else labels(y, x) = 0;
-            }
-        for (int y = 0; y < uh; y++)
-            for (int x = 0; x < uw; x++) {
-                if (labels(y, x) >= INT_MAX - 2) {
-                    if (labels(y, x) == INT_MAX) states.push_back(INTERS);
-                    else if (labels(y, x) == INT_MAX - 1) states.push_back(FIRST);
+                if (lr[x] >= INT_MAX - 2) {
+                    if (lr[x] == INT_MAX) states.push_back(INTERS);
+                    else if (lr[x] == INT_MAX - 1) states.push_back(FIRST);
                     else states.push_back(SECOND);
                     flood_fill(labels, x, y, ++ncomps);
                     tls.push_back(Pt{x, y});
                     brs.push_back(Pt{x + 1, y + 1});
                     contours.push_back(std::vector<Pt>());
                 }
-                if (labels(y, x)) {
-                    const int l = labels(y, x), ci = l - 1;
+                const int l = lr[x];
+                if (l) {
+                    const int ci = l - 1;
                     tls[ci].x = std::min(tls[ci].x, x); tls[ci].y = std::min(tls[ci].y, y);
                     brs[ci].x = std::max(brs[ci].x, x + 1); brs[ci].y = std::max(brs[ci].y, y + 1);
-                    if (on_border(y, x, l)) contours[ci].push_back(Pt{x, y});
+                    // on_border(y, x, l) on the row pointers
+                    if ((x == 0 || lr[x - 1] != l) || (x == uw - 1 || lr[x + 1] != l) || (!up || up[x] != l) || (!dn || dn[x] != l)) contours[ci].push_back(Pt{x, y});
                 }
             }
+        }
     }
 
     // DpSeamFinder::findEdges: components that touch (4-neighbourhood) are joined by an edge in both directions
@@ -410,13 +428,18 @@ struct DpPair {
                 tls[c[i]] = Pt{INT_MAX, INT_MAX};
                 brs[c[i]] = Pt{INT_MIN, INT_MIN};
                 contours[c[i]].clear();
-                for (int y = y0; y < y1; y++)
+                for (int y = y0; y < y1; y++) {
+                    const int* lr = &labels(y, 0);
+                    const int* up = y > 0 ? &labels(y - 1, 0) : nullptr;
+                    const int* dn = y < uh - 1 ? &labels(y + 1, 0) : nullptr;
+                    const int li = l[i];
                     for (int x = x0; x < x1; x++)
-                        if (labels(y, x) == l[i]) {
+                        if (lr[x] == li) {
                             tls[c[i]].x = std::min(tls[c[i]].x, x); tls[c[i]].y = std::min(tls[c[i]].y, y);
                             brs[c[i]].x = std::max(brs[c[i]].x, x + 1); brs[c[i]].y = std::max(brs[c[i]].y, y + 1);
-                            if (on_border(y, x, l[i])) contours[c[i]].push_back(Pt{x, y});
+                            if ((x == 0 || lr[x - 1] != li) || (x == uw - 1 || lr[x + 1] != li) || (!up || up[x] != li) || (!dn || dn[x] != li)) contours[c[i]].push_back(Pt{x, y});
                         }
+                }
             }
             // [uncertain] the resolved edge leaves the graph in both directions
             edges.erase(std::make_pair(c1, c2));
@@ -446,19 +469,21 @@ struct DpPair {
         union_br = Pt{std::max(tl1.x + im1.w, tl2.x + im2.w), std::max(tl1.y + im1.h, tl2.y + im2.h)};
         uw = union_br.x - union_tl.x; uh = union_br.y - union_tl.y;
         mask1.create(uw, uh, 0); mask2.create(uw, uh, 0);
-        for (int y = 0; y < m1.h; y++)
-            for (int x = 0; x < m1.w; x++) mask1(y + tl1.y - union_tl.y, x + tl1.x - union_tl.x) = m1(y, x);
-        for (int y = 0; y < m2.h; y++)
-            for (int x = 0; x < m2.w; x++) mask2(y + tl2.y - union_tl.y, x + tl2.x - union_tl.x) = m2(y, x);
+        for (int y = 0; y < m1.h; y++) memcpy(&mask1(y + tl1.y - union_tl.y, tl1.x - union_tl.x), &m1(y, 0), (size_t)m1.w);
+        for (int y = 0; y < m2.h; y++) memcpy(&mask2(y + tl2.y - union_tl.y, tl2.x - union_tl.x), &m2(y, 0), (size_t)m2.w);
         contour1.create(uw, uh, 0); contour2.create(uw, uh, 0);
-        auto edge = [&](const Grid<uint8_t>& m, int y, int x) {
-            return m(y, x) && ((x == 0 || !m(y, x - 1)) || (x == uw - 1 || !m(y, x + 1)) || (y == 0 || !m(y - 1, x)) || (y == uh - 1 || !m(y + 1, x)));
-        };
-        for (int y = 0; y < uh; y++)
-            for (int x = 0; x < uw; x++) {
-                if (edge(mask1, y, x)) contour1(y, x) = 255;
-                if (edge(mask2, y, x)) contour2(y, x) = 255;
+        auto contour_of = [&](const Grid<uint8_t>& m, Grid<uint8_t>& c) {
+            for (int y = 0; y < uh; y++) {
+                const uint8_t* r = &m(y, 0);
+                const uint8_t* up = y > 0 ? &m(y - 1, 0) : nullptr;
+                const uint8_t* dn = y < uh - 1 ? &m(y + 1, 0) : nullptr;
+                uint8_t* o = &c(y, 0);
+                for (int x = 0; x < uw; x++)
+                    if (r[x] && ((x == 0 || !r[x - 1]) || (x == uw - 1 || !r[x + 1]) || (!up || !up[x]) || (!dn || !dn[x]))) o[x] = 255;
             }
+        };
+        contour_of(mask1, contour1);
+        contour_of(mask2, contour2);
         { SeamTimer tm(1); find_components(); }
         { SeamTimer tm(2); find_edges(); }
         resolve_conflicts(im1, im2, tl1, tl2, m1, m2);
@@ -556,7 +581,7 @@ extern "C" int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisIm
     }
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     auto run_pair = [&](const PairD& p) {
-        DpPair dp;
+        static thread_local DpPair dp;      // its grids keep their capacity from pair to pair
         dp.process(im[p.i], im[p.j], Pt{corners[p.i].x, corners[p.i].y}, Pt{corners[p.j].x, corners[p.j].y}, mk[p.i], mk[p.j]);
     };
     for (int lv = 1; lv <= nlevels; lv++) {
