@@ -187,3 +187,34 @@ def test_feed_batch_equals_single_feeds(ctx, oracle_mod, n, bands):
         ob.feed(img, mask, tl)
     oref, omask = ob.blend()
     assert np.array_equal(b_out.cpu().numpy(), oref) and np.array_equal(b_mask.cpu().numpy(), omask)
+
+
+def test_feed_batch_edge_cases(ctx, oracle_mod):
+    """An empty batch is a no-op; a batch with a frame whose mask is all zero, a one-frame batch after single feeds (the
+    accumulators are no longer fresh: read-modify-write mode) and a second batch on top all equal the oracle's sequential feeds."""
+    import torch
+    import image_stitching_amd as isa
+    rng = np.random.default_rng(77)
+    frames = _frames(rng, 5, 140, 100)
+    frames[2] = (frames[2][0], np.zeros_like(frames[2][1]), frames[2][2])
+    corners = [f[2] for f in frames]
+    sizes = [(f[0].shape[1], f[0].shape[0]) for f in frames]
+    dev = [(torch.from_numpy(f[0]).cuda(), torch.from_numpy(f[1]).cuda(), f[2]) for f in frames]
+    gb = isa.MultiBandBlender(ctx, 3); gb.prepare(corners, sizes)
+    gb.feed_batch([], [], [])
+    gb.feed(*dev[0])                                                   # single feed first: the batch that follows must add to it
+    gb.feed_batch([dev[1][0]], [dev[1][1]], [dev[1][2]])               # batch of one
+    gb.feed_batch([d[0] for d in dev[2:]], [d[1] for d in dev[2:]], [d[2] for d in dev[2:]])   # empty mask inside
+    ob = oracle_mod.Blender(oracle_mod.BLEND_MULTI_BAND, 3, 0.0)
+    ob.prepare(corners, sizes)
+    for img, mask, tl in frames:
+        ob.feed(img, mask, tl)
+    for l in range(ob.num_bands + 1):
+        olap, owgt = ob.level(l)
+        glap, gwgt = gb.level(l)
+        assert np.array_equal(glap, olap), "laplacian level %d" % l
+        assert np.array_equal(gwgt.view(np.uint32), owgt.view(np.uint32)), "weight level %d" % l
+    oref, omask = ob.blend()
+    gout, gmask = gb.blend()
+    ctx.synchronize()
+    assert np.array_equal(gout.cpu().numpy(), oref) and np.array_equal(gmask.cpu().numpy(), omask)
