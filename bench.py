@@ -250,7 +250,7 @@ def measure_roofline(ctx, job, frames, cams, launches):
             traffic = pmc["warp"]["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pmc = None
-    parts = {"warp": {"kernel": "warp_fused_kernel", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
+    parts = {"warp": {"kernel": "warp_fused_batch_kernel (all frames of the compose in one grid; same body as warp_fused_kernel)", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
                       "algorithmic_bytes_per_launch": algo_w, "avg_launch_us": round(t_w * 1e6, 2), "launches": launches,
                       "launch": "mis_warp_spherical_fused_batch: %d frames in one grid, %.1f us per pass, %d passes x 3; avg_launch_us = the pass / frames (by bytes)" % (len(mine), us_b, reps),
                       "single_frame_launch_us": round(t_w1 * 1e6, 2), "single_frame_launch_frac": round(algo_w / t_w1 / 8e12, 4),
