@@ -549,6 +549,9 @@ __device__ unsigned long long g_warp_stamps[16384 * 8];
 #define WV_TILE_WAVES 2
 #endif
 constexpr int TILE_WAVES = WV_TILE_WAVES;
+#ifndef WV_WAVES_MIN
+#define WV_WAVES_MIN 4     // occupancy floor the register allocator works to (6 and 8 measured in the batched grid: no gain)
+#endif
 #ifndef WV_ORDER
 #define WV_ORDER 2
 #endif
@@ -622,7 +625,7 @@ __device__ __forceinline__ void warp_fused_body(const WarpArgs& a, const float* 
     tile_sample_store(a, cur, stage);
 #endif
 }
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(WV_WAVES_MIN, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
     warp_fused_body(a, tab, ntiles, (int)blockIdx.x, (int)gridDim.x, stage_all);
 }
@@ -635,7 +638,7 @@ struct WarpBatch {
     const float* tab[WB_MAX];
     int ntiles[WB_MAX], nwg[WB_MAX];
 };
-__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void warp_fused_batch_kernel(WarpBatch b) {
+__global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(WV_WAVES_MIN, 8))) void warp_fused_batch_kernel(WarpBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
     const int f = blockIdx.y;
     if ((int)blockIdx.x >= b.nwg[f]) return;      // the grid covers the largest frame of the batch
