@@ -426,6 +426,8 @@ class Blender:
         self.ctx.check(self.ctx.lib.mis_blender_feed_batch(self.h, im, mk, ts, n))
 
     def blend(self):
+        if self._size is None:
+            raise MisError(-5, "blend before prepare")      # MIS_E_STATE, as the library answers
         w, h = self._size
         dst = _empty_image(self.ctx, h, w, 3, torch.int16)
         msk = _empty_image(self.ctx, h, w, 1, torch.uint8)
