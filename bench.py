@@ -50,14 +50,64 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n):
+    """Start `torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child and relay its output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:          # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL / tensor sharing between ranks)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:             # rank 0 prints ONE JSON line; anything else on stdout is passed through to stderr
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            log(t)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        log("bench.py: the %d-rank run failed (exit code %d, %s)" % (n, rc, "no result line" if line is None else "result line present"))
+        return rc if rc != 0 else 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (importing torch does not) and never will --
+        # it starts the N ranks as CHILD processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1), relays
+        # rank 0's JSON line and exits with the launcher's code.  No exec: a process must not replace itself on these boxes.
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d, or run plain "
+                         "`python bench.py --gpus %d` and let this script start the ranks" % (world, args.gpus, args.gpus, args.gpus))
+    if os.environ.get("MIS_BENCH_LAUNCH_CHECK") == "1":
+        # launcher check (tests/test_bench_launch.py, runs without a GPU): the ranks rendezvous over gloo, agree on their number and
+        # rank 0 prints a line -- nothing is measured and no product code runs
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        ok = int(t.item()) == world * (world + 1) // 2 and dist.get_world_size() == args.gpus
+        dist.barrier()
+        dist.destroy_process_group()
+        if os.environ.get("MIS_BENCH_LAUNCH_CHECK_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"metric": "launch check (no measurement)", "launch_check": ok, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        return
     import image_stitching_amd as isa
     import synth
     from image_stitching_amd import distributed as misdist

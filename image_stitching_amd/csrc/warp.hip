@@ -230,6 +230,12 @@ __device__ __forceinline__ void tile_trig(const WarpArgs& a, int tx0, int ty0, f
 #ifndef WV_LROWS
 #define WV_LROWS 4
 #endif
+#ifndef WV_V3
+#define WV_V3 1      // 1: the pipelined strip kernels of round 3; 0: round 2's one-tile-per-wave kernels (kept for A/B runs)
+#endif
+#ifndef WV_ABL
+#define WV_ABL 0     // diagnostics builds only (tools/warp_variants.sh): phases switched off one at a time
+#endif
 constexpr int LROWS = WV_LROWS;          // rows per lane (4 lane rows per tile)
 constexpr int LPX = 2 * LROWS;            // pixels per lane
 constexpr int FT_W = 32, FT_H = 4 * LROWS;
@@ -354,9 +360,12 @@ __device__ __forceinline__ void stage_box(const uint8_t* src, size_t sstride, ui
     }
 }
 
+#ifdef WV_STAMPS
+__device__ unsigned long long g_warp_stamps[16384 * 8];
+#endif
 #ifdef MIS_WARP_STATS
 __device__ unsigned g_warp_stats[8];   // tiles: interior, folded, global gather, generic-map
-#define WSTAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_warp_stats[i], 1u); } while (0)
+#define WSTAT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_warp_stats[i], 1u); } while (0)
 #else
 #define WSTAT(i)
 #endif
@@ -407,7 +416,13 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
     for (int i = 0; i < LROWS; i++) {
         v2f xx, yy, zz, qx, qy;
         map_terms(a.m, su, cu, g.rt[i], &xx, &yy, &zz);
+#if WV_ABL == 4   // diagnostics: no division (approximate coordinates)
+        { const v2f r0 = {__builtin_amdgcn_rcpf(zz.x), __builtin_amdgcn_rcpf(zz.y)}; qx = xx * r0; qy = yy * r0; }
+#elif WV_ABL == 5  // diagnostics: no map at all
+        qx = v2f{(float)gx + 100.25f, (float)gx + 101.25f} + 0.f * su; qy = v2f{(float)(gy0 + i) + 100.5f, (float)(gy0 + i) + 100.5f} + 0.f * g.rt[i].x; zz = v2f{1.f, 1.f};
+#else
         div2_shared(xx, yy, zz, &qx, &qy);
+#endif
         zlo = fminf(fminf(zlo, zz.x), zz.y);
         // cvRound(32 x) for |32 x| < 2^22; anything larger lands outside +-2^22 as well and is caught by the box check
         const v2f tx = qx * k32 + magic, ty = qy * k32 + magic;
@@ -501,6 +516,9 @@ __device__ __forceinline__ void tile_map(const WarpArgs& a, const TileTrig& g, i
 // Phase 2: issue the global -> LDS copies of the tile's source box (asynchronous; completion = vmcnt)
 __device__ __forceinline__ void tile_stage(const WarpArgs& a, const TileState& t, uint8_t* stage, int lane) {
     if (!t.staged) return;
+#if WV_ABL == 3   // diagnostics: no global -> LDS copies
+    return;
+#endif
     if (t.wide) stage_box<16>(a.src + t.gbase, a.sstride, stage, t.pitch, t.nrows, lane);
     else stage_box<4>(a.src + t.gbase, a.sstride, stage, t.pitch, t.nrows, lane);
 }
@@ -514,6 +532,11 @@ __device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileS
     for (int i = 0; i < LROWS; i++, drow += a.dstride, mrow += a.mstride) {
         if (t.gy0 + i >= a.dh) break;
         int p0[3], p1[3];
+#if WV_ABL == 2   // diagnostics: no LDS gather, no bilinear arithmetic
+        if (true) {
+            p0[0] = t.xq[2 * i] & 255; p0[1] = t.yq[2 * i] & 255; p0[2] = 7; p1[0] = t.xq[2 * i + 1] & 255; p1[1] = t.yq[2 * i + 1] & 255; p1[2] = 9;
+        } else
+#endif
         if (t.staged && t.interior) {
             sample1<false>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i], t.yq[2 * i], p0);
             sample1<false>(stage, t.lbase, t.pitch, a.sw, a.sh, t.xq[2 * i + 1], t.yq[2 * i + 1], p1);
@@ -531,8 +554,12 @@ __device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileS
             w.x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
             w.y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
             w.z = (unsigned)p1[1] | ((unsigned)p1[2] << 16);
+#if WV_ABL == 1   // diagnostics: everything but the global stores
+            asm volatile("" :: "v"(w.x), "v"(w.y), "v"(w.z), "v"(m0 | (m1 << 8)), "v"(drow), "v"(mrow));
+#else
             *reinterpret_cast<uint3*>(drow) = w;
             *reinterpret_cast<unsigned short*>(mrow) = (unsigned short)(m0 | (m1 << 8));
+#endif
         } else {
             int16_t* d = reinterpret_cast<int16_t*>(drow);
             d[0] = (int16_t)p0[0]; d[1] = (int16_t)p0[1]; d[2] = (int16_t)p0[2];
@@ -541,9 +568,7 @@ __device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileS
     }
 }
 
-#ifdef WV_STAMPS
-__device__ unsigned long long g_warp_stamps[16384 * 8];
-#endif
+
 // One tile per wave, TILE_WAVES independent waves per workgroup (no barriers; fewer, larger workgroups to dispatch).
 #ifndef WV_TILE_WAVES
 #define WV_TILE_WAVES 2
@@ -662,6 +687,623 @@ __global__ __launch_bounds__(256) void warp_trig_batch_kernel(WarpBatch b) {
     }
 }
 
+
+// =====================================================================================================================
+// K10, round 3: pipelined strips (warp_strip_kernel / warp_strip_batch_kernel).
+//
+// What the ablations of round 2's kernel said (gpurun_out/r3_abl1.txt; 23.9 us per frame in the batched grid on that box:
+// without its stores 17.8, without its global -> LDS copies 16.0, without the division 22.3, without the gather 20.2): the
+// one-tile-per-wave body is bound by the latency of its memory operations and by the shape of its stores, not by arithmetic.
+//  * A wave owns a vertical STRIP of nt tiles of 64 x V3_TH pixels and runs them as a software pipeline: the backward map of
+//    tile k + 1 and the global -> LDS copies of its source box are issued BEFORE tile k is gathered, so a copy's latency is
+//    covered by the wave's own arithmetic while the stores of tile k - 1 drain.  The waits are counted: s_waitcnt vmcnt(n)
+//    with n = the vector-memory instructions issued after the copies that are waited for (never more: a lower bound is safe).
+//  * lane = ONE column x V3_TH rows.  The row terms {sin v, m1 cos v, m4 cos v, m7 cos v} are wave-uniform: scalar loads into
+//    SGPRs, no vector loads and no VGPRs; a lane's column terms are loaded once per strip; a byte read of the gather touches
+//    32 consecutive pixels per half wave (96 bytes: no LDS bank conflict; the 2 x 4 lane blocks of round 2 conflicted 2.1-fold).
+//  * Between map and gather a pixel is ONE dword {LDS address of its top-left tap, fx, fy, tap steps}: the reflect folds and
+//    the address arithmetic happen in the map stage and two tiles in flight cost 2 x V3_TH VGPRs.
+//  * The 16SC3 tile is transposed through the LDS region of its own (spent) source box, 8 rows at a time, and leaves as whole
+//    1 KB runs: 3 global_store_dwordx4 per lane and 8 rows, every 128-byte line of a 384-byte tile row written whole by one
+//    instruction (round 2's 12-byte-per-lane stores wrote partial lines at arbitrary 6-byte offsets: WRITE_SIZE 1.22 x the bytes).
+//  * The two boxes in flight share a ring per wave: even tiles grow from its bottom, odd tiles from its top; a pair that does
+//    not fit (tall boxes at a frame's corners) is simply not overlapped.
+//  * Scalar instructions are the scarce kind here (one scalar unit per compute unit): rows come in 64-byte scalar loads, the
+//    four box reductions are interleaved DPP chains that end in one v_readlane each, offsets are 32 bits, the two tiles in
+//    flight swap roles instead of being copied.
+//  * Tiles outside the fast path's guards (z <= 2^-30 somewhere, coordinates beyond +-2^15, a box larger than the ring, a
+//    frame that is not dword aligned or larger than 4 GB) are redone after the strip's loop by a compact per-pixel loop: IEEE
+//    division, x86 cvRound, global-memory taps.
+// The float operations per pixel, the guards and the results are those of round 2's kernel.
+#ifndef WV3_RING
+#define WV3_RING 10240
+#endif
+#ifndef WV3_WAVES
+#define WV3_WAVES 2
+#endif
+#ifndef WV3_CHX
+#define WV3_CHX 2
+#endif
+#ifndef WV3_CHY
+#define WV3_CHY 1
+#endif
+#ifndef WV3_WAVES_MIN
+#define WV3_WAVES_MIN 4
+#endif
+#ifndef WV3_TH
+#define WV3_TH 8
+#endif
+#ifndef WV3_GG
+#define WV3_GG 4
+#endif
+#ifndef WV3_PITCH_ALIGN
+#define WV3_PITCH_ALIGN 128
+#endif
+constexpr int V3_TW = 64, V3_TH = WV3_TH;
+constexpr int V3_RING = WV3_RING, V3_WAVES = WV3_WAVES, V3_GG = WV3_GG, V3_PITCH_ALIGN = WV3_PITCH_ALIGN;
+constexpr int V3_OUT_IMG = V3_TW * 8 * 6, V3_OUT_BYTES = V3_OUT_IMG + V3_TW * 8;   // 8 rows of the 16SC3 tile + of the mask tile
+static_assert(V3_TH % 8 == 0 && V3_TH <= 16, "tiles are whole groups of 8 rows");
+static_assert(V3_OUT_BYTES <= V3_RING / 2 && V3_RING <= 65536, "two output groups must fit the ring; LDS addresses are 16 bits");
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) f4v* cf4p;     // constant address space: uniform indices become scalar loads
+typedef const __attribute__((address_space(4))) f16v* cf16p;
+typedef const __attribute__((address_space(3))) uint8_t* lds_cp;
+typedef __attribute__((address_space(3))) uint8_t* lds_p;
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+
+enum { V3F_WIDE_SRC = 1, V3F_FAST_OK = 2, V3F_WIDE_OUT = 4, V3F_WIDE_MASK = 8 };
+struct V3Frame {        // everything a frame's strips share (filled on the host: v3_frame_of)
+    float m[9];
+    float xhi2, yhi2;   // mask test: a coordinate rounds inside the frame iff -0.5 <= v < hi2
+    int sw, sh, dw, dh, ncol;
+    unsigned sstride, dstride, mstride, total_bytes, flags;
+    const uint8_t* src;
+    uint8_t* dst;
+    uint8_t* mask;
+    const float* tab;
+};
+
+struct V3Uni {      // wave-uniform description of a tile between its map and its gather
+    int fast;       // 1: packed taps + staged box; 0: the per-pixel loop
+    int interior;   // every tap inside the frame (mask all 255, tap steps +1 / +pitch)
+    int pitch;      // LDS bytes per box row: a multiple of 128, so a tap's bank does not depend on its row (a half wave's 32 taps are
+                    // 96 consecutive bytes of the image whatever rows they fall in: conflict free; with the tight pitch the rows'
+                    // bank offsets collided: 42 % of the LDS cycles were conflicts, gpurun_out/r3_pmc_v32.txt)
+    int rowb;       // bytes copied per row (whole pieces)
+    int nrows, bytes;
+    unsigned gbase;
+};
+
+__device__ __forceinline__ void div1_shared(float nx, float ny, float d, float* qx, float* qy) {
+    const float r0 = __builtin_amdgcn_rcpf(d), nd = -d;
+    const float e = __builtin_fmaf(nd, r0, 1.f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    float q = nx * r;
+    float t = __builtin_fmaf(nd, q, nx);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(nd, q, nx);
+    *qx = __builtin_fmaf(t, r, q);
+    q = ny * r;
+    t = __builtin_fmaf(nd, q, ny);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(nd, q, ny);
+    *qy = __builtin_fmaf(t, r, q);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most n vector-memory instructions of this wave are outstanding (n uniform; any smaller immediate is safe)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    if (n >= 8) {
+        if (n >= 12) wait_vm<12>(); else if (n >= 10) wait_vm<10>(); else wait_vm<8>();
+    } else if (n >= 4) {
+        if (n >= 6) { if (n == 7) wait_vm<7>(); else wait_vm<6>(); } else { if (n == 5) wait_vm<5>(); else wait_vm<4>(); }
+    } else {
+        if (n >= 2) { if (n == 3) wait_vm<3>(); else wait_vm<2>(); } else { if (n == 1) wait_vm<1>(); else wait_vm<0>(); }
+    }
+}
+
+// One global -> LDS copy instruction outside the compiler's view (it would wait for EVERY outstanding copy before the next
+// LDS read; the pipeline waits by count): LDS address = M0 + lane * PIECE, global address = base (SGPR pair) + voff.
+// (s_nop 0: one wait state between a scalar write of M0 and an LDS-DMA instruction that reads it -- the hazard recogniser
+// does not look into inline assembly.)
+template <int PIECE>
+__device__ __forceinline__ void dma_piece(const uint8_t* base, unsigned voff, uint32_t lds_off) {
+    if constexpr (PIECE == 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_off) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_off) : "memory", "m0");
+}
+// the copies of a box (layout as stage_box: row-major with `pitch`); returns the number of instructions issued (uniform)
+template <int PIECE>
+__device__ __forceinline__ int v3_stage_box(const uint8_t* src, unsigned gbase, unsigned sstride, uint32_t lds_off, int pitch, int rowb, int nrows, int lane) {
+    const int lpr = pitch / PIECE, k = 64 / lpr;         // lanes per LDS row (the first rowb / PIECE of them copy), rows per instruction
+    const int lr = (lane * (65536 / lpr + 1)) >> 16, lc = lane - lr * lpr;
+    unsigned voff = gbase + (unsigned)lr * sstride + (unsigned)lc * PIECE;
+    const unsigned vstep = (unsigned)k * sstride;
+    const int lstep = k * pitch;
+    int left = (lr < k && lc * PIECE < rowb) ? nrows - lr : 0;      // this lane copies a row while left > 0
+    int n = 0;
+#if WV_ABL == 3
+    return 0;
+#else
+#pragma unroll 1
+    for (int r0 = 0; r0 < nrows; r0 += k, n++) {
+        if (left > 0) dma_piece<PIECE>(src, voff, lds_off);
+        voff += vstep; lds_off += lstep; left -= k;
+    }
+    return n;
+#endif
+}
+
+// four wave-wide integer reductions at once: min(a), max(b), min(c), max(d) -> uniform values.  The chains are interleaved, so
+// a DPP read is always three instructions behind the write it depends on (two wait states needed); row_bcast 15 / 31 carry the
+// row results up the wave and lane 63 holds the answers: 24 DPP instructions and four v_readlane, no scalar min / max.
+__device__ __forceinline__ void wave_box_reduce(int& a, int& b, int& c, int& d) {
+#define MIS_STEP4(CTRL, MASKS)                                                   \
+    "v_min_i32_dpp %0, %0, %0 " CTRL " " MASKS "\n\t"                               \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " " MASKS "\n\t"                               \
+    "v_min_i32_dpp %2, %2, %2 " CTRL " " MASKS "\n\t"                               \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " " MASKS "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 MIS_STEP4("quad_perm:[1,0,3,2]", "row_mask:0xf bank_mask:0xf")
+                 MIS_STEP4("quad_perm:[2,3,0,1]", "row_mask:0xf bank_mask:0xf")
+                 MIS_STEP4("row_half_mirror", "row_mask:0xf bank_mask:0xf")
+                 MIS_STEP4("row_mirror", "row_mask:0xf bank_mask:0xf")
+                 MIS_STEP4("row_bcast:15", "row_mask:0xa bank_mask:0xf")
+                 MIS_STEP4("row_bcast:31", "row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef MIS_STEP4
+    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63); d = __builtin_amdgcn_readlane(d, 63);
+}
+
+// packed pixel between map and gather: bits 0..15 LDS address of tap (0, 0); bits 16..23 = 8 fx + cx; bits 24..31 = 8 fy + cy, with
+// cx / cy = the column / row step of the right / lower taps + 1 (steps are -1 / 0 / +1 under BORDER_REFLECT; interior tiles pack 0:
+// their steps are +1 and the fields read as the weights 8 fx, 8 fy without a mask).  The weights are scaled by 8 x 8 = 64 so that
+// the rounded bilinear sum lands in the upper half of its register: (sum + 512) >> 10 == (64 sum + 32768) >> 16, stored by a
+// ds_write_b16_d16_hi without a shift.
+__device__ __forceinline__ unsigned v3_pack(int addr, unsigned xq, unsigned yq, int cx, int cy) {
+    // xq, yq: 5 fraction bits in bits 0..4 (anything above is shifted out or masked)
+    return ((unsigned)addr | (unsigned)(cx << 16) | (unsigned)(cy << 24)) | ((xq << 19) & 0x00F80000u) | (yq << 27);
+}
+
+// Map stage: backward map of a lane's column x V3_TH rows of the tile at rows ty0.., box reduction, classification, packing
+// (tile_map's logic; the cold decisions only set u.fast = 0: the per-pixel loop redoes such a tile from scratch).
+// ring_lds / parity: where the tile's region of the ring will be (even tiles from the bottom, odd tiles from the top).
+__device__ __forceinline__ void v3_map(const V3Frame& f, cf4p rowtab, float su, float cu, int ty0, uint32_t ring_lds, int parity,
+                                       unsigned* w, unsigned& msk_out, V3Uni& u) {
+    int xq[V3_TH], yq[V3_TH];
+    float zlo = 3.0e38f;
+    f4v rt[V3_TH];
+    if (ty0 + V3_TH <= f.dh) {      // whole tile inside the roi: the rows' terms are V3_TH * 16 consecutive bytes
+        cf16p r16 = (cf16p)(rowtab + ty0);
+#pragma unroll
+        for (int g = 0; g < V3_TH / 4; g++) {
+            const f16v r = r16[g];
+            rt[4 * g] = r.s0123; rt[4 * g + 1] = r.s4567; rt[4 * g + 2] = r.s89ab; rt[4 * g + 3] = r.scdef;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V3_TH; i++) rt[i] = rowtab[min(ty0 + i, f.dh - 1)];      // rows past the roi shadow the last one
+    }
+    auto terms = [&](int i, float* xx, float* yy, float* zz) {
+        const float x_ = su * rt[i].x, z_ = cu * rt[i].x;
+        *xx = (x_ * f.m[0] + rt[i].y) + z_ * f.m[2];
+        *yy = (x_ * f.m[3] + rt[i].z) + z_ * f.m[5];
+        *zz = (x_ * f.m[6] + rt[i].w) + z_ * f.m[8];
+    };
+#pragma unroll
+    for (int i = 0; i < V3_TH; i++) {
+        float xx, yy, zz, qx, qy;
+#if WV_ABL == 5
+        qx = su * 0.f + 100.25f + (float)(threadIdx.x & 63); qy = (float)(ty0 + i) + 100.5f; zz = 1.f;
+#elif WV_ABL == 4
+        terms(i, &xx, &yy, &zz);
+        { const float r0 = __builtin_amdgcn_rcpf(zz); qx = xx * r0; qy = yy * r0; }
+#else
+        terms(i, &xx, &yy, &zz);
+        div1_shared(xx, yy, zz, &qx, &qy);
+#endif
+        zlo = fminf(zlo, zz);
+        // cvRound(32 x) by the 1.5 * 2^23 magic add; one fma: 32 x is exact, so fma(x, 32, magic) rounds once, like (32 x) + magic.
+        // xq, yq keep the float's bits: 0x4B400000 + q with q the rounded coordinate (|q| < 2^22); the bias is a multiple of 2^22,
+        // so bits 0..4 are q's fraction bits, bits 5..21 its integer part, and integer min / max order biased values like q.
+        xq[i] = (int)__float_as_uint(__builtin_fmaf(qx, 32.f, 12582912.f));
+        yq[i] = (int)__float_as_uint(__builtin_fmaf(qy, 32.f, 12582912.f));
+    }
+    int xmin = xq[0], xmax = xq[0], ymin = yq[0], ymax = yq[0];
+#pragma unroll
+    for (int q = 1; q < V3_TH; q++) {
+        xmin = min(xmin, xq[q]); xmax = max(xmax, xq[q]);
+        ymin = min(ymin, yq[q]); ymax = max(ymax, yq[q]);
+    }
+    wave_box_reduce(xmin, xmax, ymin, ymax);
+    xmin -= 0x4B400000; xmax -= 0x4B400000; ymin -= 0x4B400000; ymax -= 0x4B400000;     // (uniform) back to q
+    const bool good = (f.flags & V3F_FAST_OK) && !__any(!(zlo >= 9.31322574615478515625e-10f)) &&
+                      xmin > -(1 << 20) && ymin > -(1 << 20) && xmax < (1 << 20) && ymax < (1 << 20);
+    xmin >>= 5; xmax >>= 5; ymin >>= 5; ymax >>= 5;
+    const bool interior = xmin >= 0 && ymin >= 0 && xmax + 1 <= f.sw - 1 && ymax + 1 <= f.sh - 1;
+    const bool foldable = xmin >= -f.sw && xmax + 1 < 2 * f.sw && ymin >= -f.sh && ymax + 1 < 2 * f.sh;
+    int bx0 = xmin, bx1 = xmax + 1, by0 = ymin, by1 = ymax + 1;
+    if (!interior && foldable) {
+        auto fold = [](int lo, int hi, int len, int* o0, int* o1) {
+            if (lo >= 0 && hi < len) { *o0 = lo; *o1 = hi; }
+            else if (hi < 0) { *o0 = -hi - 1; *o1 = -lo - 1; }
+            else if (lo >= len) { *o0 = 2 * len - 1 - hi; *o1 = 2 * len - 1 - lo; }
+            else if (lo < 0) { *o0 = 0; *o1 = max(-lo - 1, min(hi, len - 1)); if (hi >= len) *o1 = len - 1; }
+            else { *o0 = min(lo, 2 * len - 1 - hi); *o1 = len - 1; }
+        };
+        fold(xmin, xmax + 1, f.sw, &bx0, &bx1);
+        fold(ymin, ymax + 1, f.sh, &by0, &by1);
+    }
+    const bool wide = (f.flags & V3F_WIDE_SRC) != 0;
+    const int amask = wide ? 15 : 3;
+    const int shift = (bx0 * 3) & amask;
+    const int rowb = ((bx1 - bx0 + 1) * 3 + shift + amask) & ~amask;
+    const int pitch = (rowb + V3_PITCH_ALIGN - 1) & ~(V3_PITCH_ALIGN - 1);
+    const int nrows = by1 - by0 + 1;
+    const unsigned gbase = (unsigned)by0 * f.sstride + (unsigned)(bx0 * 3 - shift);    // frames are < 4 GB on the fast path
+    const bool fast = good && (interior || foldable) && nrows * pitch <= V3_RING && pitch <= (wide ? 1024 : 256) &&
+                      gbase + (unsigned)(nrows - 1) * f.sstride + (unsigned)rowb <= f.total_bytes;
+    u.fast = fast; u.interior = interior; u.pitch = pitch; u.rowb = rowb; u.nrows = nrows; u.gbase = gbase;
+    u.bytes = fast ? max((nrows * pitch + 15) & ~15, V3_OUT_BYTES) : V3_OUT_BYTES;
+    unsigned msk = (1u << V3_TH) - 1u;
+    if (fast) {
+        // LDS address of source pixel (0, 0) in the tile's region
+        const int lbase = (int)ring_lds + (parity ? V3_RING - u.bytes : 0) + shift - by0 * pitch - bx0 * 3;
+        // integer parts: sign-extended bits 5..21 of the biased values (one v_bfe_i32 each)
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < V3_TH; i++) {
+                const int sx = __builtin_amdgcn_sbfe(xq[i], 5, 17), sy = __builtin_amdgcn_sbfe(yq[i], 5, 17);
+                w[i] = v3_pack(lbase + __mul24(sy, pitch) + sx * 3, (unsigned)xq[i], (unsigned)yq[i], 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V3_TH; i++) {
+                const int sx = __builtin_amdgcn_sbfe(xq[i], 5, 17), sy = __builtin_amdgcn_sbfe(yq[i], 5, 17);
+                const int x0 = mis_reflect1(sx, f.sw), x1 = mis_reflect1(sx + 1, f.sw), y0 = mis_reflect1(sy, f.sh), y1 = mis_reflect1(sy + 1, f.sh);
+                w[i] = v3_pack(lbase + __mul24(y0, pitch) + x0 * 3, (unsigned)xq[i], (unsigned)yq[i], x1 - x0 + 1, y1 - y0 + 1);
+            }
+            // some taps leave the frame: the mask (nearest source pixel inside?) needs the unquantised coordinates again
+            msk = 0;
+#pragma unroll
+            for (int i = 0; i < V3_TH; i++) {
+                float xx, yy, zz, qx, qy;
+                terms(i, &xx, &yy, &zz);
+                div1_shared(xx, yy, zz, &qx, &qy);
+                msk |= (unsigned)((qx >= -0.5f) & (qx < f.xhi2) & (qy >= -0.5f) & (qy < f.yhi2)) << i;
+            }
+        }
+    }
+    msk_out = msk;
+}
+
+// bilinear sample of a packed pixel (sample1's arithmetic with both weight factors scaled by 8): p[c] holds the channel in
+// its UPPER 16 bits: (64 sum + 32768) with sum < 2^18
+template <bool INTERIOR>
+__device__ __forceinline__ void v3_sample(int pitch, unsigned w, unsigned* p) {
+    unsigned fx8 = (w >> 16) & 0xffu, fy8 = w >> 24;
+    lds_cp t00 = (lds_cp)(uintptr_t)(w & 0xffffu);
+    lds_cp t01, t10, t11;
+    if (INTERIOR) { t01 = t00 + 3; t10 = t00 + pitch; t11 = t10 + 3; }
+    else {
+        const int dx = ((int)(fx8 & 3) - 1) * 3, dy = __mul24((int)(fy8 & 3) - 1, pitch);
+        fx8 &= ~7u; fy8 &= ~7u;
+        t01 = t00 + dx; t10 = t00 + dy; t11 = t10 + dx;
+    }
+    const unsigned wa8 = 256 - fx8, wb8 = 256 - fy8;
+    const unsigned w00 = __umul24(wa8, wb8), w01 = __umul24(fx8, wb8), w10 = __umul24(wa8, fy8), w11 = __umul24(fx8, fy8);
+#pragma unroll
+    for (int c = 0; c < 3; c++) p[c] = mad24(t11[c], w11, mad24(t10[c], w10, mad24(t01[c], w01, mad24(t00[c], w00, 32768u))));
+}
+
+__device__ __forceinline__ void v3_sample_global(const V3Frame& f, int xq, int yq, int* p) {
+    const int fx = xq & 31, fy = yq & 31, sx = xq >> 5, sy = yq >> 5;
+    const int x0 = mis_reflect(sx, f.sw), x1 = mis_reflect(sx + 1, f.sw), y0 = mis_reflect(sy, f.sh), y1 = mis_reflect(sy + 1, f.sh);
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    const uint8_t* r0 = f.src + (size_t)y0 * f.sstride;
+    const uint8_t* r1 = f.src + (size_t)y1 * f.sstride;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        p[c] = (r0[x0 * 3 + c] * w00 + r0[x1 * 3 + c] * w01 + r1[x0 * 3 + c] * w10 + r1[x1 * 3 + c] * w11 + (1 << 14)) >> 15;
+}
+
+// A tile outside the fast path, pixel by pixel (cold): generic map (IEEE division, x86 cvRound overflow, saturate_cast<short>
+// of the integer part), taps from global memory, 2-byte stores.
+__device__ __noinline__ void v3_cold_tile(const V3Frame& f, float su, float cu, int gx, int ty0) {
+    if (gx >= f.dw) return;
+    const float xhi = (float)f.sw - 0.5f, yhi = (float)f.sh - 0.5f;
+    const bool xe = ((f.sw - 1) & 1) == 0, ye = ((f.sh - 1) & 1) == 0;
+    const float4* rowtab = reinterpret_cast<const float4*>(f.tab + 2 * f.ncol);
+#pragma unroll 1
+    for (int i = 0; i < V3_TH; i++) {
+        const int gy = ty0 + i;
+        if (gy >= f.dh) break;
+        const float4 rt = rowtab[gy];
+        const float x_ = su * rt.x, z_ = cu * rt.x;
+        const float xx = (x_ * f.m[0] + rt.y) + z_ * f.m[2];
+        const float yy = (x_ * f.m[3] + rt.z) + z_ * f.m[5];
+        const float zz = (x_ * f.m[6] + rt.w) + z_ * f.m[8];
+        const bool front = zz > 0;
+        const float x = front ? xx / zz : -1.f, y = front ? yy / zz : -1.f;
+        const int xr = mis_round_sat_f(x * 32.f), yr = mis_round_sat_f(y * 32.f);
+        int p[3];
+        v3_sample_global(f, (mis_sat_short(xr >> 5) << 5) | (xr & 31), (mis_sat_short(yr >> 5) << 5) | (yr & 31), p);
+        int16_t* d = reinterpret_cast<int16_t*>(f.dst + (size_t)gy * f.dstride + (size_t)gx * 6);
+        d[0] = (int16_t)p[0]; d[1] = (int16_t)p[1]; d[2] = (int16_t)p[2];
+        f.mask[(size_t)gy * f.mstride + gx] = (round_in_range(x, xhi, xe) & round_in_range(y, yhi, ye)) ? (uint8_t)255 : (uint8_t)0;
+    }
+}
+
+__device__ __forceinline__ void v3_store_piece(uint8_t* p, u4v v, bool wide_out) {
+    if (wide_out) *reinterpret_cast<u4v*>(p) = v;       // one global_store_dwordx4 (the vector type carries the 16-byte alignment)
+    else { volatile uint32_t* q = reinterpret_cast<volatile uint32_t*>(p); q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+}
+
+// The strip a wave owns: columns tx0 .. tx0 + 63, tiles ty_first .. ty_first + nt - 1 (V3_TH rows each).
+__device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int ty_first, int nt, lds_p ring) {
+    const int lane = threadIdx.x & 63;
+    const int nty = (f.dh + V3_TH - 1) / V3_TH;
+    nt = min(nt, nty - ty_first);
+    if (nt <= 0) return;
+    const int gx = min(tx0 + lane, f.dw - 1);     // lanes past the roi shadow the last column (never stored)
+    const float2 cs = *reinterpret_cast<const float2*>(f.tab + 2 * gx);
+    cf4p rowtab = (cf4p)(uintptr_t)(f.tab + 2 * f.ncol);
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+    const bool wide_out = (f.flags & V3F_WIDE_OUT) != 0, wide_mask = (f.flags & V3F_WIDE_MASK) != 0;
+    const int valid_px = min(f.dw - tx0, V3_TW), valid_bytes = valid_px * 6;
+    // a group of 8 rows leaves as 192 pieces of 16 bytes: lane l stores pieces (l & 7) + 8 kk (kk = 0, 1, 2) of row l >> 3, so one
+    // 32-bit offset per lane (plus immediates) addresses them, in the LDS image and in memory (unsigned offsets from a uniform
+    // base: the saddr + voffset form); a store instruction writes one whole 128-byte line in each of the 8 rows
+    const unsigned poff = (unsigned)(lane >> 3) * f.dstride + (unsigned)(lane & 7) * 16;
+    const unsigned loff = (unsigned)(lane >> 3) * (V3_TW * 6) + (unsigned)(lane & 7) * 16;
+    const unsigned moff = (unsigned)(lane >> 3) * f.mstride + (unsigned)(lane & 7) * 8;
+    uint8_t* drow = f.dst + (size_t)(ty_first * V3_TH) * f.dstride + (size_t)tx0 * 6;       // the current tile's first row (bumped per tile)
+    uint8_t* mrow = f.mask + (size_t)(ty_first * V3_TH) * f.mstride + tx0;
+
+    unsigned wA[V3_TH], wB[V3_TH];
+    unsigned mskA = 0, mskB = 0;
+    V3Uni uA, uB;
+    uA.fast = 0; uA.interior = 0; uA.pitch = 128; uA.rowb = 16; uA.nrows = 0; uA.bytes = V3_OUT_BYTES; uA.gbase = 0;
+    uB = uA;
+    int pend = 0;        // vector-memory instructions issued after the copies of the tile that is gathered next (a lower bound)
+    unsigned cold = 0;   // bit k: tile k is outside the fast path
+    auto issue = [&](const V3Uni& u, int parity) -> int {      // the copies of a tile's box into its region of the ring
+        const uint32_t off = ring_lds + (parity ? (uint32_t)(V3_RING - u.bytes) : 0u);
+        return (f.flags & V3F_WIDE_SRC) ? v3_stage_box<16>(f.src, u.gbase, f.sstride, off, u.pitch, u.rowb, u.nrows, lane)
+                                        : v3_stage_box<4>(f.src, u.gbase, f.sstride, off, u.pitch, u.rowb, u.nrows, lane);
+    };
+#ifdef WV_STAMPS     // diagnostics build (tools/warp_stamps3.py): shader-clock stamps at the phase boundaries of a step
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long wall0 = wall_clock64();
+#define V3_STAMP(i) st[i] = __builtin_readcyclecounter()
+#else
+#define V3_STAMP(i)
+#endif
+    // one pipeline step: map + copies of tile k + 1 (into `nw`, `nu`), gather + stores of tile k (from `cw`, `cu`)
+    auto step = [&](int k, unsigned* cw, unsigned& cmsk, V3Uni& cu_, unsigned* nw, unsigned& nmsk, V3Uni& nu) {
+        const int ty0 = (ty_first + k) * V3_TH, parity = k & 1;
+        bool deferred = false;
+        V3_STAMP(0);
+        if (k + 1 < nt) {
+            v3_map(f, rowtab, cs.x, cs.y, ty0 + V3_TH, ring_lds, parity ^ 1, nw, nmsk, nu);
+            V3_STAMP(1);
+            if (nu.fast) {
+                if (k < 0) { issue(nu, parity ^ 1); pend = 0; }     // the strip's first tile: nothing is younger than its copies yet
+                else if (cu_.bytes + nu.bytes <= V3_RING) pend += issue(nu, parity ^ 1);
+                else deferred = true;
+            }
+        }
+        V3_STAMP(2);
+        if (k >= 0) {
+            WSTAT(cu_.fast ? (cu_.interior ? 0 : 1) : 2);
+            if (deferred) WSTAT(4);
+            if (cu_.fast) {
+                const uint32_t reg = ring_lds + (parity ? (uint32_t)(V3_RING - cu_.bytes) : 0u);
+                unsigned p[V3_TH][3];     // a channel in the upper 16 bits
+                wait_vm_dyn(pend);
+                V3_STAMP(3);
+                // (the empty asm makes a pixel's word opaque per branch: otherwise the common decode of all pixels is hoisted above
+                // the branch and lives in 5 VGPRs per pixel)
+                if (cu_.interior) {
+#pragma unroll
+                    for (int i = 0; i < V3_TH; i++) {
+                        unsigned w = cw[i];
+                        asm volatile("" : "+v"(w));
+#if WV_ABL == 2
+                        p[i][0] = w << 16; p[i][1] = w << 8; p[i][2] = w;
+#else
+                        v3_sample<true>(cu_.pitch, w, p[i]);
+#endif
+                        if (i % V3_GG == V3_GG - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V3_TH; i++) {
+                        unsigned w = cw[i];
+                        asm volatile("" : "+v"(w));
+                        v3_sample<false>(cu_.pitch, w, p[i]);
+                        if (i % V3_GG == V3_GG - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const bool ones = cu_.interior != 0;     // (uniform) all taps inside the frame: every lane's mask bits are set
+                int nst = 0;
+                asm volatile("" ::"v"(p[V3_TH - 1][2]));
+                V3_STAMP(4);
+                // 8 rows at a time through the (spent) region: a lane's column of 8 pixels -> rows of 384 bytes -> 16-byte pieces
+#pragma unroll
+                for (int g = 0; g < V3_TH / 8; g++) {
+                    lds_p ob = (lds_p)(uintptr_t)(reg + lane * 6);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        // three 2-byte writes (volatile: merged into 4-byte writes at lane * 6 they are misaligned in every other lane,
+                        // and the LDS then takes ~40 cycles per instruction: SQ_LDS_IDX_ACTIVE, gpurun_out/r3_pmc_v31.txt)
+                        volatile __attribute__((address_space(3))) uint16_t* o = (volatile __attribute__((address_space(3))) uint16_t*)(ob + i * (V3_TW * 6));
+                        o[0] = (uint16_t)(p[8 * g + i][0] >> 16); o[1] = (uint16_t)(p[8 * g + i][1] >> 16); o[2] = (uint16_t)(p[8 * g + i][2] >> 16);    // ds_write_b16_d16_hi
+                    }
+                    if (!ones) {
+                        lds_p om = (lds_p)(uintptr_t)(reg + V3_OUT_IMG + lane);
+#pragma unroll
+                        for (int i = 0; i < 8; i++) om[i * V3_TW] = (cmsk >> (8 * g + i) & 1) ? (uint8_t)255 : (uint8_t)0;
+                    }
+                    uint8_t* dg = drow + (size_t)(8 * g) * f.dstride;
+                    uint8_t* mg = mrow + (size_t)(8 * g) * f.mstride;
+                    const int gy0 = ty0 + 8 * g;
+                    if (valid_px == V3_TW && gy0 + 8 <= f.dh) {
+                        u4v v[3];
+#pragma unroll
+                        for (int kk = 0; kk < 3; kk++) v[kk] = *(const __attribute__((address_space(3))) u4v*)(uintptr_t)(reg + loff + kk * 128);
+#pragma unroll
+                        for (int kk = 0; kk < 3; kk++) {
+#if WV_ABL == 1
+                            asm volatile("" ::"v"(v[kk]), "v"(dg + poff + kk * 128));
+#else
+                            v3_store_piece(dg + poff + kk * 128, v[kk], wide_out);
+#endif
+                        }
+                        const u2v mv = ones ? u2v{0xffffffffu, 0xffffffffu} : *(const __attribute__((address_space(3))) u2v*)(uintptr_t)(reg + V3_OUT_IMG + lane * 8);
+#if WV_ABL == 1
+                        asm volatile("" ::"v"(mv), "v"(mg + moff));
+#else
+                        if (wide_mask) *reinterpret_cast<u2v*>(mg + moff) = mv;
+                        else { volatile uint16_t* q = reinterpret_cast<volatile uint16_t*>(mg + moff); q[0] = (uint16_t)mv.x; q[1] = (uint16_t)(mv.x >> 16); q[2] = (uint16_t)mv.y; q[3] = (uint16_t)(mv.y >> 16); }
+#endif
+                        nst += (wide_out ? 3 : 0) + (wide_mask ? 1 : 0);     // (narrow stores: not counted -- a lower bound keeps the wait safe)
+                    } else if (gy0 < f.dh) {
+                        // edge groups (the roi's last columns / rows): whole pieces where they fit, single shorts / bytes for the rest
+#pragma unroll
+                        for (int kk = 0; kk < 3; kk++) {
+                            const int prow = lane >> 3, pcb = ((lane & 7) + 8 * kk) * 16;
+                            if (gy0 + prow >= f.dh || pcb >= valid_bytes) continue;
+                            const u4v v = *(const __attribute__((address_space(3))) u4v*)(uintptr_t)(reg + loff + kk * 128);
+                            uint8_t* d = dg + poff + kk * 128;
+                            if (pcb + 16 <= valid_bytes) v3_store_piece(d, v, wide_out);
+                            else {
+                                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int s2 = 0; s2 < 8; s2++)
+                                    if (pcb + 2 * s2 < valid_bytes) reinterpret_cast<uint16_t*>(d)[s2] = (uint16_t)(w4[s2 >> 1] >> (16 * (s2 & 1)));
+                            }
+                        }
+                        const int mr = lane >> 3, mc = (lane & 7) * 8;
+                        if (gy0 + mr < f.dh && mc < valid_px) {
+                            const u2v mv = ones ? u2v{0xffffffffu, 0xffffffffu} : *(const __attribute__((address_space(3))) u2v*)(uintptr_t)(reg + V3_OUT_IMG + lane * 8);
+                            const uint32_t w2[2] = {mv.x, mv.y};
+#pragma unroll
+                            for (int b = 0; b < 8; b++)
+                                if (mc + b < valid_px) mg[moff + b] = (uint8_t)(w2[b >> 2] >> (8 * (b & 3)));
+                        }
+                    }
+                }
+                V3_STAMP(5);
+                pend = nst;     // issued after the copies of tile k + 1
+            } else {
+                cold |= 1u << k;            // redone pixel by pixel after the loop (keeps the call out of the pipeline's registers)
+                pend = 0;
+            }
+            if (deferred) {     // the pair did not fit the ring together: tile k + 1's copies start now, into the space tile k left
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile k's reads of the ring have their data
+                issue(nu, parity ^ 1);
+                pend = 0;
+            }
+            drow += (size_t)V3_TH * f.dstride; mrow += (size_t)V3_TH * f.mstride;
+#ifdef WV_STAMPS
+            if (lane == 0) {
+                const int tile = (ty_first + k) * ((f.dw + V3_TW - 1) / V3_TW) + tx0 / V3_TW;
+                if (tile < 16384) { unsigned long long* o = g_warp_stamps + 8 * tile; for (int q = 0; q < 6; q++) o[q] = st[q]; o[6] = wall0; o[7] = wall_clock64(); }
+            }
+#endif
+        }
+    };
+#pragma unroll 1
+    for (int k = -1; k < nt; k += 2) {      // the two tiles in flight swap roles: no copies
+        step(k, wB, mskB, uB, wA, mskA, uA);
+        if (k + 1 < nt) step(k + 1, wA, mskA, uA, wB, mskB, uB);
+    }
+    if (cold) {
+        const V3Frame fc = f;       // a copy for the call: the kernel's own arguments stay in registers
+#pragma unroll 1
+        for (int k = 0; k < nt; k++)
+            if (cold >> k & 1) v3_cold_tile(fc, cs.x, cs.y, tx0 + lane, (ty_first + k) * V3_TH);
+    }
+}
+
+__device__ __forceinline__ bool v3_strip_of(int bid, int wave, int dw, int dh, int nt, int* tx0, int* ty_first) {
+    const int nsx = (dw + V3_TW - 1) / V3_TW, nty = (dh + V3_TH - 1) / V3_TH, nsy = (nty + nt - 1) / nt;
+    const int nwx = (nsx + V3_WAVES - 1) / V3_WAVES;
+    constexpr int WG_PER_CHUNK = WV3_CHX * WV3_CHY;
+    const int nchx = (nwx + WV3_CHX - 1) / WV3_CHX;
+    const int i = bid >> 3, chunk = (i / WG_PER_CHUNK) * 8 + (bid & 7), within = i % WG_PER_CHUNK;
+    const int chy = chunk / nchx, chx = chunk - chy * nchx;
+    const int wx = chx * WV3_CHX + within % WV3_CHX, wy = chy * WV3_CHY + within / WV3_CHX;
+    const int sx = wx * V3_WAVES + wave;
+    if (sx >= nsx || wy >= nsy) return false;
+    *tx0 = sx * V3_TW; *ty_first = wy * nt;
+    return true;
+}
+static int v3_grid_of(const WarpArgs& a, int nt) {
+    const int nsx = (a.dw + V3_TW - 1) / V3_TW, nty = (a.dh + V3_TH - 1) / V3_TH, nsy = (nty + nt - 1) / nt;
+    const int nwx = (nsx + V3_WAVES - 1) / V3_WAVES;
+    const int nchunks = ((nwx + WV3_CHX - 1) / WV3_CHX) * ((nsy + WV3_CHY - 1) / WV3_CHY);
+    return ((nchunks + 7) / 8) * 8 * WV3_CHX * WV3_CHY;
+}
+#ifndef WV3_NT_MAX
+#define WV3_NT_MAX 8       // <= 32: a strip's cold tiles are a bit mask
+#endif
+#ifndef WV3_SLOTS
+#define WV3_SLOTS 16       // strips wanted per compute unit before strips get longer
+#endif
+// Tiles per strip: long strips amortise the pipeline's fill, but a launch should still put WV3_SLOTS waves on every compute unit
+// (frames = the number of frames sharing the grid).
+static int v3_strip_tiles(const MisContext* ctx, const WarpArgs& a, int frames) {
+    const long long tiles = (long long)((a.dw + V3_TW - 1) / V3_TW) * ((a.dh + V3_TH - 1) / V3_TH) * std::max(frames, 1);
+    const long long nt = tiles / ((long long)std::max(ctx->num_cu, 1) * WV3_SLOTS);
+    return (int)std::min<long long>(WV3_NT_MAX, std::max<long long>(1, nt));
+}
+static V3Frame v3_frame_of(const WarpArgs& a, const float* tab) {
+    V3Frame f;
+    for (int i = 0; i < 9; i++) f.m[i] = a.m[i];
+    const float xhi = (float)a.sw - 0.5f, yhi = (float)a.sh - 0.5f;     // exact: sizes < 2^15
+    // v < hi || (even && v == hi)  <=>  v < hi2 with hi2 the next float above hi when the end point rounds inside (ties to even)
+    f.xhi2 = ((a.sw - 1) & 1) == 0 ? nextafterf(xhi, 2.f * xhi) : xhi;
+    f.yhi2 = ((a.sh - 1) & 1) == 0 ? nextafterf(yhi, 2.f * yhi) : yhi;
+    f.sw = a.sw; f.sh = a.sh; f.dw = a.dw; f.dh = a.dh; f.ncol = trig_cols(a.dw);
+    const unsigned long long total = (unsigned long long)(a.sh - 1) * a.sstride + (unsigned long long)a.sw * 3;      // last valid byte + 1
+    const bool small = total < (1ull << 32) && a.sstride < (1ull << 31) && a.dstride < (1ull << 28) && a.mstride < (1ull << 28);
+    f.sstride = (unsigned)a.sstride; f.dstride = (unsigned)a.dstride; f.mstride = (unsigned)a.mstride; f.total_bytes = (unsigned)total;
+    f.flags = 0;
+    if ((((size_t)a.src | a.sstride) & 15) == 0) f.flags |= V3F_WIDE_SRC;
+    // |z| <= |m6| + |m7| + |m8| bounds z from above; dword-aligned frames below 4 GB only
+    if (small && (((size_t)a.src | a.sstride) & 3) == 0 && fabsf(a.m[6]) + fabsf(a.m[7]) + fabsf(a.m[8]) <= 1048576.f) f.flags |= V3F_FAST_OK;
+    if ((((size_t)a.dst | a.dstride) & 15) == 0) f.flags |= V3F_WIDE_OUT;
+    if ((((size_t)a.mask | a.mstride) & 7) == 0) f.flags |= V3F_WIDE_MASK;
+    f.src = a.src; f.dst = (uint8_t*)a.dst; f.mask = a.mask; f.tab = tab;
+    return f;
+}
+struct V3Batch {
+    V3Frame f[WB_MAX];
+    int nwg[WB_MAX];
+};
+
+__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_kernel(V3Frame f, int nt) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx0, ty_first;
+    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
+    warp_strip_body(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
+}
+__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_batch_kernel(V3Batch b, int nt) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
+    const int fi = blockIdx.y;
+    if ((int)blockIdx.x >= b.nwg[fi]) return;      // the grid covers the largest frame of the batch
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const V3Frame& f = b.f[fi];
+    int tx0, ty_first;
+    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
+    warp_strip_body(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
+}
+
 // General warp (seam-scale path and plain masks): u8 with CN channels, one column per lane.
 template <int CN, bool LINEAR>
 __global__ __launch_bounds__(256) void warp_u8_kernel(WarpArgs a) {
@@ -724,8 +1366,6 @@ extern "C" int mis_debug_warp_stats(unsigned* out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_warp_stats), sizeof(unsigned) * 8);
     if (reset) { unsigned z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_warp_stats), z, sizeof(z)); }
-    return 0;
-}
     return 0;
 }
 #endif
@@ -810,8 +1450,16 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
         MIS_HIP(ctx, hipEventCreate(&e1));
         MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
+#if WV_V3
+    (void)nwg; (void)ntiles;
+    const int nt = v3_strip_tiles(ctx, a, 1);
+    const int nwg3 = v3_grid_of(a, nt);
+    for (int rep = 0; rep < repeats; rep++)
+        hipLaunchKernelGGL(warp_strip_kernel, dim3(nwg3), dim3(64 * V3_WAVES), 0, ctx->stream, v3_frame_of(a, tab), nt);
+#else
     for (int rep = 0; rep < repeats; rep++)
         hipLaunchKernelGGL(warp_fused_kernel, dim3(nwg), dim3(64 * TILE_WAVES), 0, ctx->stream, a, (const float*)tab, ntiles);
+#endif
     if (avg_us) {
         float ms = 0.f;
         MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -891,6 +1539,10 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<WarpBatch> batches;
     std::vector<dim3> grids;
+#if WV_V3
+    int nt3 = 1 << 30;      // tiles per strip: one value for the grid (the smallest any frame asks for)
+    for (int i = 0; i < n; i++) nt3 = std::min(nt3, v3_strip_tiles(ctx, args[i], n));
+#endif
     for (int g0 = 0; g0 < n; g0 += WB_MAX) {
         const int ng = std::min(WB_MAX, n - g0);
         WarpBatch b;
@@ -899,6 +1551,9 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
             const int i = g0 + (k < ng ? k : 0);
             b.a[k] = args[i]; b.tab[k] = (const float*)((uint8_t*)ctx->stage + tab_off[i]);
             b.nwg[k] = grid_of(args[i], &b.ntiles[k]);
+#if WV_V3
+            b.nwg[k] = v3_grid_of(args[i], nt3);
+#endif
             if (k < ng) { max_wg = std::max(max_wg, b.nwg[k]); max_trig = std::max(max_trig, (trig_cols(args[i].dw) + args[i].dh + 255) / 256); }
         }
         hipLaunchKernelGGL(warp_trig_batch_kernel, dim3(max_trig, ng), dim3(256), 0, ctx->stream, b);
@@ -911,7 +1566,15 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
     }
     for (int rep = 0; rep < repeats; rep++)
         for (size_t g = 0; g < batches.size(); g++)
+#if WV_V3
+            {
+                V3Batch vb;
+                for (int k = 0; k < WB_MAX; k++) { vb.f[k] = v3_frame_of(batches[g].a[k], batches[g].tab[k]); vb.nwg[k] = batches[g].nwg[k]; }
+                hipLaunchKernelGGL(warp_strip_batch_kernel, grids[g], dim3(64 * V3_WAVES), 0, ctx->stream, vb, nt3);
+            }
+#else
             hipLaunchKernelGGL(warp_fused_batch_kernel, grids[g], dim3(64 * TILE_WAVES), 0, ctx->stream, batches[g]);
+#endif
     if (avg_us) {
         float ms = 0.f;
         MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));

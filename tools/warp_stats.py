@@ -16,4 +16,4 @@ for wl in ("config3", "config4"):
         ctx.lib.mis_debug_warp_stats(out, 1)
         w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
         ctx.lib.mis_debug_warp_stats(out, 1)
-        print(wl, idx, "roi", roi, "interior %d folded %d global %d generic-map %d" % tuple(out[:4]), "mask frac %.3f" % (msk.float().mean().item() / 255))
+        print(wl, idx, "roi", roi, "interior %d folded %d cold/global %d generic-map %d not-overlapped %d" % tuple(out[:5]), "mask frac %.3f" % (msk.float().mean().item() / 255))
