@@ -870,6 +870,7 @@ __device__ __forceinline__ unsigned v3_pack(int addr, unsigned xq, unsigned yq, 
 // Map stage: backward map of a lane's column x V3_TH rows of the tile at rows ty0.., box reduction, classification, packing
 // (tile_map's logic; the cold decisions only set u.fast = 0: the per-pixel loop redoes such a tile from scratch).
 // ring_lds / parity: where the tile's region of the ring will be (even tiles from the bottom, odd tiles from the top).
+template <int RING>
 __device__ __forceinline__ void v3_map(const V3Frame& f, cf4p rowtab, float su, float cu, int ty0, uint32_t ring_lds, int parity,
                                        unsigned* w, unsigned& msk_out, V3Uni& u) {
     int xq[V3_TH], yq[V3_TH];
@@ -940,17 +941,18 @@ __device__ __forceinline__ void v3_map(const V3Frame& f, cf4p rowtab, float su, 
     const int amask = wide ? 15 : 3;
     const int shift = (bx0 * 3) & amask;
     const int rowb = ((bx1 - bx0 + 1) * 3 + shift + amask) & ~amask;
-    const int pitch = (rowb + V3_PITCH_ALIGN - 1) & ~(V3_PITCH_ALIGN - 1);
     const int nrows = by1 - by0 + 1;
+    const int pitch_cf = (rowb + V3_PITCH_ALIGN - 1) & ~(V3_PITCH_ALIGN - 1);       // conflict free; the tight pitch when that takes more than the tile's share of the ring
+    const int pitch = nrows * pitch_cf <= RING / 2 ? pitch_cf : rowb;
     const unsigned gbase = (unsigned)by0 * f.sstride + (unsigned)(bx0 * 3 - shift);    // frames are < 4 GB on the fast path
-    const bool fast = good && (interior || foldable) && nrows * pitch <= V3_RING && pitch <= (wide ? 1024 : 256) &&
+    const bool fast = good && (interior || foldable) && nrows * pitch <= RING && pitch <= (wide ? 1024 : 256) &&
                       gbase + (unsigned)(nrows - 1) * f.sstride + (unsigned)rowb <= f.total_bytes;
     u.fast = fast; u.interior = interior; u.pitch = pitch; u.rowb = rowb; u.nrows = nrows; u.gbase = gbase;
     u.bytes = fast ? max((nrows * pitch + 15) & ~15, V3_OUT_BYTES) : V3_OUT_BYTES;
     unsigned msk = (1u << V3_TH) - 1u;
     if (fast) {
         // LDS address of source pixel (0, 0) in the tile's region
-        const int lbase = (int)ring_lds + (parity ? V3_RING - u.bytes : 0) + shift - by0 * pitch - bx0 * 3;
+        const int lbase = (int)ring_lds + (parity ? RING - u.bytes : 0) + shift - by0 * pitch - bx0 * 3;
         // integer parts: sign-extended bits 5..21 of the biased values (one v_bfe_i32 each)
         if (interior) {
 #pragma unroll
@@ -1042,6 +1044,9 @@ __device__ __forceinline__ void v3_store_piece(uint8_t* p, u4v v, bool wide_out)
 }
 
 // The strip a wave owns: columns tx0 .. tx0 + 63, tiles ty_first .. ty_first + nt - 1 (V3_TH rows each).
+// PIPE = false: the same stages one tile after the other (map, copies, wait, gather, stores) -- no second tile in flight, fewer
+// registers, more waves per SIMD: the form for a launch of ONE frame, whose strips are too short to fill a pipeline.
+template <bool PIPE, int RING>
 __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int ty_first, int nt, lds_p ring) {
     const int lane = threadIdx.x & 63;
     const int nty = (f.dh + V3_TH - 1) / V3_TH;
@@ -1070,7 +1075,7 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
     int pend = 0;        // vector-memory instructions issued after the copies of the tile that is gathered next (a lower bound)
     unsigned cold = 0;   // bit k: tile k is outside the fast path
     auto issue = [&](const V3Uni& u, int parity) -> int {      // the copies of a tile's box into its region of the ring
-        const uint32_t off = ring_lds + (parity ? (uint32_t)(V3_RING - u.bytes) : 0u);
+        const uint32_t off = ring_lds + (parity ? (uint32_t)(RING - u.bytes) : 0u);
         return (f.flags & V3F_WIDE_SRC) ? v3_stage_box<16>(f.src, u.gbase, f.sstride, off, u.pitch, u.rowb, u.nrows, lane)
                                         : v3_stage_box<4>(f.src, u.gbase, f.sstride, off, u.pitch, u.rowb, u.nrows, lane);
     };
@@ -1083,15 +1088,20 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
 #endif
     // one pipeline step: map + copies of tile k + 1 (into `nw`, `nu`), gather + stores of tile k (from `cw`, `cu`)
     auto step = [&](int k, unsigned* cw, unsigned& cmsk, V3Uni& cu_, unsigned* nw, unsigned& nmsk, V3Uni& nu) {
-        const int ty0 = (ty_first + k) * V3_TH, parity = k & 1;
+        const int ty0 = (ty_first + k) * V3_TH, parity = PIPE ? (k & 1) : 0;
         bool deferred = false;
         V3_STAMP(0);
-        if (k + 1 < nt) {
-            v3_map(f, rowtab, cs.x, cs.y, ty0 + V3_TH, ring_lds, parity ^ 1, nw, nmsk, nu);
+        if (!PIPE) {        // tile k itself: map, copies, (wait for everything)
+            v3_map<RING>(f, rowtab, cs.x, cs.y, ty0, ring_lds, 0, cw, cmsk, cu_);
+            V3_STAMP(1);
+            if (cu_.fast) issue(cu_, 0);
+            pend = 0;
+        } else if (k + 1 < nt) {
+            v3_map<RING>(f, rowtab, cs.x, cs.y, ty0 + V3_TH, ring_lds, parity ^ 1, nw, nmsk, nu);
             V3_STAMP(1);
             if (nu.fast) {
                 if (k < 0) { issue(nu, parity ^ 1); pend = 0; }     // the strip's first tile: nothing is younger than its copies yet
-                else if (cu_.bytes + nu.bytes <= V3_RING) pend += issue(nu, parity ^ 1);
+                else if (cu_.bytes + nu.bytes <= RING) pend += issue(nu, parity ^ 1);
                 else deferred = true;
             }
         }
@@ -1100,7 +1110,7 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
             WSTAT(cu_.fast ? (cu_.interior ? 0 : 1) : 2);
             if (deferred) WSTAT(4);
             if (cu_.fast) {
-                const uint32_t reg = ring_lds + (parity ? (uint32_t)(V3_RING - cu_.bytes) : 0u);
+                const uint32_t reg = ring_lds + (parity ? (uint32_t)(RING - cu_.bytes) : 0u);
                 unsigned p[V3_TH][3];     // a channel in the upper 16 bits
                 wait_vm_dyn(pend);
                 V3_STAMP(3);
@@ -1216,10 +1226,15 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
 #endif
         }
     };
+    if (PIPE) {
 #pragma unroll 1
-    for (int k = -1; k < nt; k += 2) {      // the two tiles in flight swap roles: no copies
-        step(k, wB, mskB, uB, wA, mskA, uA);
-        if (k + 1 < nt) step(k + 1, wA, mskA, uA, wB, mskB, uB);
+        for (int k = -1; k < nt; k += 2) {      // the two tiles in flight swap roles: no copies
+            step(k, wB, mskB, uB, wA, mskA, uA);
+            if (k + 1 < nt) step(k + 1, wA, mskA, uA, wB, mskB, uB);
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < nt; k++) step(k, wA, mskA, uA, wB, mskB, uB);
     }
     if (cold) {
         const V3Frame fc = f;       // a copy for the call: the kernel's own arguments stay in registers
@@ -1286,12 +1301,36 @@ struct V3Batch {
     int nwg[WB_MAX];
 };
 
+#ifndef WV3_SEQ_WAVES_MIN
+#define WV3_SEQ_WAVES_MIN 6
+#endif
+#ifndef WV3_SEQ_NT
+#define WV3_SEQ_NT 1           // tiles per wave of the one-frame launch
+#endif
+#ifndef WV3_SINGLE
+#define WV3_SINGLE 0           // one-frame launches: 0 = round 2's tile kernel (fastest there: 24.6 us vs 27.5 / 28.1, gpurun_out/r3_v3_var9.txt), 1 = strips without overlap, 2 = pipelined strips
+#endif
+#ifndef WV3_SINGLE_NT_MAX
+#define WV3_SINGLE_NT_MAX 1
+#endif
+#ifndef WV3_SEQ_RING
+#define WV3_SEQ_RING 6144      // one box per wave: boxes beyond it take the per-pixel loop
+#endif
+static_assert(WV3_SEQ_RING >= V3_OUT_BYTES, "a tile's output group must fit its region");
 __global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_kernel(V3Frame f, int nt) {
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx0, ty_first;
     if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
-    warp_strip_body(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
+    warp_strip_body<true, V3_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
+}
+// one frame per launch (mis_warp_spherical_fused): short strips, one tile at a time per wave
+__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_SEQ_WAVES_MIN, 8))) void warp_strip_seq_kernel(V3Frame f, int nt) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][WV3_SEQ_RING];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx0, ty_first;
+    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
+    warp_strip_body<false, WV3_SEQ_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
 }
 __global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_batch_kernel(V3Batch b, int nt) {
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
@@ -1301,7 +1340,7 @@ __global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const V3Frame& f = b.f[fi];
     int tx0, ty_first;
     if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
-    warp_strip_body(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
+    warp_strip_body<true, V3_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
 }
 
 // General warp (seam-scale path and plain masks): u8 with CN channels, one column per lane.
@@ -1450,9 +1489,15 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
         MIS_HIP(ctx, hipEventCreate(&e1));
         MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
-#if WV_V3
+#if WV_V3 && WV3_SINGLE == 1        // one tile at a time per wave
     (void)nwg; (void)ntiles;
-    const int nt = v3_strip_tiles(ctx, a, 1);
+    const int nt = WV3_SEQ_NT;
+    const int nwg3 = v3_grid_of(a, nt);
+    for (int rep = 0; rep < repeats; rep++)
+        hipLaunchKernelGGL(warp_strip_seq_kernel, dim3(nwg3), dim3(64 * V3_WAVES), 0, ctx->stream, v3_frame_of(a, tab), nt);
+#elif WV_V3 && WV3_SINGLE == 2      // the pipelined strips, as short as the frame's tile count asks
+    (void)nwg; (void)ntiles;
+    const int nt = std::min(v3_strip_tiles(ctx, a, 1), WV3_SINGLE_NT_MAX);
     const int nwg3 = v3_grid_of(a, nt);
     for (int rep = 0; rep < repeats; rep++)
         hipLaunchKernelGGL(warp_strip_kernel, dim3(nwg3), dim3(64 * V3_WAVES), 0, ctx->stream, v3_frame_of(a, tab), nt);
