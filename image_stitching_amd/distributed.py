@@ -166,6 +166,7 @@ class HipEngine:
         self._compose_stream_handle = h
         self.compose_stream = torch.cuda.ExternalStream(h.value, device=ctx.device)
         self.cctx = st.Context(ctx.device.index, stream=h.value)
+        self.exchange_device = ctx.device     # where the buffers of the N > 1 exchanges live (distributed.stage_seam)
         self.speculative_compose = True
 
     # ---- features ----
@@ -263,6 +264,8 @@ class HipEngine:
     def warp_feed_seam_many(self, frames, cams, rois, ks):
         """warp_feed_seam for a list of frames (ks: their indices among the kept frames): one batched warp, gains and seam mask per
         frame, one batched feed -- the same accumulators as the per-frame sequence."""
+        if not frames:       # every frame of this rank was pruned: nothing to warp or feed (the collectives around still run)
+            return
         warped = self.warper.warp_fused_batch(frames, cams, rois)
         compensator, seam_masks = self._seam
         for (tl, img_s, mask), k in zip(warped, ks):
@@ -520,7 +523,9 @@ class StitchJob:
             for k, (i, it) in enumerate(zip(mine, local)):
                 meta[k] = torch.tensor([i, it[0][0], it[0][1], it[2].shape[1], it[2].shape[0]], dtype=torch.int32)
             meta[len(mine):, 0] = -1
-            dev = local[0][1].device if local else torch.device("cpu")
+            # the device the exchange buffers live on is the engine's, also when this rank has no frame left after the pruning
+            # (a CPU tensor handed to an RCCL all-gather raises on this rank and leaves the others in the collective)
+            dev = torch.device(getattr(eng, "exchange_device", None) or (local[0][1].device if local else "cpu"))
             meta_all = self.comm.all_gather(meta.to(dev)).flatten(0, 1).cpu()
             cap = max(int((meta_all[:, 3] * meta_all[:, 4]).max()), 1)
             bufs = [eng.seam_pack(it, cap) for it in local] + [torch.zeros(cap * 4, dtype=torch.uint8, device=dev) for _ in range(per - len(mine))]

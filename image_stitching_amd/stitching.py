@@ -188,6 +188,8 @@ class SphericalWarper:
         """mis_warp_spherical_fused_batch: the compose-scale step of main() for all frames (one grid per 16 frames)
         -> [(tl, img_warped_s, mask_warped)], the results of warp_fused per frame."""
         n = len(imgs)
+        if n == 0:
+            return []
         outs = [self.alloc_fused(r) for r in rois]
         im = (capi.MisImage * n)(*[as_image(i) for i in imgs])
         ds = (capi.MisImage * n)(*[as_image(o[0]) for o in outs])

@@ -26,25 +26,33 @@ def _cams():
     return [synth.make_camera(W, H, 60.0, 13.0 * i - 20.0, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i in range(NFRAMES)]
 
 
-def _run_job(rank, world, group, seam=False):
+def _cams_stray_block():
+    """Frames 0, 1 overlap; frames 2, 3 (rank 1's whole block at world size 2) look elsewhere and at nothing of each other:
+    leaveBiggestComponent keeps [0, 1] and rank 1 is left without a frame."""
+    import synth
+    yaws = [-6.0, 7.0, 105.0, -150.0]
+    return [synth.make_camera(W, H, 60.0, y, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5)) for i, y in enumerate(yaws)]
+
+
+def _run_job(rank, world, group, seam=False, stray=False):
     import synth
     from image_stitching_amd.distributed import StitchJob
     from image_stitching_amd.stitching import StitchConfig
     from oracle_engine import OracleEngine
-    cams = _cams()
+    cams = _cams_stray_block() if stray else _cams()
     cfg = StitchConfig(seam_megapix=0.02) if seam else StitchConfig.hot_path()     # seam: the reference's defaults (gain_blocks + dp_color)
     job = StitchJob(None, (W, H), cams, rank=rank, world_size=world, group=group, engine=OracleEngine((W, H), config=cfg), config=cfg)
     frames = {i: synth.render_frame(cams[i]) for i in job.my_frames}
     return job, job.run(frames)
 
 
-def _worker(rank, world, port, out_path, seam=False):
+def _worker(rank, world, port, out_path, seam=False, stray=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        job, out = _run_job(rank, world, dist.group.WORLD, seam)
+        job, out = _run_job(rank, world, dist.group.WORLD, seam, stray)
         assert job.my_frames == list(range(rank * 2, rank * 2 + 2))
         if rank == 0:
             np.savez(out_path, pano=out["pano"], mask=out["mask"], conf=out["confidence"].numpy(), indices=np.array(out["indices"]),
@@ -154,6 +162,21 @@ def test_two_rank_job_with_seam_step_matches_single_rank(tmp_path):
     d = np.abs(got["pano"].astype(np.int32) - ref["pano"].astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.02
     assert not np.array_equal(ref["pano"], plain["pano"])        # the seam step did change the panorama
+
+
+def test_two_rank_seam_job_when_one_ranks_block_is_pruned(tmp_path):
+    """Reference-default configuration (gain_blocks + dp_color) at N = 2 with rank 1's whole frame block stray: that rank has
+    nothing to warp at seam scale or at compose scale but must stay in every collective (it used to leave the job with a
+    ValueError from an empty batch, or to hand a CPU tensor to the all-gather, and the other rank hung in the next collective)."""
+    _, ref = _run_job(0, 1, None, seam=True, stray=True)
+    assert ref["indices"] == [0, 1]
+    out_path = str(tmp_path / "rank0.npz")
+    mp.start_processes(_worker, args=(2, _free_port(), out_path, True, True), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out_path)
+    assert list(got["indices"]) == [0, 1]
+    assert np.array_equal(got["mask"], ref["mask"])
+    d = np.abs(got["pano"].astype(np.int32) - ref["pano"].astype(np.int32))
+    assert d.max() <= 1
 
 
 def test_job_refuses_options_it_does_not_run():
