@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--pipeline", default="hot_path", choices=["hot_path", "reference_default"],
                     help="hot_path (the north star: no exposure / seam step) | reference_default (gain_blocks compensator + dp_color seams, rows N1b; not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpp-host", action="store_true", help="skip the C++-host leg (host/stitch_bench on the same workload)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
     ap.add_argument("--no-single-base", action="store_true", help="N > 1: skip the unsharded run of the same workload on rank 0")
     ap.add_argument("--roofline-launches", type=int, default=200)
@@ -225,6 +226,8 @@ def main():
                        "warp_roi": "computed inside every timed step (mis_warp_roi_batch: one kernel for all frames, nothing cached)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not args.no_cpp_host:
+            res["cpp_host"] = cpp_host_leg(cams, args)       # the same job driven from C++ (host/stitch_bench), after this process's GPU work
         if single:
             res["same_workload_on_1_gpu"] = single
             res["speedup_vs_1_gpu_same_workload"] = round(value / single["value"], 3)
@@ -383,6 +386,33 @@ def measure_roofline(ctx, job, frames, cams, launches):
             "aggregate_fused_model": {"achieved": round(ach_fused, 1), "frac": round(ach_fused / 8000.0, 4),
                                       "what": "the same aggregate with the finalise leg costed at its fused minimum instead of 44.3 B/px"},
             "parts": parts}
+
+
+def cpp_host_leg(cams, args):
+    """The same job (frames in HBM, ORB -> matcher with the composition speculated from its hook -> collapse) driven by the C++ host
+    over the C ABI: host/stitch_bench as a child process (this process's timed region is over; the child owns the GPU meanwhile)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "host", "stitch_bench")
+    if not os.path.exists(exe):
+        return {"error": "host/stitch_bench is not built (make -C host)"}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cams.txt")
+        with open(path, "w") as fh:
+            fh.write("%d %d %d\n" % (len(cams), cams[0]["width"], cams[0]["height"]))
+            for c in cams:
+                vals = [c["f"], c["K"][0, 2], c["K"][1, 2], c.get("gain", 1.0)] + [float(v) for v in np.asarray(c["R"], np.float64).reshape(9)]
+                fh.write(" ".join(repr(float(v)) for v in vals) + "\n")
+        try:
+            r = subprocess.run([exe, path, "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            return {"error": "host/stitch_bench timed out"}
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-300:]}
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return {"error": "no result line from host/stitch_bench"}
 
 
 def _host_cores():

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mis_stream_destroy": (_i, [_vp]),
     "mis_context_destroy": (_i, [_vp]),
     "mis_context_synchronize": (_i, [_vp]),
+    "mis_context_wait": (_i, [_vp, _vp]),
     "mis_last_error": (C.c_char_p, [_vp]),
     "mis_version": (C.c_char_p, []),
     "mis_image_free": (_i, [_vp, _P(MisImage)]),

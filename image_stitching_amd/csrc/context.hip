@@ -112,6 +112,21 @@ extern "C" int mis_context_synchronize(MisContext* ctx) {
     return MIS_OK;
 }
 
+// ctx's stream waits (on the device, the host does not block) for everything enqueued so far on other's stream
+extern "C" int mis_context_wait(MisContext* ctx, MisContext* other) {
+    if (!ctx || !other) return MIS_E_INVALID;
+    MIS_CHECK(ctx, ctx->device == other->device, MIS_E_INVALID, "the two contexts belong to different devices");
+    if (ctx->stream == other->stream) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    MIS_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, other->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+    hipEventDestroy(ev);       // released once the wait has consumed it
+    MIS_HIP(ctx, e);
+    return MIS_OK;
+}
+
 extern "C" const char* mis_last_error(const MisContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 extern "C" int mis_image_free(MisContext* ctx, MisImage* img) {

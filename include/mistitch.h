@@ -68,6 +68,10 @@ int mis_stream_create(int device, int priority, void** stream);
 int mis_stream_destroy(void* stream);
 int mis_context_destroy(MisContext* ctx);
 int mis_context_synchronize(MisContext* ctx);
+/* Device-side ordering between two contexts of one device: work enqueued on `ctx` after this call starts only after everything
+ * enqueued on `other` before it has finished (an event on other's stream; the host does not wait).  What the job does at its
+ * entry between the stream that produced the frames and its compose stream. */
+int mis_context_wait(MisContext* ctx, MisContext* other);
 const char* mis_last_error(const MisContext* ctx);
 const char* mis_version(void);
 int mis_image_free(MisContext* ctx, MisImage* img);

@@ -385,3 +385,54 @@ def test_exif_image_description_cpp_and_python_twins(tmp_path):
         path.write_bytes(bad)
         assert ser.exif_image_description(bad) is None
         assert subprocess.call([tool, "exif", str(path)]) == 3
+
+
+def write_cams_file(path, cams):
+    """Camera list in the text form host/stitch_bench reads (repr doubles round-trip exactly)."""
+    with open(path, "w") as fh:
+        fh.write("%d %d %d\n" % (len(cams), cams[0]["width"], cams[0]["height"]))
+        for c in cams:
+            vals = [c["f"], c["K"][0, 2], c["K"][1, 2], c.get("gain", 1.0)] + [float(v) for v in np.asarray(c["R"], np.float64).reshape(9)]
+            fh.write(" ".join(repr(float(v)) for v in vals) + "\n")
+
+
+def _read_dump(prefix):
+    lines = open(prefix + ".txt").read().splitlines()
+    pw, ph, bands = [int(v) for v in lines[0].split()]
+    indices = [int(v) for v in lines[1].split()]
+    nfeat = [int(v) for v in lines[2].split()]
+    conf = np.array([float(v) for v in lines[3].split()])
+    pano = np.fromfile(prefix + ".pano.s16", np.int16).reshape(ph, pw, 3)
+    mask = np.fromfile(prefix + ".mask.u8", np.uint8).reshape(ph, pw)
+    return dict(pano=pano, mask=mask, indices=indices, nfeat=nfeat, conf=conf, bands=bands)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stray", [False, True])
+def test_cpp_job_equals_python_job(tmp_path, ctx, stray):
+    """host/stitch_bench (mis::StitchJob: batched ORB, composition speculated from the matcher's hook, collapse) against the
+    Python job over the same C ABI on the same synthetic frames: indices, feature counts, confidences, panorama, mask --
+    byte for byte; with a stray frame the speculated panorama is replaced by the kept set's in both."""
+    import torch
+    import synth
+    import json
+    from image_stitching_amd.distributed import StitchJob
+    _build()
+    w, h = 640, 360
+    yaws = [-26.0, -13.0, 0.0, 13.0, 26.0, 150.0 if stray else 39.0]
+    cams = [synth.make_camera(w, h, 60.0, y, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5), 0.95 + 0.02 * i) for i, y in enumerate(yaws)]
+    cams_path, prefix = str(tmp_path / "cams.txt"), str(tmp_path / "out")
+    write_cams_file(cams_path, cams)
+    r = subprocess.run([os.path.join(HOST, "stitch_bench"), cams_path, "--steps", "2", "--warmup", "1", "--dump", prefix], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    got = _read_dump(prefix)
+    frames = {i: synth.render_frame_gpu(c) for i, c in enumerate(cams)}
+    ref = StitchJob(ctx, (w, h), cams).run(frames)
+    assert got["indices"] == ref["indices"] == ([0, 1, 2, 3, 4] if stray else [0, 1, 2, 3, 4, 5])
+    assert line["kept"] == len(ref["indices"]) and line["speculation_kept"] == (not stray)
+    assert got["nfeat"] == [len(f) for f in ref["features"]]
+    assert np.array_equal(got["conf"], np.asarray(ref["confidence"]).reshape(-1))
+    assert got["bands"] == ref["num_bands"]
+    assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
+    assert np.array_equal(got["pano"], ref["pano"].cpu().numpy())
