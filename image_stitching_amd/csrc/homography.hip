@@ -594,6 +594,47 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// ---- round 3: the pivot candidates live in registers, the searches are wave reductions ----
+// Lane t < n keeps the serial algorithm's candidate of row t (indR[t] and the value A[t][indR[t]]) and of column t (indC[t],
+// A[indC[t]][t]) in registers and updates the values itself when a rotation touches them (the INDICES of rows / columns other than
+// k, l stay stale, as in the serial code).  The pivot -- "first maximum over the row candidates 0 .. n-2, then the column
+// candidates 1 .. n-1" -- is an arg-max over (|value|, candidate order) by four DPP steps inside the 16-lane row; the four
+// re-scans after a rotation (row / column of k and of l: first maximum again) run in the wave's four DPP rows at once, one
+// candidate per lane.  Round 2's form re-read 32 LDS words and ran a 16-way tournament in every lane for the pivot (1470 of its
+// 3600 cycles per rotation) and scanned the four rows / columns serially in four lanes (850); values and results are identical.
+struct JCand {      // a candidate: signed value, order key (smaller wins ties), payload
+    double v;
+    int ord, a, b;
+};
+template <int CTRL>
+__device__ __forceinline__ JCand jc_dpp(const JCand& c) {
+    JCand r;
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(c.v), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(c.v), CTRL, 0xf, 0xf, false);
+    const int pk = __builtin_amdgcn_update_dpp(0, (c.ord << 16) | (c.a << 8) | c.b, CTRL, 0xf, 0xf, false);
+    r.v = __hiloint2double(hi, lo);
+    r.ord = pk >> 16; r.a = (pk >> 8) & 0xff; r.b = pk & 0xff;
+    return r;
+}
+// the better of two candidates: larger |v| (compared as the bit patterns of non-negative doubles), then smaller order
+__device__ __forceinline__ JCand jc_best(const JCand& x, const JCand& y) {
+    const unsigned long long ax = (unsigned long long)__double_as_longlong(x.v) & 0x7fffffffffffffffull;
+    const unsigned long long ay = (unsigned long long)__double_as_longlong(y.v) & 0x7fffffffffffffffull;
+    const bool take_y = ay > ax || (ay == ax && y.ord < x.ord);
+    JCand r;
+    r.v = take_y ? y.v : x.v; r.ord = take_y ? y.ord : x.ord; r.a = take_y ? y.a : x.a; r.b = take_y ? y.b : x.b;
+    return r;
+}
+// arg-max over each 16-lane DPP row (every lane of a row ends with the row's winner)
+__device__ __forceinline__ JCand jc_row_argmax(JCand c) {
+    c = jc_best(c, jc_dpp<0xB1>(c));      // quad_perm [1,0,3,2]
+    c = jc_best(c, jc_dpp<0x4E>(c));      // quad_perm [2,3,0,1]
+    c = jc_best(c, jc_dpp<0x141>(c));     // row_half_mirror
+    c = jc_best(c, jc_dpp<0x140>(c));     // row_mirror
+    return c;
+}
+constexpr int JC_NONE = 0x7fff;           // order of an empty candidate (value 0: loses every tie)
+
 template <int n>
 __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
     double* A = S.A; double* V = S.V; double* W = S.W;
@@ -604,6 +645,8 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
         int i, k, l, m;
         double mv;
         double Wt = 0;   // lane t < n keeps W[t] in a register: W[k], W[l] of a step are two lane reads, not an LDS round trip
+        int ir = 0, ic = 0;          // indR[t], indC[t]
+        double rv = 0, cv = 0;       // A[t][ir], A[ic][t] (signed)
         if (t < n) {
             for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
             Wt = A[(n + 1) * t];
@@ -613,53 +656,27 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
                     double val = fabs(A[n * k + i]);
                     if (mv < val) mv = val, m = i;
                 }
-                S.indR[k] = m;
+                ir = m; rv = A[n * k + m];
             }
             if (k > 0) {
                 for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
                     double val = fabs(A[n * i + k]);
                     if (mv < val) mv = val, m = i;
                 }
-                S.indC[k] = m;
+                ic = m; cv = A[n * m + k];
             }
         }
         wave_sync();
         const int maxIters = n * n * 30;
         if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
             JP_T(j0);
-            // pivot search of the serial loop: all index loads, then all value loads, then the compare chain -- with n a
-            // template parameter the loops unroll and the (broadcast) LDS reads go out back to back
-            int ir[n], ic[n];
-            double rv[n], cv[n];
-#pragma unroll
-            for (i = 0; i < n - 1; i++) ir[i] = S.indR[i];
-#pragma unroll
-            for (i = 1; i < n; i++) ic[i] = S.indC[i];
-#pragma unroll
-            for (i = 0; i < n - 1; i++) rv[i] = A[n * i + ir[i]];
-#pragma unroll
-            for (i = 1; i < n; i++) cv[i] = A[n * ic[i] + i];
-            // "first maximum" of the serial scan = a tournament in which the earlier candidate wins ties: depth 4-5
-            // instead of a chain of 16 dependent f64 compares.  Candidate order: rows 0 .. n-2, then columns 1 .. n-1.
-            // The candidates carry their signed value: the winner's is the pivot p (no further read).
-            double cand_v[2 * n - 2];
-            int cand_k[2 * n - 2], cand_l[2 * n - 2];
-#pragma unroll
-            for (i = 0; i < n - 1; i++) { cand_v[i] = rv[i]; cand_k[i] = i; cand_l[i] = ir[i]; }
-#pragma unroll
-            for (i = 1; i < n; i++) { cand_v[n - 2 + i] = cv[i]; cand_k[n - 2 + i] = ic[i]; cand_l[n - 2 + i] = i; }
-#pragma unroll
-            for (int width = 1; width < 2 * n - 2; width *= 2) {
-#pragma unroll
-                for (i = 0; i + width < 2 * n - 2; i += 2 * width) {
-                    const bool right = fabs(cand_v[i]) < fabs(cand_v[i + width]);   // strictly greater: the later candidate must beat the earlier
-                    cand_v[i] = right ? cand_v[i + width] : cand_v[i];
-                    cand_k[i] = right ? cand_k[i + width] : cand_k[i];
-                    cand_l[i] = right ? cand_l[i + width] : cand_l[i];
-                }
-            }
-            k = __builtin_amdgcn_readfirstlane(cand_k[0]); l = __builtin_amdgcn_readfirstlane(cand_l[0]);   // uniform: every lane read the same LDS words
-            const double p = cand_v[0];
+            // pivot: candidate order = rows 0 .. n-2 (order t), then columns 1 .. n-1 (order n - 2 + t)
+            JCand rc, cc;
+            rc.v = t < n - 1 ? rv : 0.; rc.ord = t < n - 1 ? t : JC_NONE; rc.a = t; rc.b = ir;
+            cc.v = (t >= 1 && t < n) ? cv : 0.; cc.ord = (t >= 1 && t < n) ? n - 2 + t : JC_NONE; cc.a = ic; cc.b = t;
+            const JCand win = jc_row_argmax(jc_best(rc, cc));
+            k = __builtin_amdgcn_readfirstlane(win.a); l = __builtin_amdgcn_readfirstlane(win.b);   // lane 0 sits in the row of lanes 0 .. n-1
+            const double p = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(win.v)), __builtin_amdgcn_readfirstlane(__double2loint(win.v)));
             if (fabs(p) <= eps) break;
             PROF_INC(1, 1);
             JP_T(j1);
@@ -675,13 +692,11 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
             asm volatile("" :: "v"(c), "v"(sn), "v"(tt));
 #endif
             JP_T(j2);
-            wave_sync();  // all pivot inputs read before anything is rewritten
             if (t == k) Wt -= tt;
             if (t == l) Wt += tt;
             {
-                // lane t rotates the pair of A that involves row / column t and the pair of V in column t: one address computation
-                // for all cases of the serial loops (t < k: (A[t][k], A[t][l]); k < t < l: (A[k][t], A[t][l]); l < t: (A[k][t], A[l][t])),
-                // one batch of loads, one of stores
+                // lane t rotates the pair of A that involves row / column t and the pair of V in column t (t < k: (A[t][k], A[t][l]);
+                // k < t < l: (A[k][t], A[t][l]); l < t: (A[k][t], A[l][t])); the previous step's writes were fenced at its end
                 const bool va = t < n, aa = va && t != k && t != l;
                 const int tc = va ? t : 0;
                 double* X = A + (tc < k ? n * tc + k : n * k + tc);
@@ -693,32 +708,44 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
                 if (aa) { *X = xa; *Y = ya; }
                 if (va) { *VX = xv; *VY = yv; }
                 if (t == 0) A[n * k + l] = 0;
+                // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
+                if (aa) {
+                    if (t < k) { if (ir == k) rv = xa; if (ir == l) rv = ya; }
+                    else if (t < l) { if (ic == k) cv = xa; if (ir == l) rv = ya; }
+                    else { if (ic == k) cv = xa; if (ic == l) cv = ya; }
+                }
             }
             wave_sync();
             JP_T(j3);
-            if (t < 4) {
-                // indR[k], indC[k], indR[l], indC[l] by four lanes, one code path: lane j scans the row (even j) or the column
-                // (odd j) of idx = k (j < 2) or l; fixed-count loop with a predicate, values loaded up front
-                const int idx = t < 2 ? k : l;
-                const bool row = (t & 1) == 0;
-                const bool need = row ? idx < n - 1 : idx > 0;
-                double vals[n - 1];
+            {
+                // indR[k], indC[k], indR[l], indC[l]: DPP row g = t >> 4 scans the row (g even) or the column (g odd) of idx = k (g < 2)
+                // or l, lane q = t & 15 holds element q of it; first maximum = arg-max with the smaller q winning ties
+                const int g = t >> 4, q = t & 15;
+                const int idx = g < 2 ? k : l;
+                const bool row = (g & 1) == 0;
+                const bool valid = row ? (q > idx && q < n) : q < idx;
+                const int qc = valid ? q : (row ? min(idx + 1, n - 1) : 0);
+                JCand sc;
+                sc.v = valid ? A[row ? n * idx + qc : n * qc + idx] : 0.;
+                sc.ord = valid ? q : JC_NONE; sc.a = q; sc.b = 0;
+                sc = jc_row_argmax(sc);
+                // row results to lanes k and l (every lane of a DPP row holds its row's winner)
+                int ra[4];
+                double rvv[4];
 #pragma unroll
-                for (i = 0; i < n - 1; i++) {
-                    // step i visits column idx + 1 + i of the row (while < n) / row i of the column (while < idx)
-                    const int q = row ? min(idx + 1 + i, n - 1) : min(i, max(idx - 1, 0));
-                    vals[i] = fabs(A[row ? n * idx + q : n * q + idx]);
+                for (int gg = 0; gg < 4; gg++) {
+                    ra[gg] = __builtin_amdgcn_readlane(sc.a, 16 * gg);
+                    rvv[gg] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sc.v), 16 * gg), __builtin_amdgcn_readlane(__double2loint(sc.v), 16 * gg));
                 }
-                m = row ? idx + 1 : 0; mv = -1.;
-#pragma unroll
-                for (i = 0; i < n - 1; i++) {
-                    const int q = row ? idx + 1 + i : i;
-                    const bool valid = row ? q < n : q < idx;
-                    if (valid && mv < vals[i]) mv = vals[i], m = q;
+                if (t == k) {
+                    if (k < n - 1) { ir = ra[0]; rv = rvv[0]; }
+                    if (k > 0) { ic = ra[1]; cv = rvv[1]; }
                 }
-                if (need) { if (row) S.indR[idx] = m; else S.indC[idx] = m; }
+                if (t == l) {
+                    if (l < n - 1) { ir = ra[2]; rv = rvv[2]; }
+                    if (l > 0) { ic = ra[3]; cv = rvv[3]; }
+                }
             }
-            wave_sync();
             JP_T(j4);
             JP_ADD(0, j0, j1); JP_ADD(1, j1, j2); JP_ADD(2, j2, j3); JP_ADD(3, j3, j4);
         }
