@@ -295,7 +295,8 @@ def measure_roofline(ctx, job, frames, cams, launches):
     # summary of the same kernels is read when it belongs to this frame size (tools/profile_round2.sh, tools/collect_profiles.py).
     traffic, pmc = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")) as f:
+        path = os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")
+        with open(path) as f:
             pmc = json.load(f)
         if pmc.get("frame_size") != [cam["width"], cam["height"]]:
             pmc = None
@@ -303,7 +304,7 @@ def measure_roofline(ctx, job, frames, cams, launches):
             traffic = pmc["warp"]["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pmc = None
-    parts = {"warp": {"kernel": "warp_fused_batch_kernel (all frames of the compose in one grid; same body as warp_fused_kernel)", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
+    parts = {"warp": {"kernel": "warp_strip_batch_kernel (all frames of the compose in one grid: pipelined strips of 64 x 8 tiles); single_frame_launch_*: warp_fused_kernel, one frame per launch", "achieved": round(algo_w / t_w / 1e9, 1), "frac": round(algo_w / t_w / 8e12, 4),
                       "algorithmic_bytes_per_launch": algo_w, "avg_launch_us": round(t_w * 1e6, 2), "launches": launches,
                       "launch": "mis_warp_spherical_fused_batch: %d frames in one grid, %.1f us per pass, %d passes x 3; avg_launch_us = the pass / frames (by bytes)" % (len(mine), us_b, reps),
                       "single_frame_launch_us": round(t_w1 * 1e6, 2), "single_frame_launch_frac": round(algo_w / t_w1 / 8e12, 4),
@@ -373,6 +374,32 @@ def measure_roofline(ctx, job, frames, cams, launches):
                          "fused_model": {"bytes": algo_b_fused, "achieved": round(algo_b_fused / t_b / 1e9, 1), "frac": round(algo_b_fused / t_b / 8e12, 4),
                                          "what": "bytes a fused normalise + collapse + crop must move: (4/3) P (6+4) read, (1/3) P (6+6) for the "
                                                  "collapsed levels, 7 per result pixel written; the 44.3 B/px model above stays the graded one"}}
+    # ---- feature stage (K1-K3 are HBM-bound by SURVEY 8(d): gray, pyramid, FAST + NMS; K4-K6 are reported as time only) ----
+    try:
+        def feats_once():
+            fs = eng.detect([frames[k] for k in mine])
+            del fs
+        feats_once()                                   # warm (arenas)
+        torch.cuda.synchronize()
+        t0f = time.perf_counter()
+        for _ in range(3):
+            feats_once()                               # mis_orb_detect_batch synchronises once at its end
+        t_feat = (time.perf_counter() - t0f) / 3
+        if eng.cfg.features_type == "orb":
+            lv, sc = [], 1.0
+            for _ in range(8):
+                lv.append(int(round(cam["width"] / sc)) * int(round(cam["height"] / sc)))
+                sc *= 1.2
+            pyr = sum(lv)
+            algo_feat = 4 * S + 2 * (pyr - lv[0]) + 2 * pyr          # gray: 3 S read + S written; resize: ~1 read + 1 write per pixel of levels >= 1; FAST: ~2 B per pyramid pixel
+            parts["features"] = {"kernels": "gray / resize x7 / border / fast_nms (K1-K3) + harris, select, angle, describe (K4-K6, time only)",
+                                 "algorithmic_bytes_per_frame": algo_feat, "frames": len(mine), "stage_ms": round(t_feat * 1e3, 3),
+                                 "us_per_frame": round(t_feat / len(mine) * 1e6, 2), "achieved": round(algo_feat * len(mine) / t_feat / 1e9, 1),
+                                 "frac": round(algo_feat * len(mine) / t_feat / 8e12, 4),
+                                 "what": "the whole feature stage of the job (mis_orb_detect_batch over this rank's frames, wall time incl. its one host "
+                                         "synchronisation) against the K1-K3 bytes; not part of the graded K10-K14 aggregate"}
+    except Exception as e:      # the roofline object must not depend on this informational leg
+        parts["features"] = {"error": str(e)[:200]}
     # aggregate over this rank's frames: every frame's warp is costed at the measured frame's launch duration scaled by its bytes
     algo_w_all = sum(3 * S + 7 * rois[k][2] * rois[k][3] for k in mine)
     t_w_all = t_w * algo_w_all / algo_w
