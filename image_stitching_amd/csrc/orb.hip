@@ -62,11 +62,30 @@ struct Work {  // device pointers of one MisOrb workspace
     int8_t* pattern;  // 512 x 2
 };
 
+// Frames of a batch run through every stage TOGETHER (round 3): their workspaces are identical blocks `ws` bytes apart, so frame
+// f's pointer is the first frame's + f * ws, and a stage is one launch with the frame as an extra grid dimension (18 launches per
+// 16 frames instead of 18 per frame on three streams: the feature stage was bound by the device's throughput on small launches).
+constexpr int ORB_BATCH = 16;
+struct OrbIO {      // per-frame inputs / outputs of a batch group (not at a regular stride)
+    const uint8_t* src[ORB_BATCH];
+    size_t sstride[ORB_BATCH];
+    int aligned[ORB_BATCH];
+    MisKeyPoint* kps[ORB_BATCH];
+    uint32_t* lxy[ORB_BATCH];
+    int* n_dev[ORB_BATCH];
+    uint8_t* desc[ORB_BATCH];
+};
+#define WS_OFF(p, f, ws) p = (decltype(p))((const char*)(p) + (size_t)(f) * (ws))
+
 // ---------------------------------------------------------------- K1 gray --------------------
 // cvtColor BGR2GRAY, 15-bit coefficients (RGB2Gray<uchar> of OpenCV 4.x: BY15 3735, GY15 19235, RY15 9798, gray_shift 15): (B*3735 + G*19235 + R*9798 + 16384) >> 15, written into the padded level 0
-__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* bgr, size_t stride, int w, int h, uint8_t* dst, int pp, int aligned) {
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+__global__ __launch_bounds__(256) void gray_kernel(OrbIO io, int w, int h, uint8_t* dst, int pp, size_t ws) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
     if (x >= w) return;
+    const uint8_t* bgr = io.src[f];
+    const size_t stride = io.sstride[f];
+    const int aligned = io.aligned[f];
+    WS_OFF(dst, f, ws);
     const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
     uint8_t* o = dst + (size_t)(y + ORB_BORDER) * pp + ORB_BORDER + x;
     if (aligned && x + 4 <= w) {
@@ -95,9 +114,10 @@ __device__ __forceinline__ unsigned byte_at(unsigned w0, unsigned w1, unsigned w
     return (o < 8 ? (unsigned)(lo >> (8 * o)) : (w2 >> (8 * (o - 8)))) & 255u;
 }
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spp, uint8_t* __restrict__ dst, int dw, int dh, int dpp,
-                                                     const int* __restrict__ tab) {
+                                                     const int* __restrict__ tab, size_t ws) {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= dw) return;
+    WS_OFF(src, blockIdx.z, ws); WS_OFF(dst, blockIdx.z, ws);
     const int dw4 = (dw + 3) & ~3;
     const int *xo = tab, *xm = tab + dw4, *yo = tab + 2 * dw4, *ym = tab + 2 * dw4 + dh;
     const int4 o4 = *reinterpret_cast<const int4*>(xo + x), m4 = *reinterpret_cast<const int4*>(xm + x);   // entries past dw are zero
@@ -141,8 +161,10 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
 // SIDES = false walks the top / bottom strips (2B rows, full padded width), SIDES = true the left /
 // right strips (2B columns of the interior rows).
 template <bool SIDES>
-__global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad) {
-    const LevelDesc& d = L.d[blockIdx.z];
+__global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad, size_t ws) {
+    const int f = blockIdx.z / L.n;
+    const LevelDesc& d = L.d[blockIdx.z - f * L.n];
+    WS_OFF(pad, f, ws);
     const int B = ORB_BORDER, pw = d.w + 2 * B, ph = d.h + 2 * B;
     int px, py;
     if (!SIDES) {
@@ -212,7 +234,7 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) { 
 // (+1 halo) are computed from LDS, and the survivors go to a per-level list (x | y << 16, score) and a
 // per-level histogram: the score map never exists in HBM.
 constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80, HIST_COPIES = 8;
-__global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc) {
+__global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc, size_t ws) {
     __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 8) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75
     __shared__ uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
     __shared__ int lh[256];
@@ -221,9 +243,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
     __shared__ uint8_t lsc[512];
     __shared__ unsigned short queue[(FT_ROWS + 2) * (FT_COLS + 2)];  // pixels that pass the cheap pre-test
     __shared__ int qcount;
-    const LevelDesc& d = L.d[blockIdx.z];
+    const int fz = blockIdx.z / L.n, lz = blockIdx.z - fz * L.n;     // frame, level
+    const LevelDesc& d = L.d[lz];
     const int x0 = blockIdx.x * FT_COLS, y0 = blockIdx.y * FT_ROWS, t = threadIdx.x;
     if (x0 >= d.w || y0 >= d.h) return;
+    WS_OFF(pad, fz, ws); WS_OFF(hist, fz, ws); WS_OFF(tile_cnt, fz, ws); WS_OFF(surv_xy, fz, ws); WS_OFF(surv_sc, fz, ws);
     lh[t] = 0;
     if (t == 0) { lcount = 0; qcount = 0; }
     {
@@ -297,15 +321,16 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
     __syncthreads();
     // HIST_COPIES copies of a level's histogram, picked by the tile: the popular bins would otherwise take one atomic from
     // nearly every tile on a single address (same-address atomics serialise); fast_cut_kernel adds the copies up
-    if (lh[t]) atomicAdd(&hist[((blockIdx.z * HIST_COPIES) + ((blockIdx.x + blockIdx.y) & (HIST_COPIES - 1))) * 256 + t], lh[t]);
+    if (lh[t]) atomicAdd(&hist[((lz * HIST_COPIES) + ((blockIdx.x + blockIdx.y) & (HIST_COPIES - 1))) * 256 + t], lh[t]);
 }
 
 // retainBest(2 N_l) on the integer FAST score: cut = the n2-th best score (1 = keep everything), found
 // from the level histogram by every block, then the survivor list is filtered against it
-__global__ __launch_bounds__(256) void fast_cut_kernel(Levels L, const int* hist, int* thr, int* flags) {
+__global__ __launch_bounds__(256) void fast_cut_kernel(Levels L, const int* hist, int* thr, int* flags, size_t ws) {
     __shared__ int suf[256];
     __shared__ int s_thr;
     const int l = blockIdx.x, t = threadIdx.x;
+    WS_OFF(hist, blockIdx.y, ws); WS_OFF(thr, blockIdx.y, ws); WS_OFF(flags, blockIdx.y, ws);
     const LevelDesc& d = L.d[l];
     // suffix sums of the histogram: suf[v] = number of survivors with score >= v
     int hsum = 0;
@@ -336,10 +361,12 @@ __global__ __launch_bounds__(256) void fast_cut_kernel(Levels L, const int* hist
 // list is arbitrary either way; the ranking kernel imposes the canonical one.
 constexpr int CT_TILES = 16;
 __global__ __launch_bounds__(256) void compact_kernel(Levels L, const int* tile_cnt, const uint32_t* surv_xy, const uint8_t* surv_sc, const int* thr,
-                                                      int* cnt1, uint32_t* cand_xy, float* cand_resp) {
+                                                      int* cnt1, uint32_t* cand_xy, float* cand_resp, size_t ws) {
     __shared__ int s_cnt[CT_TILES], s_off[CT_TILES];
     __shared__ int s_base;
     const int l = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    WS_OFF(tile_cnt, blockIdx.z, ws); WS_OFF(surv_xy, blockIdx.z, ws); WS_OFF(surv_sc, blockIdx.z, ws); WS_OFF(thr, blockIdx.z, ws);
+    WS_OFF(cnt1, blockIdx.z, ws); WS_OFF(cand_xy, blockIdx.z, ws); WS_OFF(cand_resp, blockIdx.z, ws);
     const LevelDesc& d = L.d[l];
     const int ntiles = d.tiles_x * d.tiles_y, first = blockIdx.x * CT_TILES;
     if (first >= ntiles) return;
@@ -397,8 +424,9 @@ __global__ void nms_raster_kernel(LevelDesc d, const int* tile_cnt, const uint32
 
 // ---------------------------------------------------------------- K4 Harris ------------------
 // HarrisResponses(blockSize 7, k 0.04) at the candidate (integer gradients, f32 response)
-__global__ __launch_bounds__(256) void harris_kernel(Levels L, const uint8_t* pad, const int* cnt1, const uint32_t* cand_xy, float* cand_resp) {
+__global__ __launch_bounds__(256) void harris_kernel(Levels L, const uint8_t* pad, const int* cnt1, const uint32_t* cand_xy, float* cand_resp, size_t ws) {
     const LevelDesc& d = L.d[blockIdx.y];
+    WS_OFF(pad, blockIdx.z, ws); WS_OFF(cnt1, blockIdx.z, ws); WS_OFF(cand_xy, blockIdx.z, ws); WS_OFF(cand_resp, blockIdx.z, ws);
     int i = blockIdx.x * 256 + threadIdx.x;
     int n = min(cnt1[blockIdx.y], d.cap1);
     if (i >= n) return;
@@ -432,7 +460,9 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 // retainBest(N_l) on the Harris response (ties at the cut kept) + canonical order
 // (response desc, y, x) by counting ranks.  One 1024-thread block per level.
 __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* cnt1, const uint32_t* cand_xy, const float* cand_resp,
-                                                            int* cnt2, uint32_t* fin_xy, float* fin_resp, int* flags, int use_harris) {
+                                                            int* cnt2, uint32_t* fin_xy, float* fin_resp, int* flags, int use_harris, size_t ws) {
+    WS_OFF(cnt1, blockIdx.y, ws); WS_OFF(cand_xy, blockIdx.y, ws); WS_OFF(cand_resp, blockIdx.y, ws); WS_OFF(cnt2, blockIdx.y, ws);
+    WS_OFF(fin_xy, blockIdx.y, ws); WS_OFF(fin_resp, blockIdx.y, ws); WS_OFF(flags, blockIdx.y, ws);
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k, s_m;
@@ -543,9 +573,12 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* 
 // One wave per keypoint: concatenates the per-level segments, evaluates the intensity centroid on
 // the un-blurred level (ICAngles), writes the cv::KeyPoint (pt scaled to level-0 coordinates).
 __global__ __launch_bounds__(256) void assemble_angle_kernel(Levels L, const uint8_t* pad, const int* cnt2, const uint32_t* fin_xy,
-                                                             const float* fin_resp, const int* umax, MisKeyPoint* kps, uint32_t* kp_lxy,
-                                                             int* n_out, int cap_out) {
-    const int l = blockIdx.y;
+                                                             const float* fin_resp, const int* umax, OrbIO io, int cap_out, size_t ws) {
+    const int l = blockIdx.y, fr = blockIdx.z;
+    WS_OFF(pad, fr, ws); WS_OFF(cnt2, fr, ws); WS_OFF(fin_xy, fr, ws); WS_OFF(fin_resp, fr, ws);
+    MisKeyPoint* kps = io.kps[fr];
+    uint32_t* kp_lxy = io.lxy[fr];
+    int* n_out = io.n_dev[fr];
     const LevelDesc& d = L.d[l];
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int base = 0;
@@ -684,11 +717,15 @@ __global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* 
 // inside the level are blurred (their taps may reach into the reflected border ring), samples in the ring are not: the reference
 // blurs the level's ROI of the bordered pyramid only.
 constexpr int DD_R = 28, DD_P = DD_R + 3, DD_N = 2 * DD_P + 1, DD_ROW_DW = (DD_N + 3 + 3) / 4, DD_PITCH = 4 * DD_ROW_DW + 4;
-__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, const MisKeyPoint* kps, const uint32_t* kp_lxy,
-                                                              const int* n_ptr, const int8_t* pattern, uint8_t* desc) {
+__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, OrbIO io, const int8_t* pattern, size_t ws) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4][DD_N * DD_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x * 4 + wave, fr = blockIdx.y;
+    WS_OFF(pad, fr, ws);
+    const MisKeyPoint* kps = io.kps[fr];
+    const uint32_t* kp_lxy = io.lxy[fr];
+    const int* n_ptr = io.n_dev[fr];
+    uint8_t* desc = io.desc[fr];
     if (i >= *n_ptr) return;   // wave-uniform: no workgroup barrier below
     const MisKeyPoint kp = kps[i];
     const LevelDesc& d = L.d[kp.octave];
@@ -762,19 +799,16 @@ struct MisOrb {
     int max_w = 0, max_h = 0;
     int cur_w = 0, cur_h = 0;
     Levels L;
-    Work w;
+    Work w;             // pointers of the first frame's workspace; frame f of a batch group: + f * ws_stride bytes
+    size_t ws_stride = 0;
+    int ws_frames = 0;  // workspaces allocated (1 until the first batch of more than one frame)
+    int umax_host[64] = {0};
+    int8_t pattern_host[1024] = {0};
     void* mem = nullptr;
     size_t pad_bytes = 0, map_bytes = 0;
     int cand_total = 0, fin_total = 0, tab_total = 0, surv_total = 0, out_cap = 0;
     std::vector<int> tab_host;
     int* host_counts = nullptr;   // pinned, device-visible: gather_ints_kernel writes the batch's counts / flags here
-    // Batches spread their frames over helper finders, each with its own workspace and its own non-blocking stream:
-    // the per-frame chain has ~60 launches, most of them small and latency bound, and chains of different frames
-    // overlap on the device.  Created on the first batch of more than one frame.
-    std::vector<MisOrb*> helpers;
-    std::vector<hipEvent_t> helper_done;
-    hipEvent_t fork_event = nullptr;
-    bool is_helper = false;
     bool direct_describe = false;   // the pattern's reach fits describe_direct_kernel's patch: no blurred pyramid
 };
 
@@ -872,45 +906,55 @@ inline int* feat_count(const MisFeatures* f, int cap) {
     return (int*)((uint8_t*)f->owner_ + kb + db + lb);
 }
 
-// enqueue the whole detect + describe path of one frame; no host synchronisation
-int enqueue_detect(MisOrb* o, const DevImage& img, int w, int h, MisFeatures* out) {
+// enqueue the whole detect + describe path of a group of ng <= ORB_BATCH frames (one launch per stage); no host synchronisation
+int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatures* out, int ng) {
     MisContext* ctx = o->ctx;
     const Levels& L = o->L;
     const Work& W = o->w;
     hipStream_t st = ctx->stream;
     const LevelDesc& d0 = L.d[0];
-    MIS_HIP(ctx, hipMemsetAsync(W.hist, 0, sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), st));  // hist, thr, cnt0, cnt1, cnt2
-    const int aligned = (img.stride % 4 == 0) && ((uintptr_t)img.data % 4 == 0);
-    hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h), dim3(256), 0, st, (const uint8_t*)img.data, img.stride, w, h, W.pad + d0.pad_off, d0.pp, aligned);
+    const size_t ws = o->ws_stride;
+    const unsigned nf = (unsigned)ng;
+    OrbIO io;
+    for (int k = 0; k < ORB_BATCH; k++) {
+        const int q = k < ng ? k : 0;
+        io.src[k] = (const uint8_t*)img[q].data; io.sstride[k] = img[q].stride;
+        io.aligned[k] = (img[q].stride % 4 == 0) && ((uintptr_t)img[q].data % 4 == 0);
+        io.kps[k] = out[q].keypoints; io.lxy[k] = feat_lxy(&out[q], o->out_cap); io.n_dev[k] = feat_count(&out[q], o->out_cap);
+        io.desc[k] = (uint8_t*)out[q].descriptors;
+    }
+    // hist, thr, cnt0, cnt1, cnt2 of every frame of the group (same offset in each workspace)
+    MIS_HIP(ctx, hipMemset2DAsync(W.hist, ws ? ws : sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), 0,
+                                  sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), nf, st));
+    hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h, nf), dim3(256), 0, st, io, w, h, W.pad + d0.pad_off, d0.pp, ws);
     for (int l = 1; l < L.n; l++) {
         const LevelDesc &s = L.d[l - 1], &d = L.d[l];
-        hipLaunchKernelGGL(resize_kernel, dim3((d.w + 1023) / 1024, d.h), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
-                           d.h, d.pp, W.tab + d.tab_off);
+        hipLaunchKernelGGL(resize_kernel, dim3((d.w + 1023) / 1024, d.h, nf), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
+                           d.h, d.pp, W.tab + d.tab_off, ws);
     }
     const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
-    hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h + 3) / 4, 1, L.n), dim3(256), 0, st, L, W.pad);   // sides first: the corners mirror them
-    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 255) / 256, 2 * ORB_BORDER, L.n), dim3(256), 0, st, L, W.pad);
-    dim3 gmap((d0.w + FT_COLS - 1) / FT_COLS, (d0.h + FT_ROWS - 1) / FT_ROWS, L.n);
-    hipLaunchKernelGGL(fast_nms_kernel, gmap, dim3(256), 0, st, L, W.pad, W.hist, W.tile_cnt, W.surv_xy, W.surv_sc);
-    hipLaunchKernelGGL(fast_cut_kernel, dim3(L.n), dim3(256), 0, st, L, W.hist, W.thr, W.flags);
-    hipLaunchKernelGGL(compact_kernel, dim3((d0.tiles_x * d0.tiles_y + CT_TILES - 1) / CT_TILES, L.n), dim3(256), 0, st, L, W.tile_cnt, W.surv_xy, W.surv_sc, W.thr, W.cnt1,
-                       W.cand_xy, W.cand_resp);
+    hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h + 3) / 4, 1, L.n * nf), dim3(256), 0, st, L, W.pad, ws);   // sides first: the corners mirror them
+    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 255) / 256, 2 * ORB_BORDER, L.n * nf), dim3(256), 0, st, L, W.pad, ws);
+    dim3 gmap((d0.w + FT_COLS - 1) / FT_COLS, (d0.h + FT_ROWS - 1) / FT_ROWS, L.n * nf);
+    hipLaunchKernelGGL(fast_nms_kernel, gmap, dim3(256), 0, st, L, W.pad, W.hist, W.tile_cnt, W.surv_xy, W.surv_sc, ws);
+    hipLaunchKernelGGL(fast_cut_kernel, dim3(L.n, nf), dim3(256), 0, st, L, W.hist, W.thr, W.flags, ws);
+    hipLaunchKernelGGL(compact_kernel, dim3((d0.tiles_x * d0.tiles_y + CT_TILES - 1) / CT_TILES, L.n, nf), dim3(256), 0, st, L, W.tile_cnt, W.surv_xy, W.surv_sc, W.thr, W.cnt1,
+                       W.cand_xy, W.cand_resp, ws);
     const int use_harris = o->p.score_type == 0;
     if (use_harris)
-        hipLaunchKernelGGL(harris_kernel, dim3((L.d[0].cap1 + 255) / 256, L.n), dim3(256), 0, st, L, W.pad, W.cnt1, W.cand_xy, W.cand_resp);
-    hipLaunchKernelGGL(select_rank_kernel, dim3(L.n), dim3(1024), 0, st, L, W.cnt1, W.cand_xy, W.cand_resp, W.cnt2, W.fin_xy, W.fin_resp, W.flags,
-                       use_harris);
-    uint32_t* lxy = feat_lxy(out, o->out_cap);
-    int* n_dev = feat_count(out, o->out_cap);
-    hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax,
-                       out->keypoints, lxy, n_dev, o->out_cap);
+        hipLaunchKernelGGL(harris_kernel, dim3((L.d[0].cap1 + 255) / 256, L.n, nf), dim3(256), 0, st, L, W.pad, W.cnt1, W.cand_xy, W.cand_resp, ws);
+    hipLaunchKernelGGL(select_rank_kernel, dim3(L.n, nf), dim3(1024), 0, st, L, W.cnt1, W.cand_xy, W.cand_resp, W.cnt2, W.fin_xy, W.fin_resp, W.flags,
+                       use_harris, ws);
+    hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n, nf), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax, io, o->out_cap, ws);
     if (o->direct_describe) {
-        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4), dim3(256), 0, st, L, W.pad, out->keypoints, lxy, n_dev, W.pattern,
-                           (uint8_t*)out->descriptors);
+        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, io, W.pattern, ws);
     } else {
-        hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, L.n), dim3(256), 0, st, L, W.pad, W.blur);
-        hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur, out->keypoints, lxy, n_dev, W.pattern,
-                           (uint8_t*)out->descriptors);
+        // patterns that reach beyond the direct kernel's patch: the blurred pyramid, frame by frame (not the default parameters)
+        for (int k = 0; k < ng; k++) {
+            hipLaunchKernelGGL(blur_kernel, dim3((pw0 + 63) / 64, (ph0 + 31) / 32, L.n), dim3(256), 0, st, L, W.pad + k * ws, W.blur + k * ws);
+            hipLaunchKernelGGL(describe_kernel, dim3((o->out_cap + 7) / 8), dim3(256), 0, st, L, W.blur + k * ws, out[k].keypoints, io.lxy[k], io.n_dev[k], W.pattern,
+                               (uint8_t*)out[k].descriptors);
+        }
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -933,6 +977,59 @@ int replan_if_needed(MisOrb* o, int w, int h) {
     return upload_tables(o);
 }
 
+// `frames` identical workspaces in one allocation (frame f at + f * ws_stride); W holds the first frame's pointers
+int orb_alloc_workspace(MisOrb* o, int frames) {
+    MisContext* ctx = o->ctx;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
+    size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
+    size_t o_hist = carve(sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
+    size_t o_sxy = carve(sizeof(uint32_t) * 512 * (size_t)o->surv_total), o_ssc = carve(512 * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
+    size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
+    size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
+    size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
+    void* mem = nullptr;
+    if (hipMalloc(&mem, off * (size_t)frames) != hipSuccess) return mis_set_error(ctx, MIS_E_NOMEM, "hipMalloc of %zu bytes failed", off * (size_t)frames);
+    o->mem = mem; o->ws_stride = off; o->ws_frames = frames;
+    uint8_t* m = (uint8_t*)o->mem;
+    Work& W = o->w;
+    W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
+    W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * HIST_COPIES * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
+    W.surv_xy = (uint32_t*)(m + o_sxy); W.surv_sc = m + o_ssc; W.tile_cnt = (int*)(m + o_tc);
+    W.flags = (int*)(m + o_flags);
+    W.cand_xy = (uint32_t*)(m + o_cxy); W.cand_resp = (float*)(m + o_cr); W.fin_xy = (uint32_t*)(m + o_fxy); W.fin_resp = (float*)(m + o_fr);
+    W.tab = (int*)(m + o_tab); W.umax = (int*)(m + o_umax); W.pattern = (int8_t*)(m + o_pat);
+    return MIS_OK;
+}
+
+// constants of a fresh workspace block: umax, the BRIEF pattern and the resize tables (shared: the first frame's), the overflow
+// flags of every frame
+int orb_init_workspace(MisOrb* o) {
+    MisContext* ctx = o->ctx;
+    const Work& W = o->w;
+    MIS_HIP(ctx, hipMemcpyAsync(W.umax, o->umax_host, sizeof(o->umax_host), hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipMemcpyAsync(W.pattern, o->pattern_host, sizeof(o->pattern_host), hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipMemset2DAsync(W.flags, o->ws_stride, 0, 256, (size_t)o->ws_frames, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return upload_tables(o);
+}
+
+// at least `frames` (<= ORB_BATCH) workspaces: the block is re-allocated once, on the first batch that needs more
+int orb_ensure_frames(MisOrb* o, int frames) {
+    frames = std::min(frames, ORB_BATCH);
+    if (o->ws_frames >= frames) return MIS_OK;
+    MisContext* ctx = o->ctx;
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void* old = o->mem;
+    const Work oldw = o->w;
+    const size_t olds = o->ws_stride;
+    const int oldf = o->ws_frames;
+    int rc = orb_alloc_workspace(o, frames);
+    if (rc != MIS_OK) { o->mem = old; o->w = oldw; o->ws_stride = olds; o->ws_frames = oldf; return rc; }
+    if (old) MIS_HIP(ctx, hipFree(old));
+    return orb_init_workspace(o);
+}
+
 }  // namespace
 
 extern "C" void mis_orb_default_params(MisOrbParams* p) {
@@ -952,24 +1049,9 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     o->ctx = ctx; o->p = *p; o->max_w = max_w; o->max_h = max_h;
     plan_levels(o, max_w, max_h);
     o->out_cap = o->fin_total;
-    // one allocation, carved into the workspace
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
-    size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
-    size_t o_hist = carve(sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
-    size_t o_sxy = carve(sizeof(uint32_t) * 512 * (size_t)o->surv_total), o_ssc = carve(512 * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
-    size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
-    size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
-    size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
-    if (hipMalloc(&o->mem, off) != hipSuccess) { delete o; return mis_set_error(ctx, MIS_E_NOMEM, "hipMalloc of %zu bytes failed", off); }
-    uint8_t* m = (uint8_t*)o->mem;
+    int rc0 = orb_alloc_workspace(o, 1);
+    if (rc0 != MIS_OK) { delete o; return rc0; }
     Work& W = o->w;
-    W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
-    W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * HIST_COPIES * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
-    W.surv_xy = (uint32_t*)(m + o_sxy); W.surv_sc = m + o_ssc; W.tile_cnt = (int*)(m + o_tc);
-    W.flags = (int*)(m + o_flags);
-    W.cand_xy = (uint32_t*)(m + o_cxy); W.cand_resp = (float*)(m + o_cr); W.fin_xy = (uint32_t*)(m + o_fxy); W.fin_resp = (float*)(m + o_fr);
-    W.tab = (int*)(m + o_tab); W.umax = (int*)(m + o_umax); W.pattern = (int8_t*)(m + o_pat);
     // umax (orb.cpp) and the random BRIEF pattern: patchSize != 31 -> RNG(0x34985739), 512 points
     int umax[64] = {0};
     {
@@ -998,12 +1080,11 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
         // FAST keypoints keep 3 pixels from the edge, the level carries a border ring of ORB_BORDER: the patch stays inside the padded level
         o->direct_describe = reach <= DD_R && 3 + ORB_BORDER >= DD_P && getenv("MIS_ORB_FULL_BLUR") == nullptr;
     }
-    hipMemcpyAsync(W.umax, umax, sizeof(umax), hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(W.pattern, pat, sizeof(pat), hipMemcpyHostToDevice, ctx->stream);
-    hipMemsetAsync(W.flags, 0, 256, ctx->stream);
-    hipStreamSynchronize(ctx->stream);
+    (void)W;
+    memcpy(o->umax_host, umax, sizeof(umax));
+    memcpy(o->pattern_host, pat, sizeof(pat));
     o->cur_w = max_w; o->cur_h = max_h;
-    int rc = upload_tables(o);
+    int rc = orb_init_workspace(o);
     if (rc != MIS_OK) { hipFree(o->mem); delete o; return rc; }
     *out = o;
     return MIS_OK;
@@ -1013,51 +1094,12 @@ extern "C" int mis_orb_destroy(MisOrb* o) {
     if (!o) return MIS_OK;
     hipSetDevice(o->ctx->device);
     hipStreamSynchronize(o->ctx->stream);
-    for (MisOrb* hlp : o->helpers) {
-        MisContext* hc = hlp->ctx;
-        mis_orb_destroy(hlp);
-        delete hc;      // (its stream is the parent context's auxiliary stream)
-    }
-    for (hipEvent_t e : o->helper_done) hipEventDestroy(e);
-    if (o->fork_event) hipEventDestroy(o->fork_event);
     if (o->mem) hipFree(o->mem);
     if (o->host_counts) hipHostFree(o->host_counts);
     delete o;
     return MIS_OK;
 }
 
-namespace {
-// helper finders next to the finder itself: 3 frames in flight.  The feature stage is bound by device throughput, not by
-// latency, and streams beyond the runtime's hardware queues (4 by default) share them: with 3 helpers the 16 x 4K stage
-// took 3.9 ms, with 2 it takes 3.3 ms (and the job's compose / matcher streams keep a queue each); 4 or 5 helpers cost
-// the whole step 3-4 ms through queue sharing
-#ifndef ORB_HELPERS_N
-#define ORB_HELPERS_N 2
-#endif
-constexpr int ORB_HELPERS = ORB_HELPERS_N;
-
-int ensure_helpers(MisOrb* o) {
-    if (!o->helpers.empty() || o->is_helper) return MIS_OK;
-    MisContext* ctx = o->ctx;
-    MIS_HIP(ctx, hipEventCreateWithFlags(&o->fork_event, hipEventDisableTiming));
-    for (int k = 0; k < ORB_HELPERS; k++) {
-        MisContext* hc = new MisContext();
-        hc->device = ctx->device; hc->num_cu = ctx->num_cu;
-        // a helper lane runs on one of the context's auxiliary streams (shared with the matcher's side chains, which run later)
-        int rc = mis_aux_stream(ctx, k % 2, &hc->stream);
-        if (rc != MIS_OK) { delete hc; return rc; }
-        MisOrb* hlp = nullptr;
-        rc = mis_orb_create(hc, &o->p, o->max_w, o->max_h, &hlp);
-        if (rc != MIS_OK) { mis_set_error(ctx, rc, "helper finder: %s", hc->err.c_str()); delete hc; return rc; }
-        hlp->is_helper = true;
-        hipEvent_t e;
-        MIS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        o->helpers.push_back(hlp);
-        o->helper_done.push_back(e);
-    }
-    return MIS_OK;
-}
-}  // namespace
 
 extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisFeatures* out) {
     if (!o) return MIS_E_INVALID;
@@ -1070,23 +1112,11 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
         MIS_CHECK(ctx, imgs[i].width == imgs[0].width && imgs[i].height == imgs[0].height, MIS_E_INVALID, "batch frames must share one size");
     }
     if ((rc = replan_if_needed(o, imgs[0].width, imgs[0].height)) != MIS_OK) return rc;
-    std::vector<MisOrb*> lanes{o};
-    if (n > 1) {
-        if ((rc = ensure_helpers(o)) != MIS_OK) return rc;
-        for (MisOrb* hlp : o->helpers) {
-            if ((rc = replan_if_needed(hlp, imgs[0].width, imgs[0].height)) != MIS_OK) return mis_set_error(ctx, rc, "helper finder: %s", hlp->ctx->err.c_str());
-            lanes.push_back(hlp);
-        }
-        // fork: the helper streams start after everything already queued on the context's stream (the frames' producers)
-        MIS_HIP(ctx, hipEventRecord(o->fork_event, ctx->stream));
-        for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
-    }
+    if ((rc = orb_ensure_frames(o, n)) != MIS_OK) return rc;
     std::vector<DevImage> dimg(n);
     for (int i = 0; i < n; i++) memset(&out[i], 0, sizeof(MisFeatures));
-    // an error after the fork must not leave the helper streams (the context's auxiliary streams) with work pending, nor leak the
-    // outputs / staged inputs of the frames already set up
+    // an error must not leak the outputs / staged inputs of the frames already set up
     auto fail = [&](int code) {
-        for (MisOrb* hlp : o->helpers) hipStreamSynchronize(hlp->ctx->stream);
         hipStreamSynchronize(ctx->stream);
         for (int i = 0; i < n; i++) {
             if (out[i].keypoints || out[i].descriptors) mis_features_free(ctx, &out[i]);
@@ -1099,45 +1129,33 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
         if ((rc = alloc_features(ctx, o->out_cap, 32, MIS_U8, &out[i])) != MIS_OK) return fail(rc);
         if ((rc = mis_dev_image_in(ctx, &imgs[i], &dimg[i])) != MIS_OK) return fail(rc);
     }
-    if (n > 1) {   // staged host inputs were copied on the context's stream after the fork event: fork again behind them
-        bool staged = false;
-        for (int i = 0; i < n; i++) staged |= dimg[i].owned;
-        if (staged) {
-            MIS_HIP(ctx, hipEventRecord(o->fork_event, ctx->stream));
-            for (MisOrb* hlp : o->helpers) MIS_HIP(ctx, hipStreamWaitEvent(hlp->ctx->stream, o->fork_event, 0));
-        }
-    }
     const bool trace = getenv("MIS_ORB_TRACE") != nullptr;
     const auto t_enq0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < n; i++) {
-        MisOrb* lane = lanes[i % lanes.size()];
-        if ((rc = enqueue_detect(lane, dimg[i], imgs[i].width, imgs[i].height, &out[i])) != MIS_OK)
-            return fail(lane == o ? rc : mis_set_error(ctx, rc, "helper finder: %s", lane->ctx->err.c_str()));
+    // groups of up to ORB_BATCH frames, each stage of a group in one launch; groups follow each other on the stream (they share the workspaces)
+    for (int g0 = 0; g0 < n; g0 += o->ws_frames) {
+        const int ng = std::min(o->ws_frames, n - g0);
+        if ((rc = enqueue_detect_group(o, &dimg[g0], imgs[0].width, imgs[0].height, &out[g0], ng)) != MIS_OK) return fail(rc);
     }
     if (trace) fprintf(stderr, "orb batch: %d frames enqueued in %.0f us\n", n, (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_enq0).count());
-    // join: the context's stream continues after every helper chain
-    for (size_t k = 0; k + 1 < lanes.size(); k++) {
-        MIS_HIP(ctx, hipEventRecord(o->helper_done[k], lanes[k + 1]->ctx->stream));
-        MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, o->helper_done[k], 0));
-    }
-    // one synchronisation for the whole batch: counts + overflow flags
+    // one synchronisation for the whole batch: counts + the workspaces' overflow flags
     std::vector<int> counts(n);
-    std::vector<int> lane_flags(lanes.size(), 0);
-    const int nl = (int)lanes.size();
+    const int nl = o->ws_frames;
+    std::vector<int> ws_flags(nl, 0);
     if (!o->host_counts) MIS_HIP(ctx, hipHostMalloc((void**)&o->host_counts, sizeof(int) * ORB_GATHER_MAX, hipHostMallocMapped));
     for (int i0 = 0; i0 < n + nl; i0 += ORB_GATHER_MAX) {
         const int m = std::min(ORB_GATHER_MAX, n + nl - i0);
         GatherPtrs gp;
-        for (int k = 0; k < m; k++) gp.p[k] = i0 + k < n ? feat_count(&out[i0 + k], o->out_cap) : lanes[i0 + k - n]->w.flags;
+        for (int k = 0; k < m; k++)
+            gp.p[k] = i0 + k < n ? feat_count(&out[i0 + k], o->out_cap) : (const int*)((const char*)o->w.flags + (size_t)(i0 + k - n) * o->ws_stride);
         int* dev_view = nullptr;
         MIS_HIP(ctx, hipHostGetDevicePointer((void**)&dev_view, o->host_counts, 0));
         hipLaunchKernelGGL(gather_ints_kernel, dim3(1), dim3(ORB_GATHER_MAX), 0, ctx->stream, gp, m, dev_view);
         MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < m; k++) (i0 + k < n ? counts[i0 + k] : lane_flags[i0 + k - n]) = o->host_counts[k];
+        for (int k = 0; k < m; k++) (i0 + k < n ? counts[i0 + k] : ws_flags[i0 + k - n]) = o->host_counts[k];
     }
     int flags = 0;
-    for (size_t k = 0; k < lanes.size(); k++)
-        if (lane_flags[k]) { flags |= lane_flags[k]; hipMemsetAsync(lanes[k]->w.flags, 0, sizeof(int), ctx->stream); }
+    for (int k = 0; k < nl; k++) flags |= ws_flags[k];
+    if (flags) hipMemset2DAsync(o->w.flags, o->ws_stride, 0, sizeof(int), (size_t)nl, ctx->stream);
     for (int i = 0; i < n; i++) { out[i].n = counts[i]; mis_dev_image_release(ctx, &dimg[i]); }
     if (flags) {
         return mis_set_error(ctx, MIS_E_OVERFLOW, "ORB candidate buffers overflowed (flags %d): too many tied scores", flags);

@@ -736,11 +736,14 @@ __global__ __launch_bounds__(256) void warp_trig_batch_kernel(WarpBatch b) {
 #ifndef WV3_GG
 #define WV3_GG 4
 #endif
+#ifndef WV3_MG
+#define WV3_MG 8
+#endif
 #ifndef WV3_PITCH_ALIGN
 #define WV3_PITCH_ALIGN 128
 #endif
 constexpr int V3_TW = 64, V3_TH = WV3_TH;
-constexpr int V3_RING = WV3_RING, V3_WAVES = WV3_WAVES, V3_GG = WV3_GG, V3_PITCH_ALIGN = WV3_PITCH_ALIGN;
+constexpr int V3_RING = WV3_RING, V3_WAVES = WV3_WAVES, V3_GG = WV3_GG, V3_MG = WV3_MG, V3_PITCH_ALIGN = WV3_PITCH_ALIGN;
 constexpr int V3_OUT_IMG = V3_TW * 8 * 6, V3_OUT_BYTES = V3_OUT_IMG + V3_TW * 8;   // 8 rows of the 16SC3 tile + of the mask tile
 static_assert(V3_TH % 8 == 0 && V3_TH <= 16, "tiles are whole groups of 8 rows");
 static_assert(V3_OUT_BYTES <= V3_RING / 2 && V3_RING <= 65536, "two output groups must fit the ring; LDS addresses are 16 bits");
@@ -911,6 +914,7 @@ __device__ __forceinline__ void v3_map(const V3Frame& f, cf4p rowtab, float su, 
         // so bits 0..4 are q's fraction bits, bits 5..21 its integer part, and integer min / max order biased values like q.
         xq[i] = (int)__float_as_uint(__builtin_fmaf(qx, 32.f, 12582912.f));
         yq[i] = (int)__float_as_uint(__builtin_fmaf(qy, 32.f, 12582912.f));
+        if (V3_MG < V3_TH && i % V3_MG == V3_MG - 1) __builtin_amdgcn_sched_barrier(0);     // bounds the pixels whose chains are in flight (registers)
     }
     int xmin = xq[0], xmax = xq[0], ymin = yq[0], ymax = yq[0];
 #pragma unroll
@@ -1164,45 +1168,49 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
                         u4v v[3];
 #pragma unroll
                         for (int kk = 0; kk < 3; kk++) v[kk] = *(const __attribute__((address_space(3))) u4v*)(uintptr_t)(reg + loff + kk * 128);
-#pragma unroll
-                        for (int kk = 0; kk < 3; kk++) {
 #if WV_ABL == 1
-                            asm volatile("" ::"v"(v[kk]), "v"(dg + poff + kk * 128));
+                        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(dg + poff));
 #else
-                            v3_store_piece(dg + poff + kk * 128, v[kk], wide_out);
-#endif
+                        if (wide_out) {
+                            // scalar base + 32-bit lane offset + immediate: no 64-bit address pair per lane (three of them cost the
+                            // kernel its fifth wave per SIMD)
+                            asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %0, %2, %4 offset:128\n\tglobal_store_dwordx4 %0, %3, %4 offset:256"
+                                         ::"v"(poff), "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(dg) : "memory");
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < 3; kk++) v3_store_piece(dg + poff + kk * 128, v[kk], false);
                         }
+#endif
                         const u2v mv = ones ? u2v{0xffffffffu, 0xffffffffu} : *(const __attribute__((address_space(3))) u2v*)(uintptr_t)(reg + V3_OUT_IMG + lane * 8);
 #if WV_ABL == 1
                         asm volatile("" ::"v"(mv), "v"(mg + moff));
 #else
-                        if (wide_mask) *reinterpret_cast<u2v*>(mg + moff) = mv;
+                        if (wide_mask) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(moff), "v"(mv), "s"(mg) : "memory");
                         else { volatile uint16_t* q = reinterpret_cast<volatile uint16_t*>(mg + moff); q[0] = (uint16_t)mv.x; q[1] = (uint16_t)(mv.x >> 16); q[2] = (uint16_t)mv.y; q[3] = (uint16_t)(mv.y >> 16); }
 #endif
                         nst += (wide_out ? 3 : 0) + (wide_mask ? 1 : 0);     // (narrow stores: not counted -- a lower bound keeps the wait safe)
                     } else if (gy0 < f.dh) {
                         // edge groups (the roi's last columns / rows): whole pieces where they fit, single shorts / bytes for the rest
-#pragma unroll
+                        // (rolled loops straight from the LDS image: this path must not cost the pipeline registers)
+                        const int prow = lane >> 3;
+#pragma unroll 1
                         for (int kk = 0; kk < 3; kk++) {
-                            const int prow = lane >> 3, pcb = ((lane & 7) + 8 * kk) * 16;
+                            const int pcb = ((lane & 7) + 8 * kk) * 16;
                             if (gy0 + prow >= f.dh || pcb >= valid_bytes) continue;
-                            const u4v v = *(const __attribute__((address_space(3))) u4v*)(uintptr_t)(reg + loff + kk * 128);
+                            const uint32_t lsrc = reg + loff + kk * 128;
                             uint8_t* d = dg + poff + kk * 128;
-                            if (pcb + 16 <= valid_bytes) v3_store_piece(d, v, wide_out);
+                            if (pcb + 16 <= valid_bytes) v3_store_piece(d, *(const __attribute__((address_space(3))) u4v*)(uintptr_t)lsrc, wide_out);
                             else {
-                                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                                for (int s2 = 0; s2 < 8; s2++)
-                                    if (pcb + 2 * s2 < valid_bytes) reinterpret_cast<uint16_t*>(d)[s2] = (uint16_t)(w4[s2 >> 1] >> (16 * (s2 & 1)));
+#pragma unroll 1
+                                for (int s2 = 0; pcb + 2 * s2 < valid_bytes && s2 < 8; s2++)
+                                    reinterpret_cast<uint16_t*>(d)[s2] = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(lsrc + 2 * s2);
                             }
                         }
-                        const int mr = lane >> 3, mc = (lane & 7) * 8;
-                        if (gy0 + mr < f.dh && mc < valid_px) {
-                            const u2v mv = ones ? u2v{0xffffffffu, 0xffffffffu} : *(const __attribute__((address_space(3))) u2v*)(uintptr_t)(reg + V3_OUT_IMG + lane * 8);
-                            const uint32_t w2[2] = {mv.x, mv.y};
-#pragma unroll
-                            for (int b = 0; b < 8; b++)
-                                if (mc + b < valid_px) mg[moff + b] = (uint8_t)(w2[b >> 2] >> (8 * (b & 3)));
+                        const int mc = (lane & 7) * 8;
+                        if (gy0 + prow < f.dh && mc < valid_px) {
+#pragma unroll 1
+                            for (int b = 0; b < 8 && mc + b < valid_px; b++)
+                                mg[moff + b] = ones ? (uint8_t)255 : *(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(reg + V3_OUT_IMG + lane * 8 + b);
                         }
                     }
                 }
