@@ -25,8 +25,9 @@ struct StitchConfig {
     std::string ba_cost_func = "no";       // "no" | "reproj"
     std::string ba_refine_mask = "_____";  // the reference's default: rotations only
     std::string wave_correct = "horiz";    // "horiz" | "vert" | "no"; applied after the bundle adjustment only
-    // seam-scale step (:940-1070, :1162-1171).  The reference's defaults are "gain_blocks" and "dp_color"; DpSeamFinder is
-    // not implemented in the library, so both default to "no" here.
+    // seam-scale step (:940-1070, :1162-1171).  The reference's defaults are "gain_blocks" and "dp_color" (both implemented:
+    // mis_compensator_*, mis_seam_dp); this struct defaults to the HOT PATH of the north star (no seam-scale step), like
+    // image_stitching_amd.StitchConfig.hot_path() -- pass "gain_blocks" / "dp_color" for the reference's configuration.
     std::string expos_comp_type = "no";    // "no" | "gain_blocks" (64 x 64 blocks, 1 feed, 2 filtering passes)
     std::string seam_find_type = "no";     // "no" | "voronoi" | "dp_color" (the reference's default; this driver's default is the hot path)
 };

@@ -770,8 +770,6 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     }
     // the 2-NN pass fills the device on its own; what follows are latency-bound chains.  Work that wants to share the
     // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
-    // the 2-NN pass fills the device on its own; what follows are latency-bound chains.  Work that wants to share the
-    // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
     if (!ws->ev_knn) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_knn, hipEventDisableTiming));
     MIS_HIP(ctx, hipEventRecord(ws->ev_knn, st));
     hipLaunchKernelGGL(ratio_union_kernel, dim3(np), dim3(1024), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, (const int*)d_idx,
@@ -915,13 +913,32 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             }
         }
     };
+    // an error from here on must not leave half-built entries behind: the lists are released and `out` is back to its zeroed state
+    auto drop_lists = [&]() {
+        for (int k = 0; k < np; k++) {
+            const PairDesc& pd = pairs[k];
+            MisMatchesInfo* e[2] = {&out[pd.i * n + pd.j], &out[pd.j * n + pd.i]};
+            for (MisMatchesInfo* m : e) { free(m->matches); free(m->inliers_mask); init_info(m); }
+        }
+    };
+    bool have_lists = false;
     if (early_lists) {
         MIS_HIP(ctx, hipEventSynchronize(ws->ev_lists));
         lists();
+        have_lists = true;
     }
-    MIS_HIP(ctx, hipStreamSynchronize(st));
+    {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            if (have_lists) drop_lists();
+            return mis_set_error(ctx, MIS_E_HIP, "hipStreamSynchronize failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+        }
+    }
     const auto ts = std::chrono::steady_clock::now();
-    MIS_CHECK(ctx, !l2_bad, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style)");
+    if (l2_bad) {
+        if (have_lists) drop_lists();
+        return mis_set_error(ctx, MIS_E_UNSUPPORTED, "L2 matching needs integer-valued descriptors in 0..255 (SIFT style)");
+    }
     if (!early_lists) lists();
     // part 2: masks, H, confidence; the mirror entry gets H^-1 and swapped indices
     for (int k = 0; k < np; k++) {
@@ -984,8 +1001,9 @@ extern "C" long long mis_match_sequence(MisContext* ctx) {
 
 // Makes `stream` (any stream of the device, e.g. another context's) wait for the end of the 2-NN pass of this context's
 // matcher call number `target_seq`, which another host thread is making: blocks the calling thread (at most timeout_ms)
-// until that call has enqueued the pass, then enqueues the wait.  Returns MIS_OK also when the time ran out or the call
-// ended without a 2-NN pass (the stream then simply does not wait).
+// until that call has enqueued the pass, then enqueues the wait.  Returns MIS_FENCE_TIMEOUT (> 0, not an error) when the time
+// ran out before that call showed up: nothing was queued, the stream simply does not wait; MIS_OK also when the call ended
+// without a 2-NN pass.
 extern "C" int mis_match_knn_fence(MisContext* ctx, void* stream, long long target_seq, int timeout_ms) {
     if (!ctx) return MIS_E_INVALID;
     MatchWorkspace* ws = (MatchWorkspace*)ctx->match_ws;

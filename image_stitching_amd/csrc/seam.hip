@@ -526,15 +526,24 @@ extern "C" int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisIm
     void* dblk = nullptr; size_t dgot = 0;
     if (any_dev) { int rc = mis_pool_alloc(ctx, stage_total, &dblk, &dgot); if (rc != MIS_OK) return rc; }
     uint8_t* dstage = (uint8_t*)dblk;
+    // every HIP error below returns through here: the device block goes back to the pool
+#define SEAM_HIP(call)                                                                                                          \
+    do {                                                                                                                        \
+        hipError_t e_ = (call);                                                                                                 \
+        if (e_ != hipSuccess) {                                                                                                 \
+            if (dblk) { hipStreamSynchronize(ctx->stream); mis_pool_free(ctx, dblk, dgot); }                                     \
+            return mis_set_error(ctx, MIS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+        }                                                                                                                       \
+    } while (0)
     for (int i = 0; i < n; i++) {
         const MisImage& I = images[i];
         const MisImage& M = masks[i];
-        if (I.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(dstage + ioff[i], (size_t)I.width * 3, I.data, I.stride, (size_t)I.width * 3, I.height, hipMemcpyDeviceToDevice, ctx->stream));
-        if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(dstage + moff[i], M.width, M.data, M.stride, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
+        if (I.mem == MIS_MEM_DEVICE) SEAM_HIP(hipMemcpy2DAsync(dstage + ioff[i], (size_t)I.width * 3, I.data, I.stride, (size_t)I.width * 3, I.height, hipMemcpyDeviceToDevice, ctx->stream));
+        if (M.mem == MIS_MEM_DEVICE) SEAM_HIP(hipMemcpy2DAsync(dstage + moff[i], M.width, M.data, M.stride, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (any_dev) MIS_HIP(ctx, hipMemcpyAsync(stage, dstage, stage_total, hipMemcpyDeviceToHost, ctx->stream));
+    if (any_dev) SEAM_HIP(hipMemcpyAsync(stage, dstage, stage_total, hipMemcpyDeviceToHost, ctx->stream));
     const auto t_issued = std::chrono::steady_clock::now();
-    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SEAM_HIP(hipStreamSynchronize(ctx->stream));
     const auto t_synced = std::chrono::steady_clock::now();
     for (int i = 0; i < n; i++) {   // host inputs go into their slots of the staging buffer directly
         const MisImage& I = images[i];
@@ -602,13 +611,15 @@ extern "C" int mis_seam_dp(MisContext* ctx, const MisPoint* corners, const MisIm
         else for (int y = 0; y < M.height; y++) memcpy((uint8_t*)M.data + (size_t)y * M.stride, mk[i].v.data() + (size_t)y * M.width, M.width);
     }
     if (any_dev) {
-        MIS_HIP(ctx, hipMemcpyAsync(dstage, stage, stage_total, hipMemcpyHostToDevice, ctx->stream));   // (the image slots travel back unused: one copy)
+        SEAM_HIP(hipMemcpyAsync(dstage, stage, stage_total, hipMemcpyHostToDevice, ctx->stream));   // (the image slots travel back unused: one copy)
         for (int i = 0; i < n; i++) {
             const MisImage& M = masks[i];
-            if (M.mem == MIS_MEM_DEVICE) MIS_HIP(ctx, hipMemcpy2DAsync(M.data, M.stride, dstage + moff[i], M.width, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
+            if (M.mem == MIS_MEM_DEVICE) SEAM_HIP(hipMemcpy2DAsync(M.data, M.stride, dstage + moff[i], M.width, M.width, M.height, hipMemcpyDeviceToDevice, ctx->stream));
         }
         mis_pool_free(ctx, dblk, dgot);
+        dblk = nullptr;
     }
+#undef SEAM_HIP
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (getenv("MIS_SEAM_TRACE")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration_cast<std::chrono::microseconds>(b - a).count() / 1e3; };

@@ -524,13 +524,15 @@ __device__ __forceinline__ void tile_stage(const WarpArgs& a, const TileState& t
 }
 
 // Phase 3: bilinear gather from the staged box and the 16SC3 / mask stores
-__device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileState& t, const uint8_t* stage) {
-    if (!t.col_ok) return;
-    uint8_t* drow = (uint8_t*)a.dst + (size_t)t.gy0 * a.dstride + (size_t)t.gx * 6;
-    uint8_t* mrow = a.mask + (size_t)t.gy0 * a.mstride + t.gx;
+#ifndef WV_TILE_LDS_STORE
+#define WV_TILE_LDS_STORE 0     // 1: whole tiles leave through an LDS transpose as 16-byte pieces. Measured SLOWER here (25.6 vs 24.4 us per launch,
+                                // gpurun_out/r3_v3_var12.txt): this kernel is bound by its LDS (2.1-fold bank conflicts of the 2 x 4 lane blocks); the strip kernel is the form where it pays
+#endif
+__device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileState& t, uint8_t* stage, int tx0, int ty0, int lane) {
+    uint3 w[LROWS];
+    unsigned mm[LROWS];
 #pragma unroll
-    for (int i = 0; i < LROWS; i++, drow += a.dstride, mrow += a.mstride) {
-        if (t.gy0 + i >= a.dh) break;
+    for (int i = 0; i < LROWS; i++) {
         int p0[3], p1[3];
 #if WV_ABL == 2   // diagnostics: no LDS gather, no bilinear arithmetic
         if (true) {
@@ -548,26 +550,59 @@ __device__ __forceinline__ void tile_sample_store(const WarpArgs& a, const TileS
             sample1_global(a, t.xq[2 * i], t.yq[2 * i], p0);
             sample1_global(a, t.xq[2 * i + 1], t.yq[2 * i + 1], p1);
         }
-        const unsigned m0 = (t.msk >> (2 * i) & 1) ? 255u : 0u, m1 = (t.msk >> (2 * i + 1) & 1) ? 255u : 0u;
+        w[i].x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+        w[i].y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
+        w[i].z = (unsigned)p1[1] | ((unsigned)p1[2] << 16);
+        mm[i] = ((t.msk >> (2 * i) & 1) ? 255u : 0u) | ((t.msk >> (2 * i + 1) & 1) ? 0xff00u : 0u);
+    }
+#if WV_TILE_LDS_STORE && WV_LROWS == 4 && WV_ABL != 1
+    // whole tile inside the roi, 16-byte aligned outputs (wave-uniform): the 16 rows of 192 bytes are written to the stage (the
+    // box is spent: every tap of this wave has been read), read back as 192 pieces of 16 bytes -- piece p = row * 12 + column
+    // piece, lane l takes p = l, l + 64, l + 128 -- and stored with global_store_dwordx4: 12 lanes cover a row's 192 bytes
+    const bool full = tx0 + FT_W <= a.dw && ty0 + FT_H <= a.dh && ((((size_t)a.dst | a.dstride) & 15) == 0) && ((((size_t)a.mask | a.mstride) & 7) == 0);
+    if (full) {
+        const int lx = lane & 15, ly = lane >> 4;
+        volatile unsigned* so = reinterpret_cast<volatile unsigned*>(stage + (LROWS * ly) * (FT_W * 6) + lx * 12);
+        volatile unsigned short* sm = reinterpret_cast<volatile unsigned short*>(stage + FT_W * FT_H * 6 + (LROWS * ly) * FT_W + lx * 2);
+#pragma unroll
+        for (int i = 0; i < LROWS; i++) {
+            so[i * (FT_W * 6 / 4)] = w[i].x; so[i * (FT_W * 6 / 4) + 1] = w[i].y; so[i * (FT_W * 6 / 4) + 2] = w[i].z;
+            sm[i * (FT_W / 2)] = (unsigned short)mm[i];
+        }
+        uint8_t* dbase = (uint8_t*)a.dst + (size_t)ty0 * a.dstride + (size_t)tx0 * 6;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const int p = kk * 64 + lane, row = p / 12, cb = (p - row * 12) * 16;
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 v = *reinterpret_cast<const u4*>(stage + p * 16);
+            *reinterpret_cast<u4*>(dbase + (size_t)row * a.dstride + cb) = v;
+        }
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 mv = *reinterpret_cast<const u2*>(stage + FT_W * FT_H * 6 + lane * 8);
+        *reinterpret_cast<u2*>(a.mask + (size_t)(ty0 + (lane >> 2)) * a.mstride + tx0 + (lane & 3) * 8) = mv;
+        return;
+    }
+#endif
+    if (!t.col_ok) return;
+    uint8_t* drow = (uint8_t*)a.dst + (size_t)t.gy0 * a.dstride + (size_t)t.gx * 6;
+    uint8_t* mrow = a.mask + (size_t)t.gy0 * a.mstride + t.gx;
+#pragma unroll
+    for (int i = 0; i < LROWS; i++, drow += a.dstride, mrow += a.mstride) {
+        if (t.gy0 + i >= a.dh) break;
         if (t.two) {
-            uint3 w;
-            w.x = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
-            w.y = (unsigned)p0[2] | ((unsigned)p1[0] << 16);
-            w.z = (unsigned)p1[1] | ((unsigned)p1[2] << 16);
 #if WV_ABL == 1   // diagnostics: everything but the global stores
-            asm volatile("" :: "v"(w.x), "v"(w.y), "v"(w.z), "v"(m0 | (m1 << 8)), "v"(drow), "v"(mrow));
+            asm volatile("" :: "v"(w[i].x), "v"(w[i].y), "v"(w[i].z), "v"(mm[i]), "v"(drow), "v"(mrow));
 #else
-            *reinterpret_cast<uint3*>(drow) = w;
-            *reinterpret_cast<unsigned short*>(mrow) = (unsigned short)(m0 | (m1 << 8));
+            *reinterpret_cast<uint3*>(drow) = w[i];
+            *reinterpret_cast<unsigned short*>(mrow) = (unsigned short)mm[i];
 #endif
         } else {
             int16_t* d = reinterpret_cast<int16_t*>(drow);
-            d[0] = (int16_t)p0[0]; d[1] = (int16_t)p0[1]; d[2] = (int16_t)p0[2];
-            mrow[0] = (uint8_t)m0;
+            d[0] = (int16_t)(w[i].x & 0xffff); d[1] = (int16_t)(w[i].x >> 16); d[2] = (int16_t)(w[i].y & 0xffff);
+            mrow[0] = (uint8_t)mm[i];
         }
     }
 }
-
 
 // One tile per wave, TILE_WAVES independent waves per workgroup (no barriers; fewer, larger workgroups to dispatch).
 #ifndef WV_TILE_WAVES
@@ -635,7 +670,7 @@ __device__ __forceinline__ void warp_fused_body(const WarpArgs& a, const float* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const unsigned long long s4 = __builtin_readcyclecounter();
-    tile_sample_store(a, cur, stage);
+    tile_sample_store(a, cur, stage, tx0, ty0, lane);
     const unsigned long long s5 = __builtin_readcyclecounter();
     if (lane == 0 && ty * ntx + tx < 16384) {
         unsigned long long* o = g_warp_stamps + 8 * (ty * ntx + tx);
@@ -647,7 +682,7 @@ __device__ __forceinline__ void warp_fused_body(const WarpArgs& a, const float* 
     tile_stage(a, cur, stage, lane);                       // asynchronous global -> LDS copies ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... have landed
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    tile_sample_store(a, cur, stage);
+    tile_sample_store(a, cur, stage, tx0, ty0, lane);
 #endif
 }
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(WV_WAVES_MIN, 8))) void warp_fused_kernel(WarpArgs a, const float* __restrict__ tab, int ntiles) {
@@ -738,6 +773,9 @@ __global__ __launch_bounds__(256) void warp_trig_batch_kernel(WarpBatch b) {
 #endif
 #ifndef WV3_MG
 #define WV3_MG 8
+#endif
+#ifndef WV3_PRIO
+#define WV3_PRIO 0      // diagnostics: 1 = raised priority during the gather, 2 = during map + copies
 #endif
 #ifndef WV3_PITCH_ALIGN
 #define WV3_PITCH_ALIGN 128
@@ -1095,6 +1133,9 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
         const int ty0 = (ty_first + k) * V3_TH, parity = PIPE ? (k & 1) : 0;
         bool deferred = false;
         V3_STAMP(0);
+#if WV3_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         if (!PIPE) {        // tile k itself: map, copies, (wait for everything)
             v3_map<RING>(f, rowtab, cs.x, cs.y, ty0, ring_lds, 0, cw, cmsk, cu_);
             V3_STAMP(1);
@@ -1110,6 +1151,9 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
             }
         }
         V3_STAMP(2);
+#if WV3_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (k >= 0) {
             WSTAT(cu_.fast ? (cu_.interior ? 0 : 1) : 2);
             if (deferred) WSTAT(4);
@@ -1118,6 +1162,9 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
                 unsigned p[V3_TH][3];     // a channel in the upper 16 bits
                 wait_vm_dyn(pend);
                 V3_STAMP(3);
+#if WV3_PRIO == 1
+                __builtin_amdgcn_s_setprio(2);      // the gather's LDS reads go out ahead of other waves' arithmetic
+#endif
                 // (the empty asm makes a pixel's word opaque per branch: otherwise the common decode of all pixels is hoisted above
                 // the branch and lives in 5 VGPRs per pixel)
                 if (cu_.interior) {
@@ -1141,6 +1188,9 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
                         if (i % V3_GG == V3_GG - 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#if WV3_PRIO == 1
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 const bool ones = cu_.interior != 0;     // (uniform) all taps inside the frame: every lane's mask bits are set
                 int nst = 0;
                 asm volatile("" ::"v"(p[V3_TH - 1][2]));
@@ -1565,11 +1615,25 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
     std::vector<size_t> tab_off((size_t)n);
     size_t tab_total = 0;
     int rc = MIS_OK, got = 0;
+    // which outputs this call allocates (data == NULL on entry): an error hands them back and leaves the caller's structs as they were
+    std::vector<uint8_t> fresh_d((size_t)n), fresh_m((size_t)n);
+    for (int i = 0; i < n; i++) { fresh_d[i] = dsts[i].data == nullptr; fresh_m[i] = dmasks[i].data == nullptr; }
+    auto undo = [&](int upto) {      // frames 0 .. upto (inclusive) may hold staged inputs, device twins of host outputs, fresh outputs
+        hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i <= upto && i < n; i++) {
+            if (din[i].owned && din[i].data) hipFree(din[i].data);
+            if (dout[i].owned && dout[i].data) hipFree(dout[i].data);
+            if (dm[i].owned && dm[i].data) hipFree(dm[i].data);
+            if (fresh_d[i] && dsts[i].data) { hipFree(dsts[i].data); dsts[i].data = nullptr; }
+            if (fresh_m[i] && dmasks[i].data) { hipFree(dmasks[i].data); dmasks[i].data = nullptr; }
+            din[i] = DevImage(); dout[i] = DevImage(); dm[i] = DevImage();
+        }
+    };
     for (; got < n; got++) {
         const int i = got;
         WarpArgs& a = args[i];
         int brx, bry;
-        MIS_CHECK(ctx, rois[i].width > 0 && rois[i].height > 0, MIS_E_INVALID, "frame %d: empty roi", i);
+        if (!(rois[i].width > 0 && rois[i].height > 0)) { rc = mis_set_error(ctx, MIS_E_INVALID, "frame %d: empty roi", i); break; }
         if ((rc = setup(ctx, &srcs[i], scale, Ks + 9 * i, Rs + 9 * i, &a, &brx, &bry, &rois[i])) != MIS_OK) break;
         if (srcs[i].channels != 3) { rc = mis_set_error(ctx, MIS_E_UNSUPPORTED, "fused warp needs an 8UC3 source"); break; }
         if ((rc = mis_dev_image_in(ctx, &srcs[i], &din[i])) != MIS_OK) break;
@@ -1583,7 +1647,7 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
         tab_off[i] = tab_total;
         tab_total += mis_align_up(sizeof(float) * trig_table_floats(a.dw, a.dh), 256);
     }
-    if (rc != MIS_OK) return rc;
+    if (rc != MIS_OK) { undo(got); return rc; }
     if (ctx->stage_bytes < tab_total) {
         if (ctx->stage) { MIS_HIP(ctx, hipStreamSynchronize(ctx->stream)); MIS_HIP(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
         MIS_HIP(ctx, hipMalloc(&ctx->stage, tab_total * 2 + 4096));

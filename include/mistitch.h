@@ -272,7 +272,7 @@ int mis_compensator_gain_map(const MisCompensator* c, int index, float* map_host
 /* image *= gains, in place; 8UC3, or the 16SC3 image the fused warp produces (values 0..255) */
 int mis_compensator_apply(MisCompensator* c, int index, MisImage* image);
 /* VoronoiSeamFinder::find (seam_find_type "voronoi", image_stitching.cpp:1031): masks (8UC1) are edited in place.
- * "no" (NoSeamFinder) needs no call.  The reference's default, DpSeamFinder(COLOR) ("dp_color"), is not implemented. */
+ * "no" (NoSeamFinder) needs no call; the reference's default, DpSeamFinder(COLOR) ("dp_color"), is mis_seam_dp below. */
 int mis_seam_voronoi(MisContext* ctx, const MisPoint* corners, MisImage* masks, int n);
 /* seam_finder = makePtr<detail::DpSeamFinder>(DpSeamFinder::COLOR); seam_finder->find(images_warped_f, corners, masks_warped)
  * -- replaces image_stitching.cpp:1056-1057, :1065 (the reference's default seam finder, "dp_color").  images: the seam-scale

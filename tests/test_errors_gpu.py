@@ -99,3 +99,35 @@ def test_matcher_refuses_mixed_descriptors_and_recovers(ctx):
     a, b = m(fo), m(fo)
     for x, y in zip(a, b):
         assert np.array_equal(x.matches, y.matches) and x.confidence == y.confidence
+
+
+def test_batched_warp_error_hands_back_what_it_allocated(ctx):
+    """mis_warp_spherical_fused_batch with library-allocated outputs (data == NULL) and a bad second frame: the call fails with a
+    code, frame 0's freshly allocated outputs are released and the caller's structs are back to data == NULL; the same call with
+    good frames then works."""
+    import ctypes as C
+    import torch
+    import image_stitching_amd as isa
+    from image_stitching_amd import _capi as capi
+    from image_stitching_amd.stitching import as_image
+    cams, frames = _cam_frames(2)
+    scale = isa.Stitcher.warped_image_scale(cams)
+    rois = isa.stitching.warp_rois(ctx, scale, (frames[0].shape[1], frames[0].shape[0]), cams)
+    Ks = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float32).reshape(9) for c in cams]))
+    Rs = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float32).reshape(9) for c in cams]))
+    rs = (capi.MisRect * 2)(*[capi.MisRect(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in rois])
+    fp = C.POINTER(C.c_float)
+
+    def call(imgs):
+        im = (capi.MisImage * 2)(*[as_image(i) for i in imgs])
+        ds, ms, tls = (capi.MisImage * 2)(), (capi.MisImage * 2)(), (capi.MisPoint * 2)()
+        rc = ctx.lib.mis_warp_spherical_fused_batch(ctx.h, im, 2, float(scale), Ks.ctypes.data_as(fp), Rs.ctypes.data_as(fp), rs, ds, ms, tls)
+        return rc, ds, ms
+    gray = frames[1][:, :, 0].contiguous()
+    rc, ds, ms = call([frames[0], gray])
+    assert rc in (E_UNSUPPORTED, E_INVALID)
+    assert not ds[0].data and not ms[0].data and not ds[1].data and not ms[1].data
+    rc, ds, ms = call(frames)
+    assert rc == 0 and ds[0].data and ms[1].data
+    for k in range(2):
+        ctx.lib.mis_image_free(ctx.h, C.byref(ds[k])); ctx.lib.mis_image_free(ctx.h, C.byref(ms[k]))
