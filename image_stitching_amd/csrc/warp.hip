@@ -1277,7 +1277,7 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
             }
             drow += (size_t)V3_TH * f.dstride; mrow += (size_t)V3_TH * f.mstride;
 #ifdef WV_STAMPS
-            if (lane == 0) {
+            if (lane == 0 && (gridDim.y == 1 || blockIdx.y == gridDim.y / 2)) {      // one frame of a batched grid: the steady state
                 const int tile = (ty_first + k) * ((f.dw + V3_TW - 1) / V3_TW) + tx0 / V3_TW;
                 if (tile < 16384) { unsigned long long* o = g_warp_stamps + 8 * tile; for (int q = 0; q < 6; q++) o[q] = st[q]; o[6] = wall0; o[7] = wall_clock64(); }
             }

@@ -10,7 +10,14 @@ scale = isa.Stitcher.warped_image_scale(cams)
 w = isa.SphericalWarper(ctx, scale)
 roi = w.warpRoi((3840, 2160), cam["K"], cam["R"])
 dst, msk = w.alloc_fused(roi)
-for _ in range(5): w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
+if len(sys.argv) > 1 and sys.argv[1] == "batch":     # steady state: the stamps of the middle frame of the 16-frame grid
+    rois = isa.stitching.warp_rois(ctx, scale, (3840, 2160), cams)
+    fr = [synth.render_frame_gpu(c) for c in cams]
+    outs = [w.alloc_fused(r) for r in rois]
+    w.warp_fused_batch_timed(fr, cams, rois, [o[0] for o in outs], [o[1] for o in outs], 3)
+    roi = rois[8]
+else:
+    for _ in range(5): w.warp_fused_into(frame, cam["K"], cam["R"], roi, dst, msk)
 n = ((roi[2] + 63) // 64) * ((roi[3] + 7) // 8)
 buf = np.zeros((n, 8), np.uint64)
 ctx.lib.mis_debug_warp_stamps(buf.ctypes.data_as(C.c_void_p), n)
