@@ -41,11 +41,63 @@ struct RansacState {
 };
 
 // ---------------------------------------------------------------- shared scalar helpers --------
+// IEEE f64 division and square root as the compiler's own FMA chains (v_rcp_f64 / v_rsq_f64, two refinement steps, one residual
+// correction) WITHOUT the operand scaling (v_div_scale, v_ldexp) and the special-case selection (v_div_fmas / v_div_fixup,
+// v_cmp_class) around them: 8 dependent operations instead of 10 (division) and 13 (square root).  A Jacobi rotation is one
+// dependency chain of three divisions and two square roots, so this is a quarter of its arithmetic latency
+// (tools/micro/lat_bench.hip: 904 cycles for the generic chain).  Bit-identical under ONE guard per rotation: the pivot p and
+// y = (W[l] - W[k]) / 2 normal with exponents in [-370, 370] -- then every operand of the chain (|p|, |y|, t <= 2.5 max, s <= 1.5 t)
+// stays within [-370, 373]: v_div_scale leaves such operands alone (|exponent difference| < 768, no denormal anywhere), the
+// square roots' arguments are 1 + (b/a)^2 in [1, 2].  A per-division guard costs more than it saves (a divergent branch per
+// division: 177 cycles against the generic division's 104).
+__device__ __forceinline__ bool jd_mid(int hi_word) { return (((unsigned)hi_word >> 20) & 0x7ffu) - 653u <= 740u; }
+__device__ __forceinline__ double jd_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    e = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+__device__ __forceinline__ double jd_sqrt_1to2(double x) {      // x in [1, 2]
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
 __device__ __forceinline__ double cv_hypot(double a, double b) {
     a = fabs(a); b = fabs(b);
     if (a > b) { b /= a; return a * sqrt(1 + b * b); }
     if (b > 0) { a /= b; return b * sqrt(1 + a * a); }
     return 0;
+}
+// the rotation of JacobiImpl_ for the pivot p and y = (W[l] - W[k]) / 2: c, s and the diagonal shift t
+template <bool LEAN>
+__device__ __forceinline__ void jacobi_rotation(double p, double y, double* c_, double* s_, double* t_) {
+    double tt, sn, c;
+    if (LEAN) {
+        // cv_hypot(a, b) = max * sqrt(1 + (min / max)^2) in both of its branches (a == b takes the second: 1 + 1)
+        const double ap = fabs(p), ay = fabs(y);
+        const double big = fmax(ap, ay), q1 = jd_div(fmin(ap, ay), big);
+        tt = ay + big * jd_sqrt_1to2(1 + q1 * q1);
+        const double q2 = jd_div(ap, tt);              // tt >= |p|
+        sn = tt * jd_sqrt_1to2(1 + q2 * q2);
+        c = jd_div(tt, sn);
+        sn = jd_div(p, sn); tt = jd_div(p, tt) * p;
+    } else {
+        tt = fabs(y) + cv_hypot(p, y);
+        sn = cv_hypot(p, tt);
+        c = tt / sn;
+        sn = p / sn; tt = (p / tt) * p;
+    }
+    if (y < 0) sn = -sn, tt = -tt;
+    *c_ = c; *s_ = sn; *t_ = tt;
 }
 
 // fundam.cpp haveCollinearPoints (4.5.x: only the last point is tested) + the orientation test
@@ -111,6 +163,9 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
     for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
 }
 
+#ifndef MIS_CHAIN_PRIO
+#define MIS_CHAIN_PRIO 3
+#endif
 // ---------------------------------------------------------------- draw_kernel ------------------
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
@@ -159,6 +214,9 @@ constexpr int DRAW_CHUNK = 4096;
 constexpr int DRAW_PTS = 2048;
 __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
                                                   unsigned long long state_T, int max_iters, int phase, int k_hi_arg) {
+#if MIS_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
+#endif
     __shared__ unsigned char tab[DRAW_CHUNK];  // per position: min(end - start, 127) | pass << 7
     __shared__ float2 pts[2 * DRAW_PTS];       // src then dst of small problems: the random gathers stay on chip
     __shared__ long long s_pos;
@@ -416,11 +474,9 @@ __device__ void jacobi9_compact(const CSlot s) {
         const double p = s.u(k, l);
         if (fabs(p) <= eps) break;
         const double y = (s.w(l) - s.w(k)) * 0.5;
-        double t = fabs(y) + cv_hypot(p, y);
-        double sn = cv_hypot(p, t);
-        const double c = t / sn;
-        sn = p / sn; t = (p / t) * p;
-        if (y < 0) sn = -sn, t = -t;
+        double t, sn, c;
+        if (__all(jd_mid(__double2hiint(p)) && jd_mid(__double2hiint(y)))) jacobi_rotation<true>(p, y, &c, &sn, &t);     // uniform branch
+        else jacobi_rotation<false>(p, y, &c, &sn, &t);
         s.u(k, l) = 0;
         s.w(k) -= t; s.w(l) += t;
         // rotate rows / columns k and l: element pairs (min(i,k), max(i,k)) and (min(i,l), max(i,l)) for every i != k, l
@@ -504,6 +560,9 @@ __device__ int dlt4_compact(const float* M, const float* m, const CSlot s, doubl
 
 __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, const RansacState* states, const int* sub_idx, double* Hc, int* valid,
                                                       int* good, int lo, int max_iters, float thr) {
+#if MIS_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
+#endif
     extern __shared__ double sl[];
     const int b = blockIdx.y, t = threadIdx.x;
     const RansacState st = states[b];
@@ -563,9 +622,15 @@ __global__ __launch_bounds__(256) void hyp_count_kernel(const HomoCall* calls, c
 // ---------------------------------------------------------------- scan_tail_kernel -------------
 #ifdef MIS_TAIL_PROF
 __device__ unsigned long long g_jac_prof[8];    // shader cycles: pivot search, math, rotation, index update (summed over rotations)
+#ifdef MIS_JAC_PROF     // per-rotation section timers: they serialise the rotation (s_memtime waits for the LDS queue), use the coarse ones for totals
 #define JP_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define JP_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_jac_prof[i], (b) - (a)); } while (0)
-__device__ unsigned long long g_tail_prof[8];   // jacobi ticks, rotations, normal_eq ticks, LM iterations, dlt ticks, tail ticks, tails, max tail ticks
+#else
+#define JP_T(v)
+#define JP_ADD(i, a, b)
+#endif
+__device__ unsigned long long g_tail_prof[12];  // [8..11], part 4 launches: first entry (wall clock) + 1, last exit, longest workgroup, workgroups with work
+//   // jacobi ticks, rotations, normal_eq ticks, LM iterations, dlt ticks, tail ticks, tails, max tail ticks
 #define PROF_T0(v) unsigned long long v = wall_clock64()
 #define PROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_tail_prof[i], wall_clock64() - (v)); } while (0)
 #define PROF_INC(i, n) do { if (threadIdx.x == 0) atomicAdd(&g_tail_prof[i], (unsigned long long)(n)); } while (0)
@@ -594,173 +659,186 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// ---- round 3: the pivot candidates live in registers, the searches are wave reductions ----
-// Lane t < n keeps the serial algorithm's candidate of row t (indR[t] and the value A[t][indR[t]]) and of column t (indC[t],
-// A[indC[t]][t]) in registers and updates the values itself when a rotation touches them (the INDICES of rows / columns other than
-// k, l stay stale, as in the serial code).  The pivot -- "first maximum over the row candidates 0 .. n-2, then the column
-// candidates 1 .. n-1" -- is an arg-max over (|value|, candidate order) by four DPP steps inside the 16-lane row; the four
-// re-scans after a rotation (row / column of k and of l: first maximum again) run in the wave's four DPP rows at once, one
-// candidate per lane.  Round 2's form re-read 32 LDS words and ran a 16-way tournament in every lane for the pivot (1470 of its
-// 3600 cycles per rotation) and scanned the four rows / columns serially in four lanes (850); values and results are identical.
-struct JCand {      // a candidate: signed value, order key (smaller wins ties), payload
-    double v;
-    int ord, a, b;
-};
-template <int CTRL>
-__device__ __forceinline__ JCand jc_dpp(const JCand& c) {
-    JCand r;
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(c.v), CTRL, 0xf, 0xf, false);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(c.v), CTRL, 0xf, 0xf, false);
-    const int pk = __builtin_amdgcn_update_dpp(0, (c.ord << 16) | (c.a << 8) | c.b, CTRL, 0xf, 0xf, false);
-    r.v = __hiloint2double(hi, lo);
-    r.ord = pk >> 16; r.a = (pk >> 8) & 0xff; r.b = pk & 0xff;
+// ---- round 3: a rotation without an LDS round trip on its dependency chain ----
+// The wave's four DPP rows (16 lanes each) all run the rotation: lane (g, q) of row g does the serial loop's work for index q
+// (its pair of A, its pair of V, W[q]) and keeps the serial algorithm's candidates of row q (indR[q] and the signed value
+// A[q][indR[q]]) and of column q (indC[q], A[indC[q]][q]) in registers -- four identical copies, so nothing crosses the rows.
+//  * After a rotation the new elements of rows / columns k and l ARE the values xa / ya the lanes have just computed (lane q
+//    holds A[q|k] and A[q|l]): the four re-scans (indR[k], indC[k], indR[l], indC[l]) need no LDS read; DPP row g does one of them.
+//  * "First maximum" = maximum, then the first lane that holds it: |value| is max-reduced by v_max_f64 over DPP moves (four steps
+//    in a 16-lane row, one more for 32 lanes), every lane compares its own value with the maximum and s_ff1 of the ballot is the
+//    serial loop's answer (lane order = scan order; candidate order = rows in lanes 0 .. 15, columns in lanes 16 .. 31).  An
+//    arg-max that carries (value, order, payload) through every step -- this round's first form -- costs 64-bit compares, a
+//    VALU -> SALU -> VALU mask round trip and four selects per step: 705 cycles for a wave (tools/micro/lat_bench.hip) against
+//    904 for the rotation's divisions and square roots.
+//  * W[k], W[l] are lane reads; the LDS copies of A and V are read before the arithmetic chain (they do not depend on it) and
+//    written behind it: the lanes of one wave execute LDS instructions in order, the next rotation's reads see them.
+// Values and results are those of the serial loop (and of rounds 2's and this round's earlier forms).
+__device__ __forceinline__ double jc_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double jc_max_step(double v) {      // max(v, v of the DPP source lane); lanes outside ROW_MASK keep v
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    // every lane is written when ROW_MASK is 0xf (old = 0: no copy of v on the chain); a partial step keeps v in the other rows
+    const int ohi = ROW_MASK == 0xf ? 0 : hi, olo = ROW_MASK == 0xf ? 0 : lo;
+    const double o = __hiloint2double(__builtin_amdgcn_update_dpp(ohi, hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_update_dpp(olo, lo, CTRL, ROW_MASK, 0xf, false));
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));      // the keys are never NaN-signalling: no canonicalising v_max of each operand (fmax adds two)
     return r;
 }
-// the better of two candidates: larger |v| (compared as the bit patterns of non-negative doubles), then smaller order
-__device__ __forceinline__ JCand jc_best(const JCand& x, const JCand& y) {
-    const unsigned long long ax = (unsigned long long)__double_as_longlong(x.v) & 0x7fffffffffffffffull;
-    const unsigned long long ay = (unsigned long long)__double_as_longlong(y.v) & 0x7fffffffffffffffull;
-    const bool take_y = ay > ax || (ay == ax && y.ord < x.ord);
-    JCand r;
-    r.v = take_y ? y.v : x.v; r.ord = take_y ? y.ord : x.ord; r.a = take_y ? y.a : x.a; r.b = take_y ? y.b : x.b;
-    return r;
+__device__ __forceinline__ double jc_row_max(double v) {       // every lane of a 16-lane DPP row ends with the row's maximum
+    v = jc_max_step<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = jc_max_step<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = jc_max_step<0x141>(v);     // row_half_mirror
+    v = jc_max_step<0x140>(v);     // row_mirror
+    return v;
 }
-// arg-max over each 16-lane DPP row (every lane of a row ends with the row's winner)
-__device__ __forceinline__ JCand jc_row_argmax(JCand c) {
-    c = jc_best(c, jc_dpp<0xB1>(c));      // quad_perm [1,0,3,2]
-    c = jc_best(c, jc_dpp<0x4E>(c));      // quad_perm [2,3,0,1]
-    c = jc_best(c, jc_dpp<0x141>(c));     // row_half_mirror
-    c = jc_best(c, jc_dpp<0x140>(c));     // row_mirror
-    return c;
-}
-constexpr int JC_NONE = 0x7fff;           // order of an empty candidate (value 0: loses every tie)
 
 template <int n>
 __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
+    static_assert(n <= 15, "one DPP row per scan");
     double* A = S.A; double* V = S.V; double* W = S.W;
     const int t = threadIdx.x;
     PROF_T0(pj);
     if (t < 64) {
+        JP_T(j_in);
         const double eps = DBL_EPSILON;
-        int i, k, l, m;
+        const int q = t & 15, g = t >> 4;
+        const bool live = q < n;
+        const int qc = live ? q : 0;
+        int i, m;
         double mv;
-        double Wt = 0;   // lane t < n keeps W[t] in a register: W[k], W[l] of a step are two lane reads, not an LDS round trip
-        int ir = 0, ic = 0;          // indR[t], indC[t]
-        double rv = 0, cv = 0;       // A[t][ir], A[ic][t] (signed)
-        if (t < n) {
-            for (int j = 0; j < n; j++) V[t * n + j] = (j == t) ? 1. : 0.;
-            Wt = A[(n + 1) * t];
-            k = t;
-            if (k < n - 1) {
-                for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
-                    double val = fabs(A[n * k + i]);
+        double Wt = 0;               // W[q]: W[k], W[l] of a step are two lane reads, not an LDS round trip
+        int ir = 0, ic = 0;          // indR[q], indC[q]
+        double rv = 0, cv = 0;       // A[q][ir], A[ic][q] (signed)
+        if (live) {
+            if (g == 0) for (int j = 0; j < n; j++) V[q * n + j] = (j == q) ? 1. : 0.;
+            Wt = A[(n + 1) * q];
+            if (q < n - 1) {
+                for (m = q + 1, mv = fabs(A[n * q + m]), i = q + 2; i < n; i++) {
+                    double val = fabs(A[n * q + i]);
                     if (mv < val) mv = val, m = i;
                 }
-                ir = m; rv = A[n * k + m];
+                ir = m; rv = A[n * q + m];
             }
-            if (k > 0) {
-                for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
-                    double val = fabs(A[n * i + k]);
+            if (q > 0) {
+                for (m = 0, mv = fabs(A[q]), i = 1; i < q; i++) {
+                    double val = fabs(A[n * i + q]);
                     if (mv < val) mv = val, m = i;
                 }
-                ic = m; cv = A[n * m + k];
+                ic = m; cv = A[n * m + q];
             }
         }
         wave_sync();
+        // pivot: first maximum over the row candidates 0 .. n-2 (lanes 0 .. of DPP row 0), then the column candidates 1 .. n-1 (row 1)
+        const bool isr = g == 0 && q < n - 1, isc = g == 1 && q >= 1 && live;
+        int k, l;
+        double p;
+        auto pivot = [&]() {
+            const double key = isr ? fabs(rv) : (isc ? fabs(cv) : -1.);
+            const double m32 = jc_max_step<0x142, 0x2>(jc_row_max(key));       // row_bcast:15 into row 1: lane 31 holds the maximum of lanes 0 .. 31
+            const double mx = jc_readlane(m32, 31);
+            const unsigned long long eq = __ballot(key == mx);
+            const int L = __builtin_ctzll(eq | (1ull << 63));
+            const int pk = isr ? (q << 8) | ir : (ic << 8) | q;
+            const int wk = __builtin_amdgcn_readlane(pk, L);
+            k = wk >> 8; l = wk & 0xff;
+            p = jc_readlane(isr ? rv : cv, L);
+        };
+        pivot();
+        JP_T(j_loop);
+        JP_ADD(0, j_in, j_loop);
         const int maxIters = n * n * 30;
-        if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
-            JP_T(j0);
-            // pivot: candidate order = rows 0 .. n-2 (order t), then columns 1 .. n-1 (order n - 2 + t)
-            JCand rc, cc;
-            rc.v = t < n - 1 ? rv : 0.; rc.ord = t < n - 1 ? t : JC_NONE; rc.a = t; rc.b = ir;
-            cc.v = (t >= 1 && t < n) ? cv : 0.; cc.ord = (t >= 1 && t < n) ? n - 2 + t : JC_NONE; cc.a = ic; cc.b = t;
-            const JCand win = jc_row_argmax(jc_best(rc, cc));
-            k = __builtin_amdgcn_readfirstlane(win.a); l = __builtin_amdgcn_readfirstlane(win.b);   // lane 0 sits in the row of lanes 0 .. n-1
-            const double p = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(win.v)), __builtin_amdgcn_readfirstlane(__double2loint(win.v)));
+        int iters = 0;
+        if (n > 1) for (; iters < maxIters; iters++) {
             if (fabs(p) <= eps) break;
-            PROF_INC(1, 1);
             JP_T(j1);
-            const double Wk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Wt), k), __builtin_amdgcn_readlane(__double2loint(Wt), k));
-            const double Wl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Wt), l), __builtin_amdgcn_readlane(__double2loint(Wt), l));
+            // this lane's pair of A (q < k: (A[q][k], A[q][l]); k < q < l: (A[k][q], A[q][l]); l < q: (A[k][q], A[l][q])) and of V
+            const bool aa = live & (q != k) & (q != l);
+            double* X = A + (n * min(qc, k) + max(qc, k));
+            double* Y = A + (n * min(qc, l) + max(qc, l));
+            double* VX = V + n * k + qc;
+            double* VY = V + n * l + qc;
+            const double a0 = *X, b0 = *Y, va0 = *VX, vb0 = *VY;
+            const double Wk = jc_readlane(Wt, k), Wl = jc_readlane(Wt, l);
             const double y = (Wl - Wk) * 0.5;
-            double tt = fabs(y) + cv_hypot(p, y);
-            double sn = cv_hypot(p, tt);
-            const double c = tt / sn;
-            sn = p / sn; tt = (p / tt) * p;
-            if (y < 0) sn = -sn, tt = -tt;
-#ifdef MIS_TAIL_PROF
+            double c, sn, tt;
+            if (jd_mid(__builtin_amdgcn_readfirstlane(__double2hiint(p))) && jd_mid(__builtin_amdgcn_readfirstlane(__double2hiint(y))))      // scalar branch
+                jacobi_rotation<true>(p, y, &c, &sn, &tt);
+            else
+                jacobi_rotation<false>(p, y, &c, &sn, &tt);
+#ifdef MIS_JAC_PROF
             asm volatile("" :: "v"(c), "v"(sn), "v"(tt));
 #endif
             JP_T(j2);
-            if (t == k) Wt -= tt;
-            if (t == l) Wt += tt;
-            {
-                // lane t rotates the pair of A that involves row / column t and the pair of V in column t (t < k: (A[t][k], A[t][l]);
-                // k < t < l: (A[k][t], A[t][l]); l < t: (A[k][t], A[l][t])); the previous step's writes were fenced at its end
-                const bool va = t < n, aa = va && t != k && t != l;
-                const int tc = va ? t : 0;
-                double* X = A + (tc < k ? n * tc + k : n * k + tc);
-                double* Y = A + (tc < l ? n * tc + l : n * l + tc);
-                double* VX = V + n * k + tc;
-                double* VY = V + n * l + tc;
-                const double a0 = *X, b0 = *Y, va0 = *VX, vb0 = *VY;
-                const double xa = a0 * c - b0 * sn, ya = a0 * sn + b0 * c, xv = va0 * c - vb0 * sn, yv = va0 * sn + vb0 * c;
-                if (aa) { *X = xa; *Y = ya; }
-                if (va) { *VX = xv; *VY = yv; }
-                if (t == 0) A[n * k + l] = 0;
-                // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
-                if (aa) {
-                    if (t < k) { if (ir == k) rv = xa; if (ir == l) rv = ya; }
-                    else if (t < l) { if (ic == k) cv = xa; if (ir == l) rv = ya; }
-                    else { if (ic == k) cv = xa; if (ic == l) cv = ya; }
-                }
+            // everything below is selects, not branches: a divergent region costs a VALU -> SALU -> exec round trip each
+            const bool uk = q == k, ul = q == l;
+            Wt = uk ? Wt - tt : (ul ? Wt + tt : Wt);
+            const double xa = a0 * c - b0 * sn, ya = a0 * sn + b0 * c, xv = va0 * c - vb0 * sn, yv = va0 * sn + vb0 * c;
+            if (g == 0 && live) {
+                // lanes k and l hold the pivot element (lane k as its Y, lane l as its X: zero) and a diagonal element (never read again: W is in registers)
+                *X = aa ? xa : (ul ? 0. : a0);
+                *Y = aa ? ya : (uk ? 0. : b0);
+                *VX = xv; *VY = yv;
             }
-            wave_sync();
-            JP_T(j3);
+            // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
+            // (q < k: row candidate in column k or l; k < q < l: column candidate in row k, row candidate in column l; l < q: column candidate in row k or l)
+            // (bitwise & on the conditions: && chains come out as exec-mask branches)
+            rv = (aa & (q < k) & (ir == k)) ? xa : rv;
+            rv = (aa & (q < l) & (ir == l)) ? ya : rv;
+            cv = (aa & (q > k) & (ic == k)) ? xa : cv;
+            cv = (aa & (q > l) & (ic == l)) ? ya : cv;
             {
-                // indR[k], indC[k], indR[l], indC[l]: DPP row g = t >> 4 scans the row (g even) or the column (g odd) of idx = k (g < 2)
-                // or l, lane q = t & 15 holds element q of it; first maximum = arg-max with the smaller q winning ties
-                const int g = t >> 4, q = t & 15;
+                // the scans: row k (DPP row 0), column k (1), row l (2), column l (3); element q of each is this lane's xa / ya, the
+                // pivot element A[k][l] is zero.  An empty scan (column 0, row n - 1) leaves its candidate alone.
                 const int idx = g < 2 ? k : l;
-                const bool row = (g & 1) == 0;
-                const bool valid = row ? (q > idx && q < n) : q < idx;
-                const int qc = valid ? q : (row ? min(idx + 1, n - 1) : 0);
-                JCand sc;
-                sc.v = valid ? A[row ? n * idx + qc : n * qc + idx] : 0.;
-                sc.ord = valid ? q : JC_NONE; sc.a = q; sc.b = 0;
-                sc = jc_row_argmax(sc);
-                // row results to lanes k and l (every lane of a DPP row holds its row's winner)
-                int ra[4];
-                double rvv[4];
+                const bool rowscan = (g & 1) == 0;
+                const bool valid = (rowscan & (q > idx) & live) | (!rowscan & (q < idx));
+                const double ev = g < 2 ? (ul ? 0. : xa) : (uk ? 0. : ya);
+                const double key = valid ? fabs(ev) : -1.;
+                const double mx = jc_row_max(key);
+                const unsigned long long eq = __ballot(valid & (key == mx));
+                int w[4];
+                double wv[4];
+                bool has[4];
 #pragma unroll
                 for (int gg = 0; gg < 4; gg++) {
-                    ra[gg] = __builtin_amdgcn_readlane(sc.a, 16 * gg);
-                    rvv[gg] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sc.v), 16 * gg), __builtin_amdgcn_readlane(__double2loint(sc.v), 16 * gg));
+                    const unsigned bits = (unsigned)(eq >> (16 * gg)) & 0xffffu;
+                    has[gg] = bits != 0;
+                    w[gg] = __builtin_ctz(bits | 0x10000u) & 15;
+                    wv[gg] = jc_readlane(ev, 16 * gg + w[gg]);
                 }
-                if (t == k) {
-                    if (k < n - 1) { ir = ra[0]; rv = rvv[0]; }
-                    if (k > 0) { ic = ra[1]; cv = rvv[1]; }
-                }
-                if (t == l) {
-                    if (l < n - 1) { ir = ra[2]; rv = rvv[2]; }
-                    if (l > 0) { ic = ra[3]; cv = rvv[3]; }
-                }
+                const bool r_k = uk & has[0], c_k = uk & has[1], r_l = ul & has[2], c_l = ul & has[3];
+                ir = r_k ? w[0] : (r_l ? w[2] : ir); rv = r_k ? wv[0] : (r_l ? wv[2] : rv);
+                ic = c_k ? w[1] : (c_l ? w[3] : ic); cv = c_k ? wv[1] : (c_l ? wv[3] : cv);
             }
+            JP_T(j3);
+            pivot();
+            wave_sync();
             JP_T(j4);
-            JP_ADD(0, j0, j1); JP_ADD(1, j1, j2); JP_ADD(2, j2, j3); JP_ADD(3, j3, j4);
+            JP_ADD(1, j1, j2); JP_ADD(2, j2, j3); JP_ADD(3, j3, j4);
         }
+        PROF_INC(1, iters);
+        JP_T(j_sort);
         if (t < n) W[t] = Wt;
         wave_sync();
         if (t == 0) {
-            for (k = 0; k < n - 1; k++) {
-                m = k;
-                for (i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
-                if (k != m) {
-                    double tw = W[m]; W[m] = W[k]; W[k] = tw;
-                    for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+            int kk;
+            for (kk = 0; kk < n - 1; kk++) {
+                m = kk;
+                for (i = kk + 1; i < n; i++) if (W[m] < W[i]) m = i;
+                if (kk != m) {
+                    double tw = W[m]; W[m] = W[kk]; W[kk] = tw;
+                    for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * kk + i]; V[n * kk + i] = tv; }
                 }
             }
         }
+        JP_T(j_end);
+        JP_ADD(4, j_sort, j_end);
+#ifdef MIS_JAC_PROF
+        if (t == 0) atomicAdd(&g_jac_prof[5], 1ull);
+#endif
     }
     __syncthreads();
     PROF_ADD(0, pj);
@@ -990,6 +1068,13 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
 __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
                                                        double confidence, float thr, int* fin, int part, int want) {
+#if MIS_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
+#endif
+#ifdef MIS_TAIL_PROF
+    const unsigned long long wg_in = wall_clock64();
+    if (part == 4 && want == 0 && threadIdx.x == 0) atomicMin(&g_tail_prof[8], wg_in);
+#endif
     __shared__ TailShared S;
     __shared__ int s_done_now;
     __shared__ int wcnt[TB / 64];
@@ -1100,6 +1185,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     PROF_INC(6, 1);
 #ifdef MIS_TAIL_PROF
     if (t == 0) atomicMax(&g_tail_prof[7], wall_clock64() - pt);
+    if (part == 4 && want == 0 && t == 0) { const unsigned long long o = wall_clock64(); atomicMax(&g_tail_prof[9], o); atomicMax(&g_tail_prof[10], o - wg_in); atomicAdd(&g_tail_prof[11], 1ull); }
 #endif
     if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; if (part == 4) st->tail_pending = 0; }
 }
@@ -1157,8 +1243,8 @@ int homo_batch_reserve(MisContext* ctx, HomoBatch* b, int count, long long point
 #ifdef MIS_TAIL_PROF
 extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(unsigned long long) * 12);
+    if (reset) { unsigned long long z[12] = {0}; z[8] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
     return 0;
 }
 extern "C" int mis_debug_jac_prof(unsigned long long* out, int reset) {

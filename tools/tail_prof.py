@@ -7,13 +7,15 @@ ctx = isa.Context(0)
 cams = synth.workload("config3")
 frames = {i: synth.render_frame_gpu(c) for i, c in enumerate(cams)}
 job = StitchJob(ctx, (3840, 2160), cams)
+full = len(sys.argv) > 1 and sys.argv[1] == "full"      # the whole step (composition speculated beside the chains), not the matcher alone
 feats = job.stage_features(frames)
-job.stage_match(feats)
-out = (C.c_ulonglong * 8)()
+step = (lambda: job.run(frames)) if full else (lambda: job.stage_match(feats))
+step()
+out = (C.c_ulonglong * 12)()
 jp = (C.c_ulonglong * 8)()
 ctx.lib.mis_debug_tail_prof(out, 1)
 ctx.lib.mis_debug_jac_prof(jp, 1)
-job.stage_match(feats)
+step()
 ctx.lib.mis_debug_tail_prof(out, 1)
 ctx.lib.mis_debug_jac_prof(jp, 1)
 v = list(out)
@@ -21,6 +23,10 @@ tick = 0.01  # us (100 MHz)
 print("tails %d  rotations %d  LM iterations %d" % (v[6], v[1], v[3]))
 print("jacobi %.1f us total (%.2f us / rotation)   normal_eq %.1f us   dlt(incl. its jacobi) %.1f us   tail %.1f us  max tail %.1f us"
       % (v[0] * tick, v[0] * tick / max(v[1], 1), v[2] * tick, v[4] * tick, v[5] * tick, v[7] * tick))
+print("DLT + LM launches of the first estimation (part 4 of the phase-0 finishers): first entry -> last exit %.1f us, longest workgroup %.1f us, %d workgroups with work"
+      % ((v[9] - v[8]) * tick, v[10] * tick, v[11]))
 j = list(jp)
 rot = max(v[1], 1)
-print("per rotation (shader cycles): pivot search %.0f  math %.0f  rotation %.0f  index update %.0f  sum %.0f" % (j[0] / rot, j[1] / rot, j[2] / rot, j[3] / rot, sum(j[:4]) / rot))
+if j[5]:      # library built with -DMIS_JAC_PROF as well (the fine timers serialise the rotation: totals above are then inflated)
+    print("jacobi calls %d (%.1f rotations each): set-up %.0f cycles / call, eigenvalue sort %.0f cycles / call" % (j[5], rot / j[5], j[0] / j[5], j[4] / j[5]))
+    print("per rotation (shader cycles): loads + arithmetic %.0f  rotation + re-scans %.0f  pivot %.0f  sum %.0f" % (j[1] / rot, j[2] / rot, j[3] / rot, sum(j[1:4]) / rot))
