@@ -641,6 +641,7 @@ __device__ unsigned long long g_tail_prof[12];  // [8..11], part 4 launches: fir
 #define JP_T(v)
 #define JP_ADD(i, a, b)
 #endif
+constexpr int TAIL_PCAP = 2048;
 struct TailShared {
     double A[81], V[81], W[9];
     double best[9], nrm[8];
@@ -649,7 +650,23 @@ struct TailShared {
     int indR[9], indC[9];
     int np, go;
     double chunk[TB * 10];  // per-point terms of the current 256-point chunk of a sequential sum
+    float4 pts[TAIL_PCAP];  // the tail's point set {d.x, d.y, s.x, s.y}, staged once: every pass of the DLT and of the LM refinement reads it
 };
+// The DLT (two passes for the normalisation, one for L^T L) and every normal-equations pass of the LM refinement (1 + up to 20)
+// walk the same inlier set 256 points at a time; from global memory each chunk starts with an exposed memory latency (1 - 3 us
+// beside the composition's kernels: a third of a 21 us pass over 586 points).  Points past TAIL_PCAP are read from memory.
+__device__ __forceinline__ void tail_stage_points(TailShared& S, const float* s1, const float* d1, int np) {
+    for (int i = threadIdx.x; i < min(np, TAIL_PCAP); i += TB) {
+        const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
+        S.pts[i] = make_float4(dd.x, dd.y, ss.x, ss.y);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ float4 tail_point(const TailShared& S, const float* s1, const float* d1, int i) {
+    if (i < TAIL_PCAP) return S.pts[i];
+    const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
+    return make_float4(dd.x, dd.y, ss.x, ss.y);
+}
 
 // Jacobi with the n independent plane rotations of a step spread over n lanes and the four
 // index-table scans over four lanes; the arithmetic of every element is that of the serial loop.
@@ -857,20 +874,32 @@ __device__ __forceinline__ void lm_point(const double* h, double Mx, double My, 
 // overwritten unless the configuration is degenerate.  Sums keep the sequential order.
 __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np, double* rec) {
     const int t = threadIdx.x;
-    if (t < 4) {
-        double acc = 0;
-        const float* p = t < 2 ? d1 : s1;  // cmx cmy cMx cMy
-        for (int i = 0; i < np; i++) acc += p[2 * i + (t & 1)];
-        S.nrm[t] = acc / np;
+    {
+        // the four centroids and the four mean absolute deviations: sequential sums over the points by four accumulator threads, from
+        // the staged set in LDS (a serial loop over global memory pays a memory latency per handful of points: 100 us of a 270 us DLT
+        // at 500 points); points past the staged set go through a 256-point buffer.
+        float* stage = reinterpret_cast<float*>(S.chunk);      // 4 floats per point: d.x d.y s.x s.y
+        for (int pass = 0; pass < 2; pass++) {
+            double acc = 0;
+            const double c = pass ? S.nrm[t & 3] : 0.;
+            for (int base = 0; base < np; base += TB) {
+                const int i = base + t, cnt = min(TB, np - base);
+                const float* src = reinterpret_cast<const float*>(S.pts + base);      // the staged set itself while it lasts
+                if (base + TB > TAIL_PCAP) {
+                    if (i < np) reinterpret_cast<float4*>(stage)[t] = tail_point(S, s1, d1, i);
+                    __syncthreads();
+                    src = stage;
+                }
+                if (t < 4) {
+                    if (pass == 0) for (int q = 0; q < cnt; q++) acc += src[4 * q + t];
+                    else for (int q = 0; q < cnt; q++) acc += fabs(src[4 * q + t] - c);
+                }
+                if (base + TB > TAIL_PCAP) __syncthreads();
+            }
+            if (t < 4) { if (pass == 0) S.nrm[t] = acc / np; else S.nrm[4 + t] = acc; }      // cmx cmy cMx cMy, then smx smy sMx sMy
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    if (t < 4) {
-        double acc = 0, c = S.nrm[t];
-        const float* p = t < 2 ? d1 : s1;  // smx smy sMx sMy
-        for (int i = 0; i < np; i++) acc += fabs(p[2 * i + (t & 1)] - c);
-        S.nrm[4 + t] = acc;
-    }
-    __syncthreads();
     const bool degenerate = fabs(S.nrm[4]) < DBL_EPSILON || fabs(S.nrm[5]) < DBL_EPSILON || fabs(S.nrm[6]) < DBL_EPSILON || fabs(S.nrm[7]) < DBL_EPSILON;
     __syncthreads();
     if (t == 0) S.go = !degenerate;
@@ -890,8 +919,9 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
         for (int base = 0; base < np; base += TB) {
             const int i = base + t, cnt = min(TB, np - base);
             if (i < np) {
-                double x = (d1[2 * i] - cmx) * smx, y = (d1[2 * i + 1] - cmy) * smy;
-                double X = (s1[2 * i] - cMx) * sMx, Y = (s1[2 * i + 1] - cMy) * sMy;
+                const float4 pt = tail_point(S, s1, d1, i);
+                double x = (pt.x - cmx) * smx, y = (pt.y - cmy) * smy;
+                double X = (pt.z - cMx) * sMx, Y = (pt.w - cMy) * sMy;
                 double* r = S.chunk + 10 * t;  // X Y 1 0 -xX -xY -x -yX -yY -y
                 r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
             }
@@ -919,48 +949,59 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
     double* x = S.lm;            double* xd = x + 8;   double* A = xd + 8;  double* Ap = A + 64;
     double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // S, Sd, rmax, accepted, lambda, lc, need_invert, nu
     auto normal_eq = [&](const double* h, bool with_J) {
-        // thread roles of the sequential sums: 36 entries of J^T J, 8 of J^T r, one for |r|^2 and |r|_inf
+        // thread roles of the sequential sums, all in wave 0 and all of one form, acc += r[a0] r[b0]; acc += r[a1] r[b1] per point:
+        // 36 entries of J^T J (t < 36), 8 of J^T r (36 .. 43), |r|^2 (44, which also keeps |r|_inf).  Spread over three waves
+        // (round 2) the three loops competed for the LDS pipe: 82 cycles per point against this loop's ~40 (one wave's issue rate).
         const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
         int ai = 0, aj = t;
         while (t < 36 && aj >= 8 - ai) { aj -= 8 - ai; ai++; }
         aj += ai;
         int a0 = 9, b0 = 9, a1 = 9, b1 = 9;
         if (t < 36) { a0 = j0[ai]; b0 = j0[aj]; a1 = j1[ai]; b1 = j1[aj]; }
-        else if (t >= 64 && t < 72) { a0 = j0[t - 64]; b0 = 7; a1 = j1[t - 64]; b1 = 8; }
+        else if (t < 44) { a0 = j0[t - 36]; b0 = 7; a1 = j1[t - 36]; b1 = 8; }
+        else if (t == 44) { a0 = 7; b0 = 7; a1 = 8; b1 = 8; }
         double acc = 0, mx = 0;
         PROF_T0(pn);
         for (int base = 0; base < np; base += TB) {
             const int p = base + t, cnt = min(TB, np - base);
             if (p < np) {
-                double Mx = (double)s1[2 * p], My = (double)s1[2 * p + 1], ww, xi, yi;
+                const float4 pt = tail_point(S, s1, d1, p);
+                double Mx = (double)pt.z, My = (double)pt.w, ww, xi, yi;
                 lm_point(h, Mx, My, &ww, &xi, &yi);
                 double* r = S.chunk + 10 * t;  // a b ww c0 c1 c2 c3 e0 e1 0
-                r[7] = xi - (double)d1[2 * p]; r[8] = yi - (double)d1[2 * p + 1];
+                r[7] = xi - (double)pt.x; r[8] = yi - (double)pt.y;
                 r[0] = Mx * ww; r[1] = My * ww; r[2] = ww;
                 r[3] = -Mx * ww * xi; r[4] = -My * ww * xi; r[5] = -Mx * ww * yi; r[6] = -My * ww * yi; r[9] = 0;
             }
             __syncthreads();
-            if (with_J && (t < 36 || (t >= 64 && t < 72))) {
-                for (int q = 0; q < cnt; q++) {
-                    const double* r = S.chunk + 10 * q;
-                    acc += r[a0] * r[b0];
-                    acc += r[a1] * r[b1];
+            if (with_J ? t < 45 : t == 44) {
+                // "if (fabs(e) > mx) mx = fabs(e)" is a maximum: one v_max_f64 per value (lane 44's operands are the residuals; the
+                // other lanes' maxima are not used).  Eight points per trip, LDS reads up front.
+                auto one = [&](const double* r) {
+                    const double u0 = r[a0], v0 = r[b0], u1 = r[a1], v1 = r[b1];
+                    acc += u0 * v0;
+                    acc += u1 * v1;
+                    asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(u0));
+                    asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(u1));
+                };
+                int q = 0;
+#pragma unroll 1
+                for (; q + 8 <= cnt; q += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) one(S.chunk + 10 * (q + u));
                 }
-            } else if (t == 128) {
-                for (int q = 0; q < cnt; q++) {
-                    const double e0 = S.chunk[10 * q + 7], e1 = S.chunk[10 * q + 8];
-                    acc += e0 * e0; acc += e1 * e1;
-                    if (fabs(e0) > mx) mx = fabs(e0);
-                    if (fabs(e1) > mx) mx = fabs(e1);
-                }
+                for (; q < cnt; q++) one(S.chunk + 10 * q);
             }
             __syncthreads();
         }
         if (with_J && t < 36) { A[ai * 8 + aj] = acc; A[aj * 8 + ai] = acc; }
-        else if (with_J && t >= 64 && t < 72) v[t - 64] = acc;
-        else if (t == 128) { sc[with_J ? 0 : 1] = acc; if (with_J) sc[2] = mx; }
+        else if (with_J && t >= 36 && t < 44) v[t - 36] = acc;
+        else if (t == 44) { sc[with_J ? 0 : 1] = acc; if (with_J) sc[2] = mx; }
         __syncthreads();
         PROF_ADD(2, pn);
+#ifdef MIS_TAIL_PROF
+        if (t == 0) { atomicAdd(&g_jac_prof[6], (unsigned long long)np); atomicAdd(&g_jac_prof[7], 1ull); }
+#endif
     };
     if (t < 8) x[t] = S.best[t];
     __syncthreads();
@@ -1106,6 +1147,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         // exactly four correspondences: runKernel directly, mask all ones, no refinement
         if (t == 0) for (int i = 0; i < 9; i++) S.best[i] = 0;
         __syncthreads();
+        tail_stage_points(S, c.src, c.dst, 4);
         dlt_coop(S, c.src, c.dst, 4, rec);
         const int ok = S.go;
         for (int i = t; c.mask && i < n; i += TB) c.mask[i] = ok ? 1 : 0;
@@ -1177,6 +1219,7 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     }
     PROF_T0(pt);
     if (np > 0) {
+        tail_stage_points(S, s1, d1, np);
         dlt_coop(S, s1, d1, np, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
         PROF_ADD(4, pt);
         lm_refine_coop(S, s1, d1, np, rec);

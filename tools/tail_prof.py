@@ -27,6 +27,8 @@ print("DLT + LM launches of the first estimation (part 4 of the phase-0 finisher
       % ((v[9] - v[8]) * tick, v[10] * tick, v[11]))
 j = list(jp)
 rot = max(v[1], 1)
+if j[7]:
+    print("normal equations: %d passes over %.0f points on average: %.2f us per pass, %.1f ns per point" % (j[7], j[6] / j[7], v[2] * tick / j[7], 1e3 * v[2] * tick / max(j[6], 1)))
 if j[5]:      # library built with -DMIS_JAC_PROF as well (the fine timers serialise the rotation: totals above are then inflated)
     print("jacobi calls %d (%.1f rotations each): set-up %.0f cycles / call, eigenvalue sort %.0f cycles / call" % (j[5], rot / j[5], j[0] / j[5], j[4] / j[5]))
     print("per rotation (shader cycles): loads + arithmetic %.0f  rotation + re-scans %.0f  pivot %.0f  sum %.0f" % (j[1] / rot, j[2] / rot, j[3] / rot, sum(j[1:4]) / rot))
