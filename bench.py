@@ -31,8 +31,8 @@ import torch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="config2 | config3 | config4 (default: config3, config4 when --gpus > 1)")
     ap.add_argument("--features", default=None, help="orb | sift (default: orb; sift for config5, BASELINE.json configs[4])")
     ap.add_argument("--pipeline", default="hot_path", choices=["hot_path", "reference_default"],
@@ -163,17 +163,16 @@ def main():
     gc.collect()
     gc.disable()
     barrier()
-    trace = [] if os.environ.get("BENCH_TRACE") else None
+    trace = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
         out = step()
-        if trace is not None:
-            trace.append((time.perf_counter() - ts) * 1e3)
+        trace.append((time.perf_counter() - ts) * 1e3)
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    if trace is not None:
+    if os.environ.get("BENCH_TRACE"):
         log("per-step ms: " + " ".join("%.2f" % v for v in trace))
     if world > 1:
         import torch.distributed as dist
@@ -216,6 +215,7 @@ def main():
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "ms_per_step_median": round(sorted(trace)[len(trace) // 2], 3), "ms_per_step_min": round(min(trace), 3),      # this rank's steps (value is the mean)
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%s: %d x %dx%d frames, %s + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"

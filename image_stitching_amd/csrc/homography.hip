@@ -211,8 +211,12 @@ __device__ long long attempt_at(DrawCtx& d, long long pos, const float* src, con
 // chunks of DRAW_CHUNK stream positions by all threads, then thread 0 chases through the chunk; a new
 // chunk starts exactly where the chase left the previous one.
 constexpr int DRAW_CHUNK = 4096;
+#ifndef MIS_DRAW_TB
+#define MIS_DRAW_TB 1024
+#endif
+constexpr int DRAW_TB = MIS_DRAW_TB;   // threads of a problem's workgroup: a chunk's positions are simulated DRAW_CHUNK / DRAW_TB per thread (256 threads: 0.54 + 1.08 ms for the two draw launches on the matcher's critical path)
 constexpr int DRAW_PTS = 2048;
-__global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
+__global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, RansacState* states, int* sub_idx, int* draw_idx, const unsigned* U,
                                                   unsigned long long state_T, int max_iters, int phase, int k_hi_arg) {
 #if MIS_CHAIN_PRIO
     __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     __shared__ unsigned short acc_o[DRAW_CHUNK / 4];  // chunk offsets of the accepted attempts (serial path)
     __shared__ unsigned short nxtA[DRAW_CHUNK + 1], nxtB[DRAW_CHUNK + 1];  // J^(2^r): start of the attempt 2^r hops ahead
     __shared__ unsigned char reach[DRAW_CHUNK];
-    __shared__ int scan[TB];
+    __shared__ int scan[DRAW_TB];
     __shared__ int s_big, s_firstvis, s_lastaccvis;
     __shared__ long long s_endpos;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     const float* psrc = c.src;
     const float* pdst = c.dst;
     if (c.n <= DRAW_PTS) {
-        for (int i = t; i < c.n; i += TB) { pts[i] = reinterpret_cast<const float2*>(c.src)[i]; pts[DRAW_PTS + i] = reinterpret_cast<const float2*>(c.dst)[i]; }
+        for (int i = t; i < c.n; i += DRAW_TB) { pts[i] = reinterpret_cast<const float2*>(c.src)[i]; pts[DRAW_PTS + i] = reinterpret_cast<const float2*>(c.dst)[i]; }
         psrc = reinterpret_cast<const float*>(pts); pdst = reinterpret_cast<const float*>(pts + DRAW_PTS);
         __syncthreads();
     }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
         // ~150k stream positions (two such problems set the duration of the whole launch in a 16-frame job).
         const int n = c.n, total = n * (n - 1) * (n - 2) * (n - 3);
         int any = 0;
-        for (int q = t; q < total && !any; q += TB) {
+        for (int q = t; q < total && !any; q += DRAW_TB) {
             int r = q, id[4];
             id[0] = r % n; r /= n;
             int a1 = r % (n - 1); r /= (n - 1);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
     }
     while (s_more) {
         const long long base = s_pos;
-        for (int o = t; o < DRAW_CHUNK; o += TB) {
+        for (int o = t; o < DRAW_CHUNK; o += DRAW_TB) {
             int idx[4];
             bool pass;
             long long e = attempt_at(d, base + o, psrc, pdst, c.n, idx, &pass);
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
         __syncthreads();
         // ---- which attempts does the sequential chain visit?  start -> end -> ... by pointer doubling ----
         constexpr int C = DRAW_CHUNK;
-        for (int q = t; q < C; q += TB) {
+        for (int q = t; q < C; q += DRAW_TB) {
             const unsigned char e = tab[q];
             if ((e & 0x7f) == 127) s_big = 1;  // an attempt longer than 126 draws: take the serial path for this chunk
             nxtA[q] = (unsigned short)(q + (e & 0x7f));
@@ -315,31 +319,31 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
             unsigned short* cur = nxtA;
             unsigned short* oth = nxtB;
             for (int r = 0; r < 11; r++) {  // 2^11 hops > C / 4 attempts
-                for (int q = t; q < C; q += TB) if (reach[q]) { const int j = cur[q]; if (j < C) reach[j] = 1; }
+                for (int q = t; q < C; q += DRAW_TB) if (reach[q]) { const int j = cur[q]; if (j < C) reach[j] = 1; }
                 __syncthreads();
-                for (int q = t; q < C; q += TB) { const int j = min((int)cur[q], C); oth[q] = j < C ? cur[j] : (unsigned short)C; }
+                for (int q = t; q < C; q += DRAW_TB) { const int j = min((int)cur[q], C); oth[q] = j < C ? cur[j] : (unsigned short)C; }
                 __syncthreads();
                 unsigned short* tmp = cur; cur = oth; oth = tmp;
             }
             // ranks of the visited / accepted attempts in stream order (each thread owns 16 consecutive positions)
             int lv = 0, la = 0;
-            const int q0 = t * (C / TB);
-            for (int q = q0; q < q0 + C / TB; q++) { const int rv = reach[q]; lv += rv; la += rv && (tab[q] & 0x80); }
+            const int q0 = t * (C / DRAW_TB);
+            for (int q = q0; q < q0 + C / DRAW_TB; q++) { const int rv = reach[q]; lv += rv; la += rv && (tab[q] & 0x80); }
             scan[t] = (lv << 16) | la;
             __syncthreads();
-            for (int o = 1; o < TB; o <<= 1) {
+            for (int o = 1; o < DRAW_TB; o <<= 1) {
                 const int add = t >= o ? scan[t - o] : 0;
                 __syncthreads();
                 scan[t] += add;
                 __syncthreads();
             }
-            const int incl = scan[t], total = scan[TB - 1];
+            const int incl = scan[t], total = scan[DRAW_TB - 1];
             const int total_v = total >> 16, total_a = total & 0xffff;
             int vr = (incl >> 16) - lv, ar = (incl & 0xffff) - la;  // exclusive ranks at q0
             const int need = k_hi - s_k, cut = min(total_a, need);
             if (t == 0) { s_firstvis = -1; s_lastaccvis = -1; s_endpos = -1; }
             __syncthreads();
-            for (int q = q0; q < q0 + C / TB; q++) {
+            for (int q = q0; q < q0 + C / DRAW_TB; q++) {
                 if (!reach[q]) continue;
                 const unsigned char e = tab[q];
                 if (e & 0x80) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(TB) void draw_kernel(const HomoCall* calls, RansacS
             if (!s_more) { st->draw_pos = pos; st->draw_k = k; st->draw_fail = fail; st->n_sub = k; }
         }
         __syncthreads();
-        for (int j = t; j < s_nacc; j += TB) {
+        for (int j = t; j < s_nacc; j += DRAW_TB) {
             const unsigned o = acc_o[j];
             if (o != 0xffff) *reinterpret_cast<int4*>(sidx + 4 * (s_kfirst + j)) = *reinterpret_cast<const int4*>(didx + 4 * o);
         }
@@ -412,19 +416,30 @@ struct CSlot {
     __device__ __forceinline__ double& v(int e) const { return base[(45 + e) * HYP_TPB]; }
 };
 
+#ifdef MIS_TAIL_PROF
+__device__ unsigned long long g_hyp_prof[8];    // rotations (all threads), threads, max rotations of a thread, shader cycles of lane 0's solve (summed over waves), waves
+#endif
 // core/src/lapack.cpp JacobiImpl_<double> for n = 9; the algorithm only ever touches the strict upper
 // triangle and the diagonal (kept in w), eigenvectors are the rows of v, eigenvalues sorted descending
 // One thread = one 9 x 9 problem (JacobiImpl_ of lapack.cpp, the arithmetic and the visiting order of the serial
-// loops).  Written for latency: the two index tables are nibble-packed in registers (a per-thread array with a
-// dynamic index would live in scratch), and every data-dependent loop is a fixed-count loop with a predicate, so the
-// (conflict-free, slot-strided) LDS loads of a step go out back to back.
+// loops).  The kernel is bound by the latency of a rotation (126 doubles of LDS per problem: two waves per compute unit), so a
+// rotation makes ONE LDS round trip:
+//  * the two index tables are nibble-packed in registers and the candidates' signed VALUES (A[i][indR[i]], A[indC[i]][i]) are
+//    register arrays with static indices (every loop over i is unrolled): the pivot search reads no memory;
+//  * all operands of the rotation (W[k], W[l], the 7 element pairs of A, the 9 pairs of V) are read as soon as k, l are known,
+//    before the arithmetic chain of c and s, at addresses that only depend on k, l (an index that does not exist, i = k or
+//    i = l, reads the pivot element and writes a zero there);
+//  * the four re-scans (indR[k], indC[k], indR[l], indC[l]) run over the rotated values in registers -- they ARE the new rows and
+//    columns k, l -- and the candidates of the other rows / columns follow the rotation by selects.
+// Round 2's form read its 16 candidates, then p and W, then the pairs, then the four scans: five dependent LDS round trips and
+// 32 more loads per rotation.
 __device__ void jacobi9_compact(const CSlot s) {
     constexpr int n = 9;
     const double eps = DBL_EPSILON;
     unsigned long long IR = 0, IC = 0;   // indR[k] / indC[k] in bits 4k .. 4k+3
     auto get = [](unsigned long long t, int k) { return (int)((t >> (4 * k)) & 15ull); };
     auto set = [](unsigned long long& t, int k, int v) { t = (t & ~(15ull << (4 * k))) | ((unsigned long long)v << (4 * k)); };
-    // max |u(idx, i)| over i in (idx, n): first maximum, as the serial scan
+    // set-up only: max |u(idx, i)| over i in (idx, n) / max |u(i, idx)| over i in [0, idx): first maximum, as the serial scan
     auto row_arg = [&](int idx) {
         double vals[n];
 #pragma unroll
@@ -436,7 +451,6 @@ __device__ void jacobi9_compact(const CSlot s) {
             if (i > idx && mv < vals[i]) mv = vals[i], m = i;
         return m;
     };
-    // max |u(i, idx)| over i in [0, idx)
     auto col_arg = [&](int idx) {
         double vals[n];
 #pragma unroll
@@ -450,58 +464,112 @@ __device__ void jacobi9_compact(const CSlot s) {
     };
 #pragma unroll
     for (int i = 0; i < n * n; i++) s.v(i) = (i / n == i % n) ? 1. : 0.;
+    double rv[n], cv[n];      // signed candidate values: rv[i] = u(i, indR[i]) (i < n - 1), cv[i] = u(indC[i], i) (i >= 1)
 #pragma unroll
     for (int k = 0; k < n; k++) {
-        if (k < n - 1) set(IR, k, row_arg(k));
-        if (k > 0) set(IC, k, col_arg(k));
+        rv[k] = 0; cv[k] = 0;
+        if (k < n - 1) { const int m = row_arg(k); set(IR, k, m); rv[k] = s.u(k, m); }
+        if (k > 0) { const int m = col_arg(k); set(IC, k, m); cv[k] = s.u(m, k); }
     }
-    for (int iters = 0; iters < n * n * 30; iters++) {
+    // element (r, c), r < c, of the strict upper triangle sits at slot index T(r) + c with T(r) = r (17 - r) / 2 - r - 1
+    auto T = [](int r) { return (r * (17 - r)) / 2 - r - 1; };
+#ifdef MIS_TAIL_PROF
+    const unsigned long long hp0 = __builtin_readcyclecounter();
+#endif
+    int iters = 0;
+    for (; iters < n * n * 30; iters++) {
         // pivot: first maximum over the row candidates 0 .. n-2, then the column candidates 1 .. n-1
-        int ir[n], ic[n];
-        double rv[n], cvv[n];
+        int k = 0, l = get(IR, 0);
+        double p = rv[0], mv = fabs(rv[0]);
 #pragma unroll
-        for (int i = 0; i < n - 1; i++) { ir[i] = get(IR, i); rv[i] = fabs(s.u(i, ir[i])); }
+        for (int i = 1; i < n - 1; i++) {
+            const double a = fabs(rv[i]);
+            const bool up = mv < a;
+            mv = up ? a : mv; p = up ? rv[i] : p; k = up ? i : k; l = up ? get(IR, i) : l;
+        }
 #pragma unroll
-        for (int i = 1; i < n; i++) { ic[i] = get(IC, i); cvv[i] = fabs(s.u(ic[i], i)); }
-        int k = 0, l = ir[0];
-        double mv = rv[0];
-#pragma unroll
-        for (int i = 1; i < n - 1; i++)
-            if (mv < rv[i]) mv = rv[i], k = i, l = ir[i];
-#pragma unroll
-        for (int i = 1; i < n; i++)
-            if (mv < cvv[i]) mv = cvv[i], k = ic[i], l = i;
-        const double p = s.u(k, l);
+        for (int i = 1; i < n; i++) {
+            const double a = fabs(cv[i]);
+            const bool up = mv < a;
+            mv = up ? a : mv; p = up ? cv[i] : p; k = up ? get(IC, i) : k; l = up ? i : l;
+        }
         if (fabs(p) <= eps) break;
-        const double y = (s.w(l) - s.w(k)) * 0.5;
+        // every operand of the rotation, at addresses that depend on k and l only
+        const int Tk = T(k), Tl = T(l), kl = Tk + l;
+        double* Xp[n]; double* Yp[n];
+        double a0[n], b0[n], va[n], vb[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const int ox = i == k ? kl : (i < k ? T(i) + k : Tk + i);
+            const int oy = i == l ? kl : (i < l ? T(i) + l : Tl + i);
+            Xp[i] = s.base + ox * HYP_TPB; Yp[i] = s.base + oy * HYP_TPB;
+        }
+        const double wk = s.w(k), wl = s.w(l);
+#pragma unroll
+        for (int i = 0; i < n; i++) { a0[i] = *Xp[i]; b0[i] = *Yp[i]; }
+#pragma unroll
+        for (int i = 0; i < n; i++) { va[i] = s.v(n * k + i); vb[i] = s.v(n * l + i); }
+        const double y = (wl - wk) * 0.5;
         double t, sn, c;
-        if (__all(jd_mid(__double2hiint(p)) && jd_mid(__double2hiint(y)))) jacobi_rotation<true>(p, y, &c, &sn, &t);     // uniform branch
+        if (__all(jd_mid(__double2hiint(p)) & jd_mid(__double2hiint(y)))) jacobi_rotation<true>(p, y, &c, &sn, &t);     // uniform branch
         else jacobi_rotation<false>(p, y, &c, &sn, &t);
-        s.u(k, l) = 0;
-        s.w(k) -= t; s.w(l) += t;
-        // rotate rows / columns k and l: element pairs (min(i,k), max(i,k)) and (min(i,l), max(i,l)) for every i != k, l
+        s.w(k) = wk - t; s.w(l) = wl + t;
+        double xa[n], ya[n];
 #pragma unroll
         for (int i = 0; i < n; i++) {
-            if (i == k || i == l) continue;
-            double& X = i < k ? s.u(i, k) : s.u(k, i);
-            double& Y = i < l ? s.u(i, l) : s.u(l, i);
-            const double a0 = X, b0 = Y;
-            X = a0 * c - b0 * sn;
-            Y = a0 * sn + b0 * c;
+            const bool pair = (i != k) & (i != l);
+            xa[i] = a0[i] * c - b0[i] * sn;
+            ya[i] = a0[i] * sn + b0[i] * c;
+            *Xp[i] = pair ? xa[i] : 0.;       // i = k, l: the pivot element
+            *Yp[i] = pair ? ya[i] : 0.;
         }
 #pragma unroll
         for (int i = 0; i < n; i++) {
-            double& X = s.v(n * k + i);
-            double& Y = s.v(n * l + i);
-            const double a0 = X, b0 = Y;
-            X = a0 * c - b0 * sn;
-            Y = a0 * sn + b0 * c;
+            s.v(n * k + i) = va[i] * c - vb[i] * sn;
+            s.v(n * l + i) = va[i] * sn + vb[i] * c;
         }
-        if (k < n - 1) set(IR, k, row_arg(k));
-        if (k > 0) set(IC, k, col_arg(k));
-        if (l < n - 1) set(IR, l, row_arg(l));
-        if (l > 0) set(IC, l, col_arg(l));
+        // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const bool pair = (i != k) & (i != l);
+            const int iri = get(IR, i), ici = get(IC, i);
+            rv[i] = (pair & (i < k) & (iri == k)) ? xa[i] : rv[i];
+            rv[i] = (pair & (i < l) & (iri == l)) ? ya[i] : rv[i];
+            cv[i] = (pair & (i > k) & (ici == k)) ? xa[i] : cv[i];
+            cv[i] = (pair & (i > l) & (ici == l)) ? ya[i] : cv[i];
+        }
+        // indR[k], indC[k], indR[l], indC[l]: first maxima over the rotated rows / columns (element i of row / column k is xa[i],
+        // of row / column l ya[i]; the pivot element is zero)
+        int rk = k + 1, ck = 0, rl = l + 1, cl = 0;
+        double rkv = 0, ckv = 0, rlv = 0, clv = 0, m0 = -1., m1 = -1., m2 = -1., m3 = -1.;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double ek = i == l ? 0. : xa[i], el = i == k ? 0. : ya[i];
+            const double aek = fabs(ek), ael = fabs(el);
+            const bool u0 = (i > k) & (m0 < aek), u1 = (i < k) & (m1 < aek), u2 = (i > l) & (m2 < ael), u3 = (i < l) & (m3 < ael);
+            m0 = u0 ? aek : m0; rk = u0 ? i : rk; rkv = u0 ? ek : rkv;
+            m1 = u1 ? aek : m1; ck = u1 ? i : ck; ckv = u1 ? ek : ckv;
+            m2 = u2 ? ael : m2; rl = u2 ? i : rl; rlv = u2 ? el : rlv;
+            m3 = u3 ? ael : m3; cl = u3 ? i : cl; clv = u3 ? el : clv;
+        }
+        if (k < n - 1) set(IR, k, rk);
+        if (k > 0) set(IC, k, ck);
+        if (l < n - 1) set(IR, l, rl);
+        if (l > 0) set(IC, l, cl);
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            rv[i] = ((i == k) & (k < n - 1)) ? rkv : (((i == l) & (l < n - 1)) ? rlv : rv[i]);
+            cv[i] = ((i == k) & (k > 0)) ? ckv : ((i == l) ? clv : cv[i]);
+        }
     }
+#ifdef MIS_TAIL_PROF
+    {
+        atomicAdd(&g_hyp_prof[0], (unsigned long long)iters); atomicAdd(&g_hyp_prof[1], 1ull); atomicMax(&g_hyp_prof[2], (unsigned long long)iters);
+        int wmax = 0;
+        for (unsigned long long mm = __ballot(1); mm; mm &= mm - 1) wmax = max(wmax, __builtin_amdgcn_readlane(iters, __builtin_ctzll(mm)));
+        if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) { atomicAdd(&g_hyp_prof[3], __builtin_readcyclecounter() - hp0); atomicAdd(&g_hyp_prof[4], 1ull); atomicAdd(&g_hyp_prof[5], (unsigned long long)wmax); }
+    }
+#endif
     // sort the eigenvalues (and vectors) in descending order: selection sort of the serial code
     for (int k = 0; k < n - 1; k++) {
         int m = k;
@@ -1290,6 +1358,12 @@ extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[12] = {0}; z[8] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
     return 0;
 }
+extern "C" int mis_debug_hyp_prof(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hyp_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_hyp_prof), z, sizeof(z)); }
+    return 0;
+}
 extern "C" int mis_debug_jac_prof(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jac_prof), sizeof(unsigned long long) * 8);
@@ -1337,7 +1411,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     const int p0 = std::min(PHASE0, max_iters);
     if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
-        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
+        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
         hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
@@ -1353,7 +1427,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
                            max_iters, confidence, thr, b->fin, part, want);
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
-        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
+        hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,

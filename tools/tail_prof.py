@@ -15,7 +15,14 @@ out = (C.c_ulonglong * 12)()
 jp = (C.c_ulonglong * 8)()
 ctx.lib.mis_debug_tail_prof(out, 1)
 ctx.lib.mis_debug_jac_prof(jp, 1)
+hp = (C.c_ulonglong * 8)()
+ctx.lib.mis_debug_hyp_prof(hp, 1)
 step()
+ctx.lib.mis_debug_hyp_prof(hp, 1)
+h = list(hp)
+if h[1]:
+    print("hyp_kernel: %d 4-point solves, %.1f rotations each (max %d); per wave: %.1f rotations (its slowest lane), %.0f cycles = %.0f cycles per rotation"
+          % (h[1], h[0] / h[1], h[2], h[5] / max(h[4], 1), h[3] / max(h[4], 1), h[3] / max(h[5], 1)))
 ctx.lib.mis_debug_tail_prof(out, 1)
 ctx.lib.mis_debug_jac_prof(jp, 1)
 v = list(out)
