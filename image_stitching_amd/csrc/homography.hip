@@ -166,6 +166,9 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
 #ifndef MIS_CHAIN_PRIO
 #define MIS_CHAIN_PRIO 3
 #endif
+#ifndef MIS_HYP_QUAD
+#define MIS_HYP_QUAD 1          // the 4-point solves on four lanes each (hyp_quad_kernel); 0: one thread each (hyp_kernel)
+#endif
 // ---------------------------------------------------------------- draw_kernel ------------------
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
@@ -659,6 +662,252 @@ __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, con
     }
     valid[(size_t)b * max_iters + k] = ok;
     (void)good; (void)thr;     // the inlier counts are hyp_count_kernel's
+}
+
+// ---------------------------------------------------------------- hyp_quad_kernel --------------
+// The same 4-point solves with FOUR lanes per hypothesis (a DPP quad).  One thread per solve (hyp_kernel above) runs ~1300
+// instructions per rotation on a wave that is alone on its SIMD (126 doubles of LDS per solve allow two waves per compute
+// unit): 9500 cycles per rotation, 140 rotations, 0.6 ms per launch whatever its size, and three such launches sit on the
+// matcher's critical path.  Here lane q of a quad owns the indices i = q, q + 4, q + 8 (< 9): its element pairs of A, its
+// columns of V, the candidates of rows / columns i (index + |value| in registers).  A rotation is: quad arg-max of the
+// candidates (two DPP steps), ONE LDS round trip for p, W[k], W[l] and the lane's <= 3 + 3 pairs, the arithmetic chain (every
+// lane computes c, s, t), the lane's share of the rotation, four quad arg-max re-scans over the rotated values in registers.
+// A wave holds 16 solves and a workgroup 64 (66 KB of LDS: the same 128 solves per compute unit, on eight waves instead of
+// two).  Arithmetic per element and visiting order of every scan are those of the serial loops.
+constexpr int HQ_HYPS = 64;           // solves per workgroup (4 lanes each)
+constexpr int HQ_STRIDE = 65;         // doubles between consecutive elements of a solve (solve h at + h): the quad's lanes, same h, different elements, fall in different banks
+constexpr int HQ_ELEMS = 127;         // 36 (strict upper triangle) + 9 (W) + 81 (V) + 1 (a dummy element: the target of the pairs that do not exist)
+struct QSlot {
+    double* base;
+    __device__ __forceinline__ double& e(int idx) const { return base[idx * HQ_STRIDE]; }
+};
+__device__ __forceinline__ int hq_T(int r) { return ((r * (17 - r)) >> 1) - r - 1; }       // element (r, c), r < c, at T(r) + c
+constexpr int HQ_W = 36, HQ_V = 45, HQ_DUMMY = 126;
+
+struct QCand { double a; int pk; };     // |value| (or -1: none) and a packed payload whose upper bits order ties (smaller first)
+template <int CTRL>
+__device__ __forceinline__ QCand hq_step(const QCand& c) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(c.a), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(c.a), CTRL, 0xf, 0xf, false);
+    const int pk = __builtin_amdgcn_update_dpp(0, c.pk, CTRL, 0xf, 0xf, false);
+    const double oa = __hiloint2double(hi, lo);
+    const bool take = (c.a < oa) | ((c.a == oa) & (pk < c.pk));
+    QCand r;
+    r.a = take ? oa : c.a; r.pk = take ? pk : c.pk;
+    return r;
+}
+__device__ __forceinline__ QCand hq_quad_best(QCand c) {       // all four lanes end with the quad's first maximum
+    c = hq_step<0xB1>(c);      // quad_perm [1,0,3,2]
+    c = hq_step<0x4E>(c);      // quad_perm [2,3,0,1]
+    return c;
+}
+
+__device__ void jacobi9_quad(const QSlot s, const int q) {
+    constexpr int n = 9;
+    const double eps = DBL_EPSILON;
+    int ii[3];
+    bool own[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { ii[j] = q + 4 * j; own[j] = ii[j] < n; }
+    for (int e = q; e < n * n; e += 4) s.e(HQ_V + e) = (e % (n + 1) == 0) ? 1. : 0.;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // candidates of the owned rows / columns: index and |value|
+    int ir[3], ic[3];
+    double arv[3], acv[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int i = ii[j];
+        ir[j] = 0; ic[j] = 0; arv[j] = -1.; acv[j] = -1.;
+        if (own[j] && i < n - 1) {
+            int m = i + 1;
+            double mv = fabs(s.e(hq_T(i) + m));
+            for (int c = i + 2; c < n; c++) { const double v = fabs(s.e(hq_T(i) + c)); if (mv < v) mv = v, m = c; }
+            ir[j] = m; arv[j] = mv;
+        }
+        if (own[j] && i > 0) {
+            int m = 0;
+            double mv = fabs(s.e(hq_T(0) + i));
+            for (int r = 1; r < i; r++) { const double v = fabs(s.e(hq_T(r) + i)); if (mv < v) mv = v, m = r; }
+            ic[j] = m; acv[j] = mv;
+        }
+    }
+    for (int iters = 0; iters < n * n * 30; iters++) {
+        // pivot: first maximum over the row candidates 0 .. n-2, then the column candidates 1 .. n-1 (order in bits 8.., k, l below)
+        QCand best; best.a = -1.; best.pk = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = ii[j];
+            const bool ok = own[j] & (i < n - 1);
+            const bool up = ok & (best.a < arv[j]);
+            best.a = up ? arv[j] : best.a; best.pk = up ? ((i << 8) | (i << 4) | ir[j]) : best.pk;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = ii[j];
+            const bool ok = own[j] & (i > 0);
+            const bool up = ok & (best.a < acv[j]);
+            best.a = up ? acv[j] : best.a; best.pk = up ? (((n - 1 + i) << 8) | (ic[j] << 4) | i) : best.pk;
+        }
+        best = hq_quad_best(best);
+        const int k = (best.pk >> 4) & 15, l = best.pk & 15;
+        if (!(best.a > eps)) break;          // |p| <= eps (uniform over the quad)
+        // every operand of the rotation, at addresses that depend on k and l only
+        const int Tk = hq_T(k), Tl = hq_T(l);
+        double* Xp[3]; double* Yp[3]; double* VXp[3]; double* VYp[3];
+        bool pair[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = ii[j];
+            pair[j] = own[j] & (i != k) & (i != l);
+            const int ox = i < k ? hq_T(i) + k : Tk + i, oy = i < l ? hq_T(i) + l : Tl + i;
+            Xp[j] = &s.e(pair[j] ? ox : HQ_DUMMY); Yp[j] = &s.e(pair[j] ? oy : HQ_DUMMY);
+            VXp[j] = &s.e(own[j] ? HQ_V + n * k + i : HQ_DUMMY); VYp[j] = &s.e(own[j] ? HQ_V + n * l + i : HQ_DUMMY);
+        }
+        double* Pp = &s.e(Tk + l);
+        const double p = *Pp, wk = s.e(HQ_W + k), wl = s.e(HQ_W + l);
+        double a0[3], b0[3], va[3], vb[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { a0[j] = *Xp[j]; b0[j] = *Yp[j]; va[j] = *VXp[j]; vb[j] = *VYp[j]; }
+        const double y = (wl - wk) * 0.5;
+        double t, sn, c;
+        if (__all(jd_mid(__double2hiint(p)) & jd_mid(__double2hiint(y)))) jacobi_rotation<true>(p, y, &c, &sn, &t);     // uniform branch
+        else jacobi_rotation<false>(p, y, &c, &sn, &t);
+        *Pp = 0;
+        s.e(HQ_W + k) = wk - t; s.e(HQ_W + l) = wl + t;      // the four lanes write the same values
+        double xa[3], ya[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            xa[j] = a0[j] * c - b0[j] * sn;
+            ya[j] = a0[j] * sn + b0[j] * c;
+            *Xp[j] = xa[j]; *Yp[j] = ya[j];
+            *VXp[j] = va[j] * c - vb[j] * sn;
+            *VYp[j] = va[j] * sn + vb[j] * c;
+        }
+        // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
+        QCand rk, ck, rl, cl;       // the four re-scans (first maxima; payload: scan position << 4 | position, so the smaller position wins ties)
+        rk.a = ck.a = rl.a = cl.a = -1.; rk.pk = ck.pk = rl.pk = cl.pk = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = ii[j];
+            const double ax = fabs(xa[j]), ay = fabs(ya[j]);
+            arv[j] = (pair[j] & (i < k) & (ir[j] == k)) ? ax : arv[j];
+            arv[j] = (pair[j] & (i < l) & (ir[j] == l)) ? ay : arv[j];
+            acv[j] = (pair[j] & (i > k) & (ic[j] == k)) ? ax : acv[j];
+            acv[j] = (pair[j] & (i > l) & (ic[j] == l)) ? ay : acv[j];
+            // element i of row / column k is xa (zero at i = l: the pivot), of row / column l ya (zero at i = k)
+            const double ek = i == l ? 0. : ax, el = i == k ? 0. : ay;
+            const bool vk = own[j] & (i != k), vl = own[j] & (i != l);
+            const bool u0 = vk & (i > k) & (rk.a < ek), u1 = vk & (i < k) & (ck.a < ek), u2 = vl & (i > l) & (rl.a < el), u3 = vl & (i < l) & (cl.a < el);
+            const int tag = (i << 4) | i;
+            rk.a = u0 ? ek : rk.a; rk.pk = u0 ? tag : rk.pk;
+            ck.a = u1 ? ek : ck.a; ck.pk = u1 ? tag : ck.pk;
+            rl.a = u2 ? el : rl.a; rl.pk = u2 ? tag : rl.pk;
+            cl.a = u3 ? el : cl.a; cl.pk = u3 ? tag : cl.pk;
+        }
+        rk = hq_quad_best(rk); ck = hq_quad_best(ck); rl = hq_quad_best(rl); cl = hq_quad_best(cl);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = ii[j];
+            const bool isk = own[j] & (i == k), isl = own[j] & (i == l);
+            ir[j] = isk ? (rk.pk & 15) : (isl ? (rl.pk & 15) : ir[j]);
+            arv[j] = isk ? rk.a : (isl ? rl.a : arv[j]);
+            ic[j] = isk ? (ck.pk & 15) : (isl ? (cl.pk & 15) : ic[j]);
+            acv[j] = isk ? ck.a : (isl ? cl.a : acv[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the next rotation's reads come after these writes (one wave: LDS executes in order)
+    }
+    // sort the eigenvalues (and vectors) in descending order: selection sort of the serial code, by all four lanes in lockstep
+    // (same reads, same writes)
+    for (int k = 0; k < n - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < n; i++) if (s.e(HQ_W + m) < s.e(HQ_W + i)) m = i;
+        if (k != m) {
+            double tw = s.e(HQ_W + m); s.e(HQ_W + m) = s.e(HQ_W + k); s.e(HQ_W + k) = tw;
+            for (int i = 0; i < n; i++) { double tv = s.e(HQ_V + n * m + i); s.e(HQ_V + n * m + i) = s.e(HQ_V + n * k + i); s.e(HQ_V + n * k + i) = tv; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// HomographyEstimatorCallback::runKernel on 4 correspondences by one quad (every lane computes the normalisation and L^T L)
+__device__ int dlt4_quad(const float* M, const float* m, const QSlot s, const int q, double* H) {
+    const int count = 4;
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; i++) { cmx += m[2 * i]; cmy += m[2 * i + 1]; cMx += M[2 * i]; cMy += M[2 * i + 1]; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; i++) {
+        smx += fabs(m[2 * i] - cmx); smy += fabs(m[2 * i + 1] - cmy);
+        sMx += fabs(M[2 * i] - cMx); sMy += fabs(M[2 * i + 1] - cMy);
+    }
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;      // uniform over the quad
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double LtL[45];  // upper triangle incl. diagonal, row-major; static indices only -> registers
+#pragma unroll
+    for (int e = 0; e < 45; e++) LtL[e] = 0;
+#pragma unroll
+    for (int i = 0; i < count; i++) {
+        const double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+        const double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++, e++) LtL[e] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    {
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++, e++) {
+                if ((e & 3) != q) continue;            // a quarter of the stores per lane
+                if (k == j) s.e(HQ_W + j) = LtL[e];
+                else s.e(hq_T(j) + k) = LtL[e];
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    jacobi9_quad(s, q);
+    double H0[9];
+    for (int i = 0; i < 9; i++) H0[i] = s.e(HQ_V + 72 + i);
+    const double nrm[8] = {cmx, cmy, cMx, cMy, smx, smy, sMx, sMy};
+    dlt_denormalise(H0, nrm, H);
+    return 1;
+}
+
+__global__ __launch_bounds__(4 * HQ_HYPS) void hyp_quad_kernel(const HomoCall* calls, const RansacState* states, const int* sub_idx, double* Hc, int* valid, int lo,
+                                                               int max_iters) {
+#if MIS_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);
+#endif
+    extern __shared__ double sl[];
+    const int b = blockIdx.y, t = threadIdx.x, h = t >> 2, q = t & 3;
+    const RansacState st = states[b];
+    if (st.mode != 2 || st.done) return;
+    const int limit = min(st.n_sub, st.niters);  // hypotheses at or beyond niters can never be replayed
+    const int k = lo + blockIdx.x * HQ_HYPS + h;
+    if (k >= limit) return;                      // whole quads leave together
+    const HomoCall c = calls[b];
+    const int* id = sub_idx + ((size_t)b * max_iters + k) * 4;
+    float ms1[8], ms2[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int qq = id[i];
+        ms1[2 * i] = c.src[2 * qq]; ms1[2 * i + 1] = c.src[2 * qq + 1];
+        ms2[2 * i] = c.dst[2 * qq]; ms2[2 * i + 1] = c.dst[2 * qq + 1];
+    }
+    double H[9];
+    const QSlot s{sl + h};
+    const int ok = dlt4_quad(ms1, ms2, s, q, H);
+    if (q == 0) {
+        if (ok) {
+            double* o = Hc + ((size_t)b * max_iters + k) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = H[i];
+        }
+        valid[(size_t)b * max_iters + k] = ok;
+    }
 }
 
 // findInliers of every hypothesis of hyp_kernel: one wave per hypothesis, lanes over the points (the per-thread loop over all
@@ -1223,22 +1472,48 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
         return;
     }
     // ---- replay of RANSACPointSetRegistrator::run over hypotheses [lo, hi) ----
-    if (t == 0) {
-        int iter = st->iter, niters = st->niters, max_good = st->max_good, best_k = st->best_k;
-        const int nsub = st->n_sub;
-        int k = lo;
-        for (; k < hi && k < nsub && iter < niters; k++) {
-            iter++;
-            if (!valid[(size_t)b * max_iters + k]) continue;
-            int g = good[(size_t)b * max_iters + k];
-            if (g > (max_good > 3 ? max_good : 3)) {
-                best_k = k; max_good = g;
-                niters = ransac_update_num_iters(confidence, (double)(n - g) / n, niters);
-            }
+    // The loop only changes state at a hypothesis that beats every earlier one (a new maximum of `good`), so the workgroup stages
+    // good[] (-1 for a degenerate sample) in LDS with the maximum of every run of `seg` entries beside it, and the replaying thread
+    // steps over the runs that hold no new maximum.  A serial walk over global memory paid a load latency per hypothesis: 0.43 ms
+    // for the 1872 hypotheses of phase 1, on the matcher's critical path.
+    {
+        // (niters never grows: nothing at or beyond the current limit is visited -- or has been computed)
+        const int nsub = st->n_sub, kmax = min(hi, nsub), cnt = max(min(kmax - lo, st->niters - st->iter), 0);
+        int* gl = reinterpret_cast<int*>(S.chunk);            // cnt entries (<= 4096), then the run maxima at + 4096
+        int* segmax = gl + 4096;
+        const bool staged = cnt <= 4096;
+        const int seg = (cnt + TB - 1) / TB > 0 ? (cnt + TB - 1) / TB : 1;
+        if (staged) {
+            for (int i = t; i < cnt; i += TB) gl[i] = valid[(size_t)b * max_iters + lo + i] ? good[(size_t)b * max_iters + lo + i] : -1;
+            __syncthreads();
+            int mx = -1;
+            for (int i = t * seg; i < min((t + 1) * seg, cnt); i++) mx = max(mx, gl[i]);
+            segmax[t] = mx;
+            __syncthreads();
         }
-        st->iter = iter; st->niters = niters; st->max_good = max_good; st->best_k = best_k;
-        // the loop ends when iter reaches niters, when getSubset failed (subsets exhausted) or at maxIters
-        if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
+        if (t == 0) {
+            int iter = st->iter, niters = st->niters, max_good = st->max_good, best_k = st->best_k;
+            int k = lo;
+            while (k < kmax && iter < niters) {
+                const int off = k - lo;
+                if (staged && off % seg == 0 && segmax[off / seg] <= (max_good > 3 ? max_good : 3)) {
+                    // nothing in this run changes the state: the loop walks to its end, or to the iteration limit
+                    const int adv = min(min(seg, kmax - k), niters - iter);
+                    k += adv; iter += adv;
+                    continue;
+                }
+                iter++;
+                const int g = staged ? gl[off] : (valid[(size_t)b * max_iters + k] ? good[(size_t)b * max_iters + k] : -1);
+                if (g >= 0 && g > (max_good > 3 ? max_good : 3)) {
+                    best_k = k; max_good = g;
+                    niters = ransac_update_num_iters(confidence, (double)(n - g) / n, niters);
+                }
+                k++;
+            }
+            st->iter = iter; st->niters = niters; st->max_good = max_good; st->best_k = best_k;
+            // the loop ends when iter reaches niters, when getSubset failed (subsets exhausted) or at maxIters
+            if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
+        }
     }
     __syncthreads();
     if (!s_done_now) return;
@@ -1402,9 +1677,10 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     const float thr = (float)(thresh * thresh);
     hipStream_t st = stream ? stream : ctx->stream;
     static bool attr_set[64] = {false};
-    const size_t hyp_lds = sizeof(double) * SLOT_DOUBLES * HYP_TPB;
+    const size_t hyp_lds = sizeof(double) * SLOT_DOUBLES * HYP_TPB, hq_lds = sizeof(double) * HQ_ELEMS * HQ_STRIDE;
     if (!attr_set[ctx->device & 63]) {
         MIS_HIP(ctx, hipFuncSetAttribute((const void*)hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
+        MIS_HIP(ctx, hipFuncSetAttribute((const void*)hyp_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hq_lds));
         attr_set[ctx->device & 63] = true;
     }
     RansacState* states = (RansacState*)b->state;
@@ -1412,7 +1688,8 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
-        hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
+        if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, 0, max_iters);
+        else hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
@@ -1428,7 +1705,8 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
-        hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
+        if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((max_iters - p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, p0, max_iters);
+        else hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);
