@@ -27,7 +27,10 @@ namespace {
 
 constexpr int HYP_TPB = 128;      // hypotheses (threads) per workgroup of hyp_kernel
 constexpr int SLOT_DOUBLES = 126; // 36 (strict upper triangle) + 9 (diagonal / eigenvalues) + 81 (eigenvectors)
-constexpr int PHASE0 = 128;       // hypotheses evaluated before the first replay (a single phase over all 2000 was measured: 26 ms instead of 15 ms per step)
+#ifndef MIS_PHASE0
+#define MIS_PHASE0 128
+#endif
+constexpr int PHASE0 = MIS_PHASE0;       // hypotheses evaluated before the first replay (a single phase over all 2000 was measured: 26 ms instead of 15 ms per step)
 constexpr int RNG_TABLE = 1 << 17;
 constexpr int TB = 256;           // threads of draw / scan_tail workgroups
 
@@ -967,20 +970,21 @@ struct TailShared {
     int indR[9], indC[9];
     int np, go;
     double chunk[TB * 10];  // per-point terms of the current 256-point chunk of a sequential sum
-    float4 pts[TAIL_PCAP];  // the tail's point set {d.x, d.y, s.x, s.y}, staged once: every pass of the DLT and of the LM refinement reads it
+    float4* pts;            // the tail's point set {d.x, d.y, s.x, s.y}, staged once in the launch's dynamic LDS: every pass of the DLT and of the LM refinement reads it
+    int pcap;               // points that fit (0 in the launches that only replay or mask: 23 KB workgroups find a compute unit beside the composition's kernels, 55 KB ones wait)
 };
 // The DLT (two passes for the normalisation, one for L^T L) and every normal-equations pass of the LM refinement (1 + up to 20)
 // walk the same inlier set 256 points at a time; from global memory each chunk starts with an exposed memory latency (1 - 3 us
-// beside the composition's kernels: a third of a 21 us pass over 586 points).  Points past TAIL_PCAP are read from memory.
+// beside the composition's kernels: a third of a 21 us pass over 586 points).  Points past S.pcap are read from memory.
 __device__ __forceinline__ void tail_stage_points(TailShared& S, const float* s1, const float* d1, int np) {
-    for (int i = threadIdx.x; i < min(np, TAIL_PCAP); i += TB) {
+    for (int i = threadIdx.x; i < min(np, S.pcap); i += TB) {
         const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
         S.pts[i] = make_float4(dd.x, dd.y, ss.x, ss.y);
     }
     __syncthreads();
 }
 __device__ __forceinline__ float4 tail_point(const TailShared& S, const float* s1, const float* d1, int i) {
-    if (i < TAIL_PCAP) return S.pts[i];
+    if (i < S.pcap) return S.pts[i];
     const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
     return make_float4(dd.x, dd.y, ss.x, ss.y);
 }
@@ -1202,7 +1206,7 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
             for (int base = 0; base < np; base += TB) {
                 const int i = base + t, cnt = min(TB, np - base);
                 const float* src = reinterpret_cast<const float*>(S.pts + base);      // the staged set itself while it lasts
-                if (base + TB > TAIL_PCAP) {
+                if (base + TB > S.pcap) {
                     if (i < np) reinterpret_cast<float4*>(stage)[t] = tail_point(S, s1, d1, i);
                     __syncthreads();
                     src = stage;
@@ -1211,7 +1215,7 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
                     if (pass == 0) for (int q = 0; q < cnt; q++) acc += src[4 * q + t];
                     else for (int q = 0; q < cnt; q++) acc += fabs(src[4 * q + t] - c);
                 }
-                if (base + TB > TAIL_PCAP) __syncthreads();
+                if (base + TB > S.pcap) __syncthreads();
             }
             if (t < 4) { if (pass == 0) S.nrm[t] = acc / np; else S.nrm[4 + t] = acc; }      // cmx cmy cMx cMy, then smx smy sMx sMy
             __syncthreads();
@@ -1425,7 +1429,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
 // another stream while phase 1 of the others -- which only needs the replay's verdict -- goes on.
 __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
-                                                       double confidence, float thr, int* fin, int part, int want) {
+                                                       double confidence, float thr, int* fin, int part, int want, int pcap) {
 #if MIS_CHAIN_PRIO
     __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
 #endif
@@ -1434,7 +1438,10 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     if (part == 4 && want == 0 && threadIdx.x == 0) atomicMin(&g_tail_prof[8], wg_in);
 #endif
     __shared__ TailShared S;
+    extern __shared__ float4 tail_dyn[];
     __shared__ int s_done_now;
+    if (threadIdx.x == 0) { S.pts = tail_dyn; S.pcap = pcap; }
+    __syncthreads();
     __shared__ int wcnt[TB / 64];
     __shared__ int s_base;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -1477,6 +1484,9 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
     // steps over the runs that hold no new maximum.  A serial walk over global memory paid a load latency per hypothesis: 0.43 ms
     // for the 1872 hypotheses of phase 1, on the matcher's critical path.
     {
+#ifdef MIS_TAIL_PROF
+        const unsigned long long rp0 = wall_clock64();
+#endif
         // (niters never grows: nothing at or beyond the current limit is visited -- or has been computed)
         const int nsub = st->n_sub, kmax = min(hi, nsub), cnt = max(min(kmax - lo, st->niters - st->iter), 0);
         int* gl = reinterpret_cast<int*>(S.chunk);            // cnt entries (<= 4096), then the run maxima at + 4096
@@ -1513,6 +1523,9 @@ __global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, Ra
             st->iter = iter; st->niters = niters; st->max_good = max_good; st->best_k = best_k;
             // the loop ends when iter reaches niters, when getSubset failed (subsets exhausted) or at maxIters
             if (iter >= niters || (k >= nsub && st->draw_fail) || hi >= max_iters) { s_done_now = 1; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
+#ifdef MIS_TAIL_PROF
+            if (lo > 0) { const unsigned long long d = wall_clock64() - rp0; atomicAdd(&g_hyp_prof[6], d); atomicMax(&g_hyp_prof[7], d); }
+#endif
         }
     }
     __syncthreads();
@@ -1685,6 +1698,9 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     RansacState* states = (RansacState*)b->state;
     const int p0 = std::min(PHASE0, max_iters);
+    // the launches that run a DLT / LM refinement (parts 0, 2, 4) stage the point set in dynamic LDS; replay-only and mask-only ones do not
+    auto tail_cap = [](int part) { return (part == 1 || part == 3) ? 0 : TAIL_PCAP; };
+    auto tail_lds = [&](int part) { return sizeof(float4) * (size_t)tail_cap(part); };
     if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
@@ -1692,16 +1708,16 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         else hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
-        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 3 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0, tail_cap(phases == 3 ? 1 : 0));
     }
     if (phases == 4)   // the tails a phases == 3 run left pending (fin == 0)
-        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, 2, 0);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(2), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin, 2, 0, tail_cap(2));
     if (phases >= 10) {   // 10 + 2 w: mask + compaction, 11 + 2 w: DLT + LM, of the problems a replay-only run left pending with fin == w
         const int want = (phases - 10) >> 1, part = 3 + ((phases - 10) & 1);
-        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, part, want);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(part), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
+                           max_iters, confidence, thr, b->fin, part, want, tail_cap(part));
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
@@ -1710,8 +1726,8 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);
-        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), 0, st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
-                           max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 6 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
+                           max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0, tail_cap(phases == 6 ? 1 : 0));
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

@@ -618,6 +618,7 @@ struct MatchWorkspace : MisWorkspace {
     hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr, ev_phase1 = nullptr, ev_third_done = nullptr, ev_matches = nullptr;
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
+    hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
     hipEvent_t ev_lists = nullptr;                       // the early download of the match lists has landed
     void (*enqueued_cb)(void*) = nullptr;                // mis_match_on_enqueued: one-shot hook of the next call
@@ -772,6 +773,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // device with the matcher (the job's speculative composition) can queue behind this event: mis_match_knn_fence
     if (!ws->ev_knn) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_knn, hipEventDisableTiming));
     MIS_HIP(ctx, hipEventRecord(ws->ev_knn, st));
+    ws->ev_gate = ws->ev_knn;
     hipLaunchKernelGGL(ratio_union_kernel, dim3(np), dim3(1024), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, (const int*)d_idx,
                        (const float*)d_dist, 1.f - p->match_conf, d_matches, d_src, d_dst, d_nm);
     hipLaunchKernelGGL(first_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, st, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const float*)d_src,
@@ -785,12 +787,17 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     bool early_lists = false;
     // everything between the forks to the auxiliary streams and their joins runs inside one scope: an error in there must not
     // leave those streams with work pending (they are the context's, shared with the feature finders) or a copy in flight
+    // MIS_COMPOSE_GATE: 0 = a stream fenced by mis_match_knn_fence (the job's speculative composition) starts behind the 2-NN pass,
+    // 1 = behind the first RANSAC phase of the first estimation (draw, 4-point solves, replay, masks: 0.7 ms of large workgroups
+    // that wait for room once the composition's grids fill the device)
+    static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 1;
     auto enqueue_chains = [&]() -> int {
     static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 3;   // 2: the two-chain flow below
     if (chains != 3) {
     // first estimation, phase 0 up to the replay's verdict (pairs with a clear overlap finish here)
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
+    if (compose_gate == 1) ws->ev_gate = ws->ev_phase0;
     // side stream: the tails of those pairs (mask, DLT on the inliers, LM: ~2 ms of latency) and their inlier-only estimation ...
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 4, ws->side)) != MIS_OK) return rc;
@@ -828,6 +835,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 10, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
+    if (compose_gate == 1) ws->ev_gate = ws->ev_phase0;
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out, 0);
@@ -1013,7 +1021,7 @@ extern "C" int mis_match_knn_fence(MisContext* ctx, void* stream, long long targ
         if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return MIS_FENCE_TIMEOUT;   // not an error: `stream` was not queued behind anything
         std::this_thread::yield();
     }
-    if (stream && ws->ev_knn && hipStreamWaitEvent((hipStream_t)stream, ws->ev_knn, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");
+    if (stream && ws->ev_gate && hipStreamWaitEvent((hipStream_t)stream, ws->ev_gate, 0) != hipSuccess) return mis_set_error(ctx, MIS_E_HIP, "hipStreamWaitEvent failed");
     return MIS_OK;
 }
 

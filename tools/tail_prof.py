@@ -20,6 +20,7 @@ ctx.lib.mis_debug_hyp_prof(hp, 1)
 step()
 ctx.lib.mis_debug_hyp_prof(hp, 1)
 h = list(hp)
+print("phase-1 replays: %.1f us in total, longest %.1f us" % (h[6] * 0.01, h[7] * 0.01))
 if h[1]:
     print("hyp_kernel: %d 4-point solves, %.1f rotations each (max %d); per wave: %.1f rotations (its slowest lane), %.0f cycles = %.0f cycles per rotation"
           % (h[1], h[0] / h[1], h[2], h[5] / max(h[4], 1), h[3] / max(h[4], 1), h[3] / max(h[5], 1)))
