@@ -234,9 +234,12 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) { 
 // (+1 halo) are computed from LDS, and the survivors go to a per-level list (x | y << 16, score) and a
 // per-level histogram: the score map never exists in HBM.
 constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80, HIST_COPIES = 8;
+#ifdef MIS_ORB_STATS
+__device__ unsigned long long g_orb_stats[8];   // pixels tested, opposite-pair test passes, pre-test passes, corners (score > 0), survivors
+#endif
 __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc, size_t ws) {
-    __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 8) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75
-    __shared__ uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
+    __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 10) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75 (+ two rows that are read by the last wave's column window and never used)
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
     __shared__ int lh[256];
     __shared__ int lcount;
     __shared__ uint32_t lxy[512];  // at most 2048 / 4 strict local maxima per tile
@@ -266,38 +269,97 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
     }
     __syncthreads();
     const int SP = FT_COLS + 4;
-    // cheap pre-test of every pixel; the few that pass are queued so the expensive arc evaluation runs
-    // on dense wavefronts instead of diverging inside the scan
-    for (int i = t; i < (FT_ROWS + 2) * (FT_COLS + 2); i += 256) {
-        const int r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);
-        const int x = x0 - 1 + c, y = y0 - 1 + r;
-        sc[r * SP + c] = 0;
-        const bool pass = x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3 && fast_pretest(g + (r + 3) * FG_PITCH + (c + 3), FG_PITCH, L.fast_t);
-        // wave-aggregated append: one LDS atomic per wave instead of one per pixel on a single address
-        const unsigned long long m = __ballot(pass);
+    // Stage A, every pixel of the scored region (34 rows x 66 columns): a 9-arc of the 16-pixel circle holds one of the positions
+    // {0, 8} (three rows below / above) and one of {4, 12} (three columns right / left), so a corner needs
+    // max(|p0 - v|, |p8 - v|) > t and max(|p4 - v|, |p12 - v|) > t.  4 % of the bench frames' pyramid pixels pass (2.7 % pass round 2's
+    // pre-test of adjacent compass pixels + diagonals, 1.4 % are corners: tools/orb_stats.py), so this is where the kernel's time goes:
+    // a wave owns 9 scored rows, a lane one column -- its 15 gray values are read once and slide through registers (the vertical
+    // taps), the horizontal taps are two byte reads, the test is 4 v_sad + 2 max + 2 compares; the passes of the 9 rows are
+    // appended to the queue with ONE LDS atomic per wave.  The full arc evaluation then runs on the queue in dense wavefronts.
+    for (int i = t; i < (FT_ROWS + 2) * SP / 4; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;       // the wave index in a scalar register: row conditions are scalar
+        const unsigned ft = (unsigned)L.fast_t;
+        const int r0 = 9 * wv;                                   // first scored row of the wave (g row of scored row r: r + 3)
+        bool pass[10];
+        unsigned long long ball[10];
+        int total = 0;
+        {
+            const uint8_t* colp = g + r0 * FG_PITCH + (lane + 3);      // g rows r0 .. r0 + 14 (the last wave reads two rows past the staged 40: g has 42)
+            unsigned col[15];
+#pragma unroll
+            for (int j = 0; j < 15; j++) col[j] = colp[j * FG_PITCH];
+            const int x = x0 - 1 + lane;
+            const bool xin = x >= 3 && x < d.w - 3;
+            const uint8_t* rowp = g + (r0 + 3) * FG_PITCH + lane;      // columns c + 3 - 3 and c + 3 + 3 of scored row r0
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int r = r0 + k, y = y0 - 1 + r;
+                const bool rowok = r < FT_ROWS + 2 && y >= 3 && y < d.h - 3;      // uniform
+                const unsigned v = col[k + 3];
+                // |a - v| of bytes held in dwords: v_sad_u8 (the three upper byte lanes are zero)
+                const unsigned dv = max(__builtin_amdgcn_sad_u8(col[k + 6], v, 0u), __builtin_amdgcn_sad_u8(col[k], v, 0u));
+                const unsigned dh = max(__builtin_amdgcn_sad_u8(rowp[k * FG_PITCH + 6], v, 0u), __builtin_amdgcn_sad_u8(rowp[k * FG_PITCH], v, 0u));
+                pass[k] = rowok & xin & (min(dv, dh) > ft);
+                ball[k] = __ballot(pass[k]);
+                total += __popcll(ball[k]);
+            }
+        }
+        {
+            // the two halo columns (scored columns 64, 65): lane = 2 k + side
+            const int k = lane >> 1, cc = FT_COLS + (lane & 1), r = r0 + k, y = y0 - 1 + r, x = x0 - 1 + cc;
+            bool ps = false;
+            if (lane < 18 && r < FT_ROWS + 2) {
+                const uint8_t* pp = g + (r + 3) * FG_PITCH + (cc + 3);
+                const unsigned v = pp[0];
+                const unsigned dv = max(__builtin_amdgcn_sad_u8(pp[3 * FG_PITCH], v, 0u), __builtin_amdgcn_sad_u8(pp[-3 * FG_PITCH], v, 0u));
+                const unsigned dh = max(__builtin_amdgcn_sad_u8(pp[3], v, 0u), __builtin_amdgcn_sad_u8(pp[-3], v, 0u));
+                ps = x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3 && min(dv, dh) > ft;
+            }
+            pass[9] = ps;
+            ball[9] = __ballot(ps);
+            total += __popcll(ball[9]);
+        }
         int base = 0;
-        if ((t & 63) == 0 && m) base = atomicAdd(&qcount, __popcll(m));
-        base = __shfl(base, 0);
-        if (pass) queue[base + __popcll(m & ((1ull << (t & 63)) - 1ull))] = (unsigned short)i;
+        if (lane == 0 && total) base = atomicAdd(&qcount, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            if (pass[k]) {
+                const int r = k < 9 ? r0 + k : r0 + (lane >> 1), c = k < 9 ? lane : FT_COLS + (lane & 1);
+                queue[base + __popcll(ball[k] & below)] = (unsigned short)(r * (FT_COLS + 2) + c);
+            }
+            base += __popcll(ball[k]);
+        }
     }
     __syncthreads();
     for (int q = t; q < qcount; q += 256) {
         const int i = queue[q], r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);
         const int fsv = fast_score_full(g + (r + 3) * FG_PITCH + (c + 3), FG_PITCH, L.fast_t);
         sc[r * SP + c] = (uint8_t)fsv;
+#ifdef MIS_ORB_STATS
+        if (fsv) atomicAdd(&g_orb_stats[3], 1ull);
+#endif
     }
     __syncthreads();
     {
-        // every lane takes part in every ballot: survivors are appended with one LDS atomic per wave
-        const int c = t & 63, x = x0 + c;
-        const bool xok = x >= 3 && x < d.w - 3 && x >= L.edge && x < d.w - L.edge;
-#pragma unroll
-        for (int k = 0; k < FT_ROWS / 4; k++) {
-            const int r = (t >> 6) * (FT_ROWS / 4) + k, y = y0 + r;
-            const uint8_t* s = sc + (r + 1) * SP + (c + 1);
-            const int v = s[0];
-            const bool keep = xok && v && y >= 3 && y < d.h - 3 && y >= L.edge && y < d.h - L.edge &&  // runByImageBorder(edgeThreshold)
-                              v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] && v > s[SP - 1] && v > s[SP] && v > s[SP + 1];
+        // 3 x 3 strict non-max suppression of the corners, from the queue (1.4 % of the pixels have a score at all: a raster pass
+        // over the tile read 9 scores per pixel for nothing).  Every lane takes part in every ballot: survivors are appended with
+        // one LDS atomic per wave.
+        const int nq = qcount;
+        for (int q0 = 0; q0 < nq; q0 += 256) {
+            const int q = q0 + t;
+            bool keep = false;
+            int x = 0, y = 0, v = 0;
+            if (q < nq) {
+                const int i = queue[q], r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);     // scored row / column: the tile's pixels are 1 .. 32 / 1 .. 64
+                const uint8_t* s_ = sc + r * SP + c;
+                v = s_[0];
+                x = x0 - 1 + c; y = y0 - 1 + r;
+                keep = v && r >= 1 && r <= FT_ROWS && c >= 1 && c <= FT_COLS && x >= L.edge && x < d.w - L.edge && y >= L.edge && y < d.h - L.edge &&   // runByImageBorder(edgeThreshold)
+                       v > s_[-1] && v > s_[1] && v > s_[-SP - 1] && v > s_[-SP] && v > s_[-SP + 1] && v > s_[SP - 1] && v > s_[SP] && v > s_[SP + 1];
+            }
             const unsigned long long m = __ballot(keep);
             int base = 0;
             if ((t & 63) == 0 && m) base = atomicAdd(&lcount, __popcll(m));
@@ -1244,3 +1306,12 @@ extern "C" int mis_orb_debug_level(MisOrb* o, int level, int which, uint8_t* hos
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MIS_OK;
 }
+
+#ifdef MIS_ORB_STATS
+extern "C" int mis_debug_orb_stats(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_orb_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_orb_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
