@@ -208,6 +208,142 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma_kernel(const FeatDev* f
     }
 }
 
+// Round 3: the same pass paced by the matrix pipe.  The first form issued a tile's 16 MFMAs back to back (into AGPRs), then
+// ~200 vector instructions (16 accumulator seeds per query set with the tail-tile test folded in, 32 v_accvgpr_read, 64 min /
+// med3): 1075 cycles per wave and tile against 512 of matrix work.  Here
+//  * the accumulators are VGPRs (inline-asm MFMAs with "v" operands) and ping-pong between tiles: the 64 key updates of tile
+//    t - 1 are spread over the 16 MFMA slots of tile t, four or five vector instructions per slot (an MFMA holds the SIMD's vector
+//    issue for 8 of its 32 cycles: up to six ride along for free);
+//  * the seeds are ONE set of 16 registers for both query sets (C operand of each chain's first MFMA), advanced by 32 per tile;
+//  * only the pass's last tile can hold rows past the train set: its keys are masked in the epilogue (trainIdx = key & 8191);
+//  * a tile's A fragments are re-read from LDS (next tile's image) right behind the two MFMAs that used them.
+// Hazards the assembler does not see inside inline assembly: a vector instruction reads an accumulator at least three MFMA
+// slots (96 cycles) after the chain's last MFMA was issued (16 passes = 64 cycles); the seeds are advanced from slot 4 on
+// (the chains' first MFMAs, which read them as srcC, are slots 0 and 1).
+#define HM_MFMA_FIRST(D, A, B, C) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C))
+#define HM_MFMA_ACC(D, A, B) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B))
+struct HmKeys { int k0[2], k1[2]; };
+// One workgroup of the pass: 256 queries of a directed pair against all trains.  The table is ordered so that workgroup L runs on
+// XCD L mod 8 (the dispatcher deals workgroups round-robin over the eight XCDs) and every XCD only ever sees the TRAIN sets of
+// the frames t with t mod 8 = its number: two frames of a 16-frame job, 2 MB of expanded descriptors, resident in its 4 MB L2
+// (with the (query block, pair) grid every XCD walked all 16 MB and every tile was a miss to the fabric: the tile loads' latency,
+// not the matrix pipe, paced the loop).
+struct HmJob { int pair, dir, q0, pad; };
+__device__ __forceinline__ void hm_update(HmKeys& K, int set, int key) {
+    // k0 <= k1 always: the new second best is the median of (k0, k1, key), the new best the minimum
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(K.k1[set]) : "v"(K.k0[set]), "v"(K.k1[set]), "v"(key));
+    K.k0[set] = min(K.k0[set], key);
+}
+template <bool UPD>
+__device__ __forceinline__ void hm_tile(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16i& cb, v4i* a, const v4i (&bq)[2][8], HmKeys& K,
+                                        const int8_t* lds_next, int8_t* lds_store, const int8_t* gnext, int r, int h, int prow, int pcol) {
+    const v4i* gp = reinterpret_cast<const v4i*>(gnext);
+    const v4i pre0 = gp[0], pre1 = gp[1];          // tile t + 2 (two 16-byte pieces per thread), stored into LDS at the end of this tile
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int slot = 2 * s8 + half;
+            if (half == 0) { if (s8 == 0) HM_MFMA_FIRST(accA, a[0], bq[0][0], cb); else HM_MFMA_ACC(accA, a[s8], bq[0][s8]); }
+            else {
+                if (s8 == 0) HM_MFMA_FIRST(accB, a[0], bq[1][0], cb); else HM_MFMA_ACC(accB, a[s8], bq[1][s8]);
+                a[s8] = *reinterpret_cast<const v4i*>(lds_next + r * HM_PITCH + 32 * s8 + 16 * h);      // the next tile's fragment
+            }
+            if (slot >= 2) {
+                if (UPD) {
+                    // keys 0 .. 15: set 0 (prevA), 16 .. 31: set 1 (prevB); 32 keys over slots 2 .. 15
+                    const int lo = (slot - 2) * 32 / 14, hi = (slot - 1) * 32 / 14;
+#pragma unroll
+                    for (int i = lo; i < hi; i++) hm_update(K, i >> 4, i < 16 ? prevA[i] : prevB[i - 16]);
+                }
+                if (slot >= 4) {
+                    const int lo = (slot - 4) * 16 / 12, hi = (slot - 3) * 16 / 12;
+#pragma unroll
+                    for (int g = lo; g < hi; g++) cb[g] += 32;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    v4i* l = reinterpret_cast<v4i*>(lds_store + prow * HM_PITCH + pcol);
+    l[0] = pre0; l[1] = pre1;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
+                                                                 float* dist2, const HmJob* jobs) {
+    __shared__ __attribute__((aligned(16))) int8_t tr[2][32 * HM_PITCH];
+    const HmJob job = jobs[blockIdx.x];
+    if (job.pair < 0) return;                       // padding of the XCD interleave
+    const PairDesc pd = pairs[job.pair];
+    const bool fwd = job.dir == 0;
+    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
+    const int nq = feats[qi].n, nt = feats[ti].n;
+    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
+    const int q0 = job.q0;
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int8_t* qx = xp + fr[qi].query_off;
+    const int8_t* tx = xp + fr[ti].train_off;
+    HmKeys K;
+    K.k0[0] = K.k0[1] = K.k1[0] = K.k1[1] = HM_NONE;
+    const int ntiles = (nt + 31) / 32;
+    if (ntiles > 0) {
+        // the wave's 2 x 32 queries as B fragments (step s, lane (r, h): bytes 32 s + 16 h .. + 15 of query r), in registers for the whole pass
+        v4i bq[2][8];
+#pragma unroll
+        for (int set = 0; set < 2; set++)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++)
+                bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
+        v16i cb;
+#pragma unroll
+        for (int g = 0; g < 16; g++) cb[g] = (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        // a tile = 32 expanded trains = 8 KB: two 16-byte pieces per thread; tile t lives in tr[t & 1]
+        const int prow = threadIdx.x >> 3, pcol = (threadIdx.x & 7) * 32;
+        auto gtile = [&](int t) { return tx + (size_t)(min(t, ntiles - 1) * 32 + prow) * 256 + pcol; };      // (the blocks are padded: any tile of the set is readable)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const v4i* g = reinterpret_cast<const v4i*>(gtile(t));
+            v4i* l = reinterpret_cast<v4i*>(&tr[t][prow * HM_PITCH + pcol]);
+            l[0] = g[0]; l[1] = g[1];
+        }
+        __syncthreads();
+        v4i a[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][r * HM_PITCH + 32 * s8 + 16 * h]);
+        v16i A0, B0, A1, B1;
+        hm_tile<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], tr[0], gtile(2), r, h, prow, pcol);
+        int t = 1;
+        for (; t + 1 < ntiles; t += 2) {
+            hm_tile<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], tr[1], gtile(t + 2), r, h, prow, pcol);
+            hm_tile<true>(A0, B0, A1, B1, cb, a, bq, K, tr[1], tr[0], gtile(t + 3), r, h, prow, pcol);
+        }
+        const bool odd_last = t < ntiles;
+        if (odd_last) hm_tile<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], tr[1], gtile(t + 2), r, h, prow, pcol);
+        // the last tile's keys, masked against the train count (its chains' last MFMAs are two slots old at most)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int ka = odd_last ? A1[g] : A0[g], kb = odd_last ? B1[g] : B0[g];      // (selected by value: a reference picked at run time would put the accumulators in memory)
+            hm_update(K, 0, (ka & (HM_MAX_TRAINS - 1)) < nt ? ka : HM_NONE);
+            hm_update(K, 1, (kb & (HM_MAX_TRAINS - 1)) < nt ? kb : HM_NONE);
+        }
+    }
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+        // the other half of the trains sits in lane (r, 1 - h)
+        const int o0 = __shfl_xor(K.k0[set], 32), o1 = __shfl_xor(K.k1[set], 32);
+        const int b0 = min(K.k0[set], o0), b1 = min(max(K.k0[set], o0), min(K.k1[set], o1));
+        const int q = q0 + wave * 64 + set * 32 + r;
+        if (h == 0 && q < nq) {
+            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
+            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
+            dist2[(off + q) * 2] = (float)(v0 ? b0 >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? b1 >> 13 : 1 << 30);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K8: exact 2-NN, L2 on MFMA ----
 // SIFT descriptors are integer valued (0..255, stored as f32): they are exact in fp16, every dot
 // product of two 128-D descriptors is an integer < 2^24 and therefore exact in the f32 accumulator of
@@ -696,6 +832,23 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if (np == 0) return MIS_OK;
     int maxq = 0;
     for (int i = 0; i < n; i++) maxq = std::max(maxq, feats[i].n);
+    // workgroup table of the Hamming pass on the matrix cores (HmJob): eight lists by train frame mod 8, interleaved
+    std::vector<HmJob> hm_jobs;
+    if (!use_l2 && maxq <= HM_MAX_TRAINS) {
+        std::vector<HmJob> lists[8];
+        for (int t = 0; t < n; t++)
+            for (int k = 0; k < np; k++) {
+                const int dir = pairs[k].j == t ? 0 : (pairs[k].i == t ? 1 : -1);      // direction 0: queries of i against the trains of j
+                if (dir < 0) continue;
+                const int nqf = feats[dir == 0 ? pairs[k].i : pairs[k].j].n;
+                for (int q0 = 0; q0 < nqf; q0 += 256) lists[t & 7].push_back(HmJob{k, dir, q0, 0});
+            }
+        size_t longest = 0;
+        for (auto& l : lists) longest = std::max(longest, l.size());
+        hm_jobs.assign(longest * 8, HmJob{-1, 0, 0, 0});
+        for (int c = 0; c < 8; c++)
+            for (size_t sl = 0; sl < lists[c].size(); sl++) hm_jobs[sl * 8 + c] = lists[c][sl];
+    }
     MatchWorkspace* ws = workspace(ctx);
     hipStream_t st = ctx->stream;
     MIS_HIP(ctx, hipStreamSynchronize(st));  // the arenas may still be read by a previous call's copies
@@ -716,7 +869,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // pinned host mirror of everything that comes back
     Carver hc;
     const size_t h_in = hc.take(sizeof(FeatDev) * n + sizeof(PairDesc) * np + sizeof(HmFrame) * n + 1024), h_nm = hc.take(sizeof(int) * np), h_out = hc.take(sizeof(PairOut) * np),
-                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total), h_bad = hc.take(256);
+                 h_r1 = hc.take(sizeof(HomoResult) * np), h_r2 = hc.take(sizeof(HomoResult) * np), h_r3 = hc.take(sizeof(HomoResult) * np), h_fin = hc.take(sizeof(int) * np), h_m = hc.take(sizeof(MisDMatch) * m_total), h_mask = hc.take(m_total), h_bad = hc.take(256), h_jobs = hc.take(sizeof(HmJob) * std::max<size_t>(hm_jobs.size(), 1));
     MIS_HIP(ctx, ws->pinned.reserve(hc.off));
     uint8_t* Hh = (uint8_t*)ws->pinned.p;
     memcpy(Hh + h_in, fd.data(), sizeof(FeatDev) * n);
@@ -734,7 +887,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         // every frame's descriptors once as int8 (train form and query form), then all directed pairs in one MFMA launch
         std::vector<HmFrame> hf(n);
         Carver lc;
-        const size_t o_fr = lc.take(sizeof(HmFrame) * n);
+        const size_t o_fr = lc.take(sizeof(HmFrame) * n), o_jobs = lc.take(sizeof(HmJob) * std::max<size_t>(hm_jobs.size(), 1));
         for (int i = 0; i < n; i++) {
             const size_t rows = (size_t)(std::max(feats[i].n, 1) + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
             hf[i].train_off = lc.take(rows * 256); hf[i].query_off = lc.take(rows * 256);
@@ -746,8 +899,16 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         MIS_HIP(ctx, hipMemcpyAsync(L + o_fr, h_fr, sizeof(HmFrame) * n, hipMemcpyHostToDevice, st));
         const int maxpad = (maxq + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
         hipLaunchKernelGGL(hamming_expand_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
-        hipLaunchKernelGGL(knn2_hamming_mfma_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
-                           (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist);
+        static const bool hm_v1 = getenv("MIS_KNN_MFMA_V1") != nullptr;     // diagnostics: round 2's form of the pass
+        if (hm_v1 || hm_jobs.empty()) {
+            hipLaunchKernelGGL(knn2_hamming_mfma_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+                               (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist);
+        } else {
+            memcpy(Hh + h_jobs, hm_jobs.data(), sizeof(HmJob) * hm_jobs.size());
+            MIS_HIP(ctx, hipMemcpyAsync(L + o_jobs, Hh + h_jobs, sizeof(HmJob) * hm_jobs.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+                               (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist, (const HmJob*)(L + o_jobs));
+        }
     } else {
         // fp16 copies + squared norms of every image once, then one MFMA distance pass per directed pair
         std::vector<size_t> hoff(n), noff(n);

@@ -1,7 +1,9 @@
 #!/bin/bash
-# PMC pass over the Hamming 2-NN kernel inside the config-3 job: bash tools/pmc_knn.sh
+# issue / matrix-pipe / LDS / L2 counters of the Hamming 2-NN pass (run on the GPU box): bash tools/pmc_knn.sh
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/pmc_knn
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pmc_knn -- python3 $R/tools/step_times.py 3 > $R/gpurun_out/pmc_knn.log 2>&1
-cd $R && python3 tools/pmc_summary.py -k=knn2_hamming gpurun_out/pmc_knn
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmck_mix -- python3 $R/tools/match_time.py > $R/gpurun_out/pmck_mix.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM --output-format csv -d $R/gpurun_out/pmck_pipe -- python3 $R/tools/match_time.py > $R/gpurun_out/pmck_pipe.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/pmck_l2 -- python3 $R/tools/match_time.py > $R/gpurun_out/pmck_l2.log 2>&1
+cd $R
+python3 tools/pmc_summary.py -k=knn2_hamming gpurun_out/pmck_mix gpurun_out/pmck_pipe gpurun_out/pmck_l2
