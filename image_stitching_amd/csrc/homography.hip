@@ -1427,7 +1427,10 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
 // part 1: replay only -- a problem that ends here is marked tail_pending; part 2: the tail of the pending problems whose
 // fin equals `want`.  The split lets the tails of the problems that end in RANSAC phase 0 (latency bound, ~2 ms) run on
 // another stream while phase 1 of the others -- which only needs the replay's verdict -- goes on.
-__global__ __launch_bounds__(TB) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
+#ifndef MIS_TAIL_WAVES
+#define MIS_TAIL_WAVES 3      // <= 168 registers: a 200-register workgroup waits longer for room beside the composition's grids (6.65 vs 6.9 ms per step; 4 waves = 128 registers spill into the Jacobi loop)
+#endif
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MIS_TAIL_WAVES, 8))) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
                                                        double confidence, float thr, int* fin, int part, int want, int pcap) {
 #if MIS_CHAIN_PRIO

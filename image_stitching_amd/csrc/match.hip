@@ -229,10 +229,17 @@ struct HmKeys { int k0[2], k1[2]; };
 // (with the (query block, pair) grid every XCD walked all 16 MB and every tile was a miss to the fabric: the tile loads' latency,
 // not the matrix pipe, paced the loop).
 struct HmJob { int pair, dir, q0, pad; };
+// The keys carry HM_FBIAS = the bits of 1.0f: bit patterns of positive normal floats order like the integers they are, and
+// v_min_f32 / v_med3_f32 issue at the full vector rate where v_min_i32 / v_med3_i32 take two issue slots (tools/valu_rate.hip) --
+// 64 of them per tile and wave were 512 of the 700 vector-issue cycles against 512 cycles of matrix work (rocprofv3: the
+// matrix pipe 59 % busy, the waves stalled on issue).  The selections return one of their operands bit for bit.
+constexpr int HM_FBIAS = 0x3F800000;
 __device__ __forceinline__ void hm_update(HmKeys& K, int set, int key) {
     // k0 <= k1 always: the new second best is the median of (k0, k1, key), the new best the minimum
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(K.k1[set]) : "v"(K.k0[set]), "v"(K.k1[set]), "v"(key));
-    K.k0[set] = min(K.k0[set], key);
+    // (volatile: the statements keep their place between the MFMAs -- the scheduler otherwise issues a slot pair's two MFMAs back
+    // to back, the second waits 24 cycles for the pipe, and the vector work follows while the pipe idles: 92 cycles per pair for 64)
+    asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(K.k1[set]) : "v"(K.k0[set]), "v"(K.k1[set]), "v"(key));
+    asm volatile("v_min_f32 %0, %1, %2" : "=v"(K.k0[set]) : "v"(K.k0[set]), "v"(key));
 }
 template <bool UPD>
 __device__ __forceinline__ void hm_tile(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16i& cb, v4i* a, const v4i (&bq)[2][8], HmKeys& K,
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* 
                 bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
         v16i cb;
 #pragma unroll
-        for (int g = 0; g < 16; g++) cb[g] = (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        for (int g = 0; g < 16; g++) cb[g] = HM_FBIAS + (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
         // a tile = 32 expanded trains = 8 KB: two 16-byte pieces per thread; tile t lives in tr[t & 1]
         const int prow = threadIdx.x >> 3, pcol = (threadIdx.x & 7) * 32;
         auto gtile = [&](int t) { return tx + (size_t)(min(t, ntiles - 1) * 32 + prow) * 256 + pcol; };      // (the blocks are padded: any tile of the set is readable)
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* 
         if (h == 0 && q < nq) {
             const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
             idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
-            dist2[(off + q) * 2] = (float)(v0 ? b0 >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? b1 >> 13 : 1 << 30);
+            dist2[(off + q) * 2] = (float)(v0 ? (b0 - HM_FBIAS) >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? (b1 - HM_FBIAS) >> 13 : 1 << 30);
         }
     }
 }
