@@ -31,7 +31,7 @@ struct LevelDesc {
     float scale;       // 1.2^l
     int nfeat;         // N_l
     int n2;            // retainBest #1 size (2 N_l with the Harris score)
-    int tiles_x, tiles_y, tile_off;  // FAST tile grid of the level and its first slot (512 survivors per tile)
+    int tiles_x, tiles_y, tile_off;  // FAST tile grid of the level and its first slot (FT_SLOTS survivors per tile)
     int cap1, cand_off;  // candidate capacity / offset
     int cap2, fin_off;   // final capacity / offset (per level segment before concatenation)
     int tab_off;       // offset of the resize coefficient tables (x then y) of this level
@@ -48,7 +48,7 @@ struct Work {  // device pointers of one MisOrb workspace
     int* hist;      // nlevels x 256
     int* thr;       // nlevels: FAST score cut
     int* tile_cnt;      // per tile: NMS survivors
-    uint32_t* surv_xy;  // per tile slot of 512: x | y << 16
+    uint32_t* surv_xy;  // per tile slot of FT_SLOTS: x | y << 16
     uint8_t* surv_sc;   // survivor FAST score
     int* cnt1;      // nlevels: candidates written by the compaction
     int* cnt2;      // nlevels: final keypoints per level
@@ -233,17 +233,25 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* p, int pp, int t) { 
 // The gray tile (+4 halo) is staged with coalesced dword loads issued up front, the scores of the tile
 // (+1 halo) are computed from LDS, and the survivors go to a per-level list (x | y << 16, score) and a
 // per-level histogram: the score map never exists in HBM.
-constexpr int FT_COLS = 64, FT_ROWS = 32, FG_PITCH = 80, HIST_COPIES = 8;
+#ifndef FN_ABL
+#define FN_ABL 0
+#endif
+#ifndef MIS_FT_ROWS
+#define MIS_FT_ROWS 64
+#endif
+constexpr int FT_COLS = 64, FT_ROWS = MIS_FT_ROWS, FG_PITCH = 96, FG_COL0 = 15, HIST_COPIES = 8;
+constexpr int FT_WR = (FT_ROWS + 2 + 3) / 4;          // scored rows per wave (the tile's rows + one above and below, over four waves)
+constexpr int FT_SLOTS = FT_COLS * FT_ROWS / 4;       // survivors a tile can hold: strict 3 x 3 maxima   // g: 96 columns from x0 - 16; scored column c (x = x0 - 1 + c) at g column c + FG_COL0
 #ifdef MIS_ORB_STATS
 __device__ unsigned long long g_orb_stats[8];   // pixels tested, opposite-pair test passes, pre-test passes, corners (score > 0), survivors
 #endif
 __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* pad, int* hist, int* tile_cnt, uint32_t* surv_xy, uint8_t* surv_sc, size_t ws) {
-    __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 10) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-4 .. x0+75 (+ two rows that are read by the last wave's column window and never used)
+    __shared__ __attribute__((aligned(16))) uint8_t g[(FT_ROWS + 10) * FG_PITCH];  // rows y0-4 .. y0+35, cols x0-16 .. x0+79 (+ two rows that are read by the last wave's column window and never used)
     __shared__ __attribute__((aligned(16))) uint8_t sc[(FT_ROWS + 2) * (FT_COLS + 4)];                          // rows y0-1 .. y0+32, cols x0-1 .. x0+64 (pitch 68)
     __shared__ int lh[256];
     __shared__ int lcount;
-    __shared__ uint32_t lxy[512];  // at most 2048 / 4 strict local maxima per tile
-    __shared__ uint8_t lsc[512];
+    __shared__ uint32_t lxy[FT_SLOTS];  // at most a quarter of the tile's pixels are strict local maxima
+    __shared__ uint8_t lsc[FT_SLOTS];
     __shared__ unsigned short queue[(FT_ROWS + 2) * (FT_COLS + 2)];  // pixels that pass the cheap pre-test
     __shared__ int qcount;
     const int fz = blockIdx.z / L.n, lz = blockIdx.z - fz * L.n;     // frame, level
@@ -254,46 +262,50 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
     lh[t] = 0;
     if (t == 0) { lcount = 0; qcount = 0; }
     {
-        // padded coordinates of the tile origin are dword aligned (x0 multiple of 64, border 32)
-        const int pw = d.w + 2 * ORB_BORDER, ph = d.h + 2 * ORB_BORDER;
+        // the gray tile: FT_ROWS + 8 rows x 96 bytes from column x0 - 16 -- six 16-byte pieces per row, one or two pieces per thread (x0 is a multiple of
+        // 64, the border 32, the pitch a multiple of 64: every piece is 16-byte aligned; dword loads from x0 - 4 were 3 - 4 per thread
+        // with their index arithmetic, and the staging alone took 23 of a frame's 58 us)
+        const int ph = d.h + 2 * ORB_BORDER;
         const uint8_t* src = pad + d.pad_off;
-        const int px0 = x0 - 4 + ORB_BORDER, py0 = y0 - 4 + ORB_BORDER;
-        for (int i = t; i < (FT_ROWS + 8) * (FG_PITCH / 4); i += 256) {
-            const int r = i / (FG_PITCH / 4), c = i - r * (FG_PITCH / 4);
+        const int px0 = x0 - 16 + ORB_BORDER, py0 = y0 - 4 + ORB_BORDER;
+        for (int i = t; i < (FT_ROWS + 8) * (FG_PITCH / 16); i += 256) {
+            const int r = i / (FG_PITCH / 16), c = i - r * (FG_PITCH / 16);
             const int py = min(py0 + r, ph - 1);
-            int px = px0 + 4 * c;
-            if (px + 3 >= d.pp) px = d.pp - 4;  // past the row: any in-buffer dword (those pixels are never scored)
-            (void)pw;
-            reinterpret_cast<unsigned*>(g)[i] = *reinterpret_cast<const unsigned*>(src + (size_t)py * d.pp + px);
+            int px = px0 + 16 * c;
+            if (px + 15 >= d.pp) px = d.pp - 16;  // past the row: any in-buffer piece (those pixels are never scored)
+            reinterpret_cast<uint4*>(g)[i] = *reinterpret_cast<const uint4*>(src + (size_t)py * d.pp + px);
         }
     }
     __syncthreads();
+#if FN_ABL == 1
+    if (lcount >= 0) return;      // ablation: stop behind the staging of the gray tile
+#endif
     const int SP = FT_COLS + 4;
     // Stage A, every pixel of the scored region (34 rows x 66 columns): a 9-arc of the 16-pixel circle holds one of the positions
     // {0, 8} (three rows below / above) and one of {4, 12} (three columns right / left), so a corner needs
     // max(|p0 - v|, |p8 - v|) > t and max(|p4 - v|, |p12 - v|) > t.  4 % of the bench frames' pyramid pixels pass (2.7 % pass round 2's
     // pre-test of adjacent compass pixels + diagonals, 1.4 % are corners: tools/orb_stats.py), so this is where the kernel's time goes:
-    // a wave owns 9 scored rows, a lane one column -- its 15 gray values are read once and slide through registers (the vertical
+    // a wave owns FT_WR scored rows, a lane one column -- its FT_WR + 6 gray values are read once and slide through registers (the vertical
     // taps), the horizontal taps are two byte reads, the test is 4 v_sad + 2 max + 2 compares; the passes of the 9 rows are
-    // appended to the queue with ONE LDS atomic per wave.  The full arc evaluation then runs on the queue in dense wavefronts.
+    // appended to the queue with ONE LDS atomic per wave (tiles of 64 rows: half the workgroups of 32-row tiles, whose staging latency -- load, LDS write, barrier -- was a third of the kernel).  The full arc evaluation then runs on the queue in dense wavefronts.
     for (int i = t; i < (FT_ROWS + 2) * SP / 4; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;
     {
         const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;       // the wave index in a scalar register: row conditions are scalar
         const unsigned ft = (unsigned)L.fast_t;
-        const int r0 = 9 * wv;                                   // first scored row of the wave (g row of scored row r: r + 3)
-        bool pass[10];
-        unsigned long long ball[10];
+        const int r0 = FT_WR * wv;                                   // first scored row of the wave (g row of scored row r: r + 3)
+        bool pass[FT_WR + 1];
+        unsigned long long ball[FT_WR + 1];
         int total = 0;
         {
-            const uint8_t* colp = g + r0 * FG_PITCH + (lane + 3);      // g rows r0 .. r0 + 14 (the last wave reads two rows past the staged 40: g has 42)
-            unsigned col[15];
+            const uint8_t* colp = g + r0 * FG_PITCH + (lane + FG_COL0);      // g rows r0 .. r0 + FT_WR + 5 (the last wave reads two rows past the staged ones: g has FT_ROWS + 10)
+            unsigned col[FT_WR + 6];
 #pragma unroll
-            for (int j = 0; j < 15; j++) col[j] = colp[j * FG_PITCH];
+            for (int j = 0; j < FT_WR + 6; j++) col[j] = colp[j * FG_PITCH];
             const int x = x0 - 1 + lane;
             const bool xin = x >= 3 && x < d.w - 3;
-            const uint8_t* rowp = g + (r0 + 3) * FG_PITCH + lane;      // columns c + 3 - 3 and c + 3 + 3 of scored row r0
+            const uint8_t* rowp = g + (r0 + 3) * FG_PITCH + (lane + FG_COL0 - 3);      // the columns three to the left (+ 0) and to the right (+ 6) of scored row r0
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
+            for (int k = 0; k < FT_WR; k++) {
                 const int r = r0 + k, y = y0 - 1 + r;
                 const bool rowok = r < FT_ROWS + 2 && y >= 3 && y < d.h - 3;      // uniform
                 const unsigned v = col[k + 3];
@@ -309,40 +321,46 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
             // the two halo columns (scored columns 64, 65): lane = 2 k + side
             const int k = lane >> 1, cc = FT_COLS + (lane & 1), r = r0 + k, y = y0 - 1 + r, x = x0 - 1 + cc;
             bool ps = false;
-            if (lane < 18 && r < FT_ROWS + 2) {
-                const uint8_t* pp = g + (r + 3) * FG_PITCH + (cc + 3);
+            if (lane < 2 * FT_WR && r < FT_ROWS + 2) {
+                const uint8_t* pp = g + (r + 3) * FG_PITCH + (cc + FG_COL0);
                 const unsigned v = pp[0];
                 const unsigned dv = max(__builtin_amdgcn_sad_u8(pp[3 * FG_PITCH], v, 0u), __builtin_amdgcn_sad_u8(pp[-3 * FG_PITCH], v, 0u));
                 const unsigned dh = max(__builtin_amdgcn_sad_u8(pp[3], v, 0u), __builtin_amdgcn_sad_u8(pp[-3], v, 0u));
                 ps = x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3 && min(dv, dh) > ft;
             }
-            pass[9] = ps;
-            ball[9] = __ballot(ps);
-            total += __popcll(ball[9]);
+            pass[FT_WR] = ps;
+            ball[FT_WR] = __ballot(ps);
+            total += __popcll(ball[FT_WR]);
         }
         int base = 0;
         if (lane == 0 && total) base = atomicAdd(&qcount, total);
         base = __builtin_amdgcn_readfirstlane(base);
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < FT_WR + 1; k++) {
             if (pass[k]) {
-                const int r = k < 9 ? r0 + k : r0 + (lane >> 1), c = k < 9 ? lane : FT_COLS + (lane & 1);
+                const int r = k < FT_WR ? r0 + k : r0 + (lane >> 1), c = k < FT_WR ? lane : FT_COLS + (lane & 1);
                 queue[base + __popcll(ball[k] & below)] = (unsigned short)(r * (FT_COLS + 2) + c);
             }
             base += __popcll(ball[k]);
         }
     }
     __syncthreads();
+#if FN_ABL == 2
+    if (qcount >= 0) return;      // ablation: stop behind stage A
+#endif
     for (int q = t; q < qcount; q += 256) {
         const int i = queue[q], r = i / (FT_COLS + 2), c = i - r * (FT_COLS + 2);
-        const int fsv = fast_score_full(g + (r + 3) * FG_PITCH + (c + 3), FG_PITCH, L.fast_t);
+        const int fsv = fast_score_full(g + (r + 3) * FG_PITCH + (c + FG_COL0), FG_PITCH, L.fast_t);
         sc[r * SP + c] = (uint8_t)fsv;
 #ifdef MIS_ORB_STATS
         if (fsv) atomicAdd(&g_orb_stats[3], 1ull);
 #endif
     }
     __syncthreads();
+#if FN_ABL == 3
+    if (qcount >= 0) return;      // ablation (tools): stop behind the arc evaluation
+#endif
     {
         // 3 x 3 strict non-max suppression of the corners, from the queue (1.4 % of the pixels have a score at all: a raster pass
         // over the tile read 9 scores per pixel for nothing).  Every lane takes part in every ballot: survivors are appended with
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(Levels L, const uint8_t* 
     if (n == 0) return;  // uniform
     for (int j = t; j < n; j += 256) {
         atomicAdd(&lh[lsc[j]], 1);  // histogram from the list: spread over bins
-        surv_xy[(size_t)tile * 512 + j] = lxy[j]; surv_sc[(size_t)tile * 512 + j] = lsc[j];
+        surv_xy[(size_t)tile * FT_SLOTS + j] = lxy[j]; surv_sc[(size_t)tile * FT_SLOTS + j] = lsc[j];
     }
     __syncthreads();
     // HIST_COPIES copies of a level's histogram, picked by the tile: the popular bins would otherwise take one atomic from
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(256) void compact_kernel(Levels L, const int* tile_
             const int tile = d.tile_off + til, n = tile_cnt[tile];
             for (int j0 = 0; j0 < n; j0 += 64) {
                 const int j = j0 + lane;
-                const int v = j < n ? surv_sc[(size_t)tile * 512 + j] : 0;
+                const int v = j < n ? surv_sc[(size_t)tile * FT_SLOTS + j] : 0;
                 cnt += __popcll(__ballot(v >= th && v > 0));
             }
         }
@@ -460,12 +478,12 @@ __global__ __launch_bounds__(256) void compact_kernel(Levels L, const int* tile_
         int run = s_base + s_off[slot];
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            const int v = j < n ? surv_sc[(size_t)tile * 512 + j] : 0;
+            const int v = j < n ? surv_sc[(size_t)tile * FT_SLOTS + j] : 0;
             const bool keep = v >= th && v > 0;
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int i = run + __popcll(m & ((1ull << lane) - 1ull));
-                if (i < d.cap1) { cand_xy[d.cand_off + i] = surv_xy[(size_t)tile * 512 + j]; cand_resp[d.cand_off + i] = (float)v; }
+                if (i < d.cap1) { cand_xy[d.cand_off + i] = surv_xy[(size_t)tile * FT_SLOTS + j]; cand_resp[d.cand_off + i] = (float)v; }
             }
             run += __popcll(m);
         }
@@ -478,8 +496,8 @@ __global__ void nms_raster_kernel(LevelDesc d, const int* tile_cnt, const uint32
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tile = d.tile_off + tl, n = tile_cnt[tile];
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            uint32_t xy = surv_xy[(size_t)tile * 512 + j];
-            nms[d.map_off + (size_t)(xy >> 16) * d.sp + (xy & 0xffff)] = surv_sc[(size_t)tile * 512 + j];
+            uint32_t xy = surv_xy[(size_t)tile * FT_SLOTS + j];
+            nms[d.map_off + (size_t)(xy >> 16) * d.sp + (xy & 0xffff)] = surv_sc[(size_t)tile * FT_SLOTS + j];
         }
     }
 }
@@ -1046,7 +1064,7 @@ int orb_alloc_workspace(MisOrb* o, int frames) {
     auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
     size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
     size_t o_hist = carve(sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
-    size_t o_sxy = carve(sizeof(uint32_t) * 512 * (size_t)o->surv_total), o_ssc = carve(512 * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
+    size_t o_sxy = carve(sizeof(uint32_t) * FT_SLOTS * (size_t)o->surv_total), o_ssc = carve(FT_SLOTS * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
     size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
     size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
     size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
