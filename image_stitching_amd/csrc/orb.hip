@@ -653,31 +653,61 @@ __global__ __launch_bounds__(1024) void select_rank_kernel(Levels L, const int* 
 // One wave per keypoint: concatenates the per-level segments, evaluates the intensity centroid on
 // the un-blurred level (ICAngles), writes the cv::KeyPoint (pt scaled to level-0 coordinates).
 __global__ __launch_bounds__(256) void assemble_angle_kernel(Levels L, const uint8_t* pad, const int* cnt2, const uint32_t* fin_xy,
-                                                             const float* fin_resp, const int* umax, OrbIO io, int cap_out, size_t ws) {
-    const int l = blockIdx.y, fr = blockIdx.z;
+                                                             const float* fin_resp, const int* umax, OrbIO io, int cap_out, size_t ws, int with_angle) {
+    // One wave per OUTPUT keypoint j (grid.x = ceil(cap_out / 4), grid.y = frame): its level is the one whose run of the output
+    // holds j.  A grid of (capacity per level / 4) x levels x frames was 65 k workgroups of which three quarters found nothing to
+    // do -- 0.18 ms of workgroup dispatch for 12 us of arithmetic.
+    const int fr = blockIdx.y;
     WS_OFF(pad, fr, ws); WS_OFF(cnt2, fr, ws); WS_OFF(fin_xy, fr, ws); WS_OFF(fin_resp, fr, ws);
     MisKeyPoint* kps = io.kps[fr];
     uint32_t* kp_lxy = io.lxy[fr];
     int* n_out = io.n_dev[fr];
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int base = 0, l = 0, total = 0;
+    {
+        int c[ORB_MAX_LEVELS];
+#pragma unroll
+        for (int k = 0; k < ORB_MAX_LEVELS; k++) c[k] = k < L.n ? cnt2[min(k, L.n - 1)] : 0;
+#pragma unroll
+        for (int k = 0; k < ORB_MAX_LEVELS; k++) {
+            if (j >= total + c[k]) { base = total + c[k]; l = k + 1; }      // (runs are consecutive: the last assignment is the level before j's)
+            total += c[k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = min(total, cap_out);
+    if (j >= total || j >= cap_out) return;
     const LevelDesc& d = L.d[l];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int base = 0;
-    for (int k = 0; k < l; k++) base += cnt2[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && l == L.n - 1) *n_out = min(base + cnt2[l], cap_out);
-    if (i >= cnt2[l] || base + i >= cap_out) return;
+    const int i = j - base;
     uint32_t xy = fin_xy[d.fin_off + i];
     int x = xy & 0xffff, y = xy >> 16;
     const int pp = d.pp, hp = L.half_patch;
     const uint8_t* ctr = pad + d.pad_off + (size_t)(y + ORB_BORDER) * pp + (x + ORB_BORDER);
     int m01 = 0, m10 = 0;
     const int u = lane - hp;  // lanes 0..2hp cover u = -hp..hp
-    if (lane <= 2 * hp) {
+    if (with_angle && lane <= 2 * hp) {      // (describe_direct_kernel computes the angle from the patch it stages anyway)
         m10 = u * ctr[u];
-        for (int v = 1; v <= hp; ++v) {
-            if (abs(u) <= umax[v]) {
-                int vp = ctr[u + v * pp], vm = ctr[u - v * pp];
-                m10 += u * (vp + vm);
-                m01 += v * (vp - vm);
+        if (hp <= 15) {
+            // every load of the patch goes out before the first use: the row limits umax[1 .. hp] and the 2 hp pixels of the lane's
+            // column (a pixel outside the circle is read -- it lies inside the level's 32-pixel border -- and not added).  The loop
+            // below loaded umax[v], compared, then loaded two pixels, per row: hp dependent memory latencies per keypoint (10 us a wave).
+            int um[16], vp[16], vm[16];
+#pragma unroll
+            for (int v = 1; v <= 15; ++v) um[v] = umax[min(v, hp)];
+#pragma unroll
+            for (int v = 1; v <= 15; ++v) { const int vv = min(v, hp); vp[v] = ctr[u + vv * pp]; vm[v] = ctr[u - vv * pp]; }
+#pragma unroll
+            for (int v = 1; v <= 15; ++v) {
+                const bool in = v <= hp && abs(u) <= um[v];
+                m10 += in ? u * (vp[v] + vm[v]) : 0;
+                m01 += in ? v * (vp[v] - vm[v]) : 0;
+            }
+        } else {
+            for (int v = 1; v <= hp; ++v) {
+                if (abs(u) <= umax[v]) {
+                    int vp = ctr[u + v * pp], vm = ctr[u - v * pp];
+                    m10 += u * (vp + vm);
+                    m01 += v * (vp - vm);
+                }
             }
         }
     }
@@ -687,7 +717,7 @@ __global__ __launch_bounds__(256) void assemble_angle_kernel(Levels L, const uin
         MisKeyPoint kp;
         kp.x = (float)x * d.scale; kp.y = (float)y * d.scale;
         kp.size = (float)L.patch * d.scale;
-        kp.angle = mis_fast_atan2((float)m01, (float)m10);
+        kp.angle = with_angle ? mis_fast_atan2((float)m01, (float)m10) : 0.f;
         kp.response = fin_resp[d.fin_off + i];
         kp.octave = l;
         kps[base + i] = kp;
@@ -797,12 +827,12 @@ __global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* 
 // inside the level are blurred (their taps may reach into the reflected border ring), samples in the ring are not: the reference
 // blurs the level's ROI of the bordered pyramid only.
 constexpr int DD_R = 28, DD_P = DD_R + 3, DD_N = 2 * DD_P + 1, DD_ROW_DW = (DD_N + 3 + 3) / 4, DD_PITCH = 4 * DD_ROW_DW + 4;
-__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, OrbIO io, const int8_t* pattern, size_t ws) {
+__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, OrbIO io, const int8_t* pattern, const int* umax, size_t ws) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4][DD_N * DD_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave, fr = blockIdx.y;
     WS_OFF(pad, fr, ws);
-    const MisKeyPoint* kps = io.kps[fr];
+    MisKeyPoint* kps = io.kps[fr];
     const uint32_t* kp_lxy = io.lxy[fr];
     const int* n_ptr = io.n_dev[fr];
     uint8_t* desc = io.desc[fr];
@@ -811,26 +841,63 @@ __global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const ui
     const LevelDesc& d = L.d[kp.octave];
     const float inv = 1.f / d.scale;
     const int cx = mis_round_f(kp.x * inv), cy = mis_round_f(kp.y * inv);
-    float ang = kp.angle * (float)(3.14159265358979323846 / 180.f);
-    float sa, ca;
-    mis_sincosf(ang, &sa, &ca);
     const int pp = d.pp;
     const uint8_t* org = pad + d.pad_off + (size_t)(cy + ORB_BORDER - DD_P) * pp + (cx + ORB_BORDER - DD_P);
     const int shift = (int)((uintptr_t)org & 3);
     const uint8_t* abase = org - shift;   // rows are copied as aligned dwords; the patch starts `shift` bytes into an LDS row
     uint8_t* P = patch[wave];
+    int um[16];
+#pragma unroll
+    for (int v = 1; v <= 15; ++v) um[v] = umax[min(v, L.half_patch)];
     for (int k = lane; k < DD_N * DD_ROW_DW; k += 64) {
         const int r = k / DD_ROW_DW, c = k - r * DD_ROW_DW;
         reinterpret_cast<unsigned*>(P + r * DD_PITCH)[c] = *reinterpret_cast<const unsigned*>(abase + (size_t)r * pp + 4 * c);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the lanes of one wave execute their LDS instructions in order
     __builtin_amdgcn_wave_barrier();
+    const int c0 = DD_P * DD_PITCH + DD_P + shift;               // byte offset of the keypoint's pixel
+    // IC_Angle on the staged patch (the intensity centroid of the 31-pixel disc): the keypoint kernel read the same pixels from
+    // memory a second time -- 31 rows = 31 cache lines per keypoint, 0.18 ms for 64 k keypoints
+    float kp_angle;
+    {
+        const int hp = L.half_patch;
+        const uint8_t* ctr = P + c0;
+        int m01 = 0, m10 = 0;
+        const int u = lane - hp;  // lanes 0..2hp cover u = -hp..hp
+        if (lane <= 2 * hp) {
+            m10 = u * ctr[u];
+            if (hp <= 15) {
+#pragma unroll
+                for (int v = 1; v <= 15; ++v) {      // (um[]: the disc's row limits, loaded before the patch was staged)
+                    const int vv = min(v, hp);
+                    const int vp = ctr[u + vv * DD_PITCH], vm = ctr[u - vv * DD_PITCH];
+                    const bool in = v <= hp && abs(u) <= um[v];
+                    m10 += in ? u * (vp + vm) : 0;
+                    m01 += in ? v * (vp - vm) : 0;
+                }
+            } else {
+                for (int v = 1; v <= hp; ++v) {
+                    if (abs(u) <= umax[v]) {
+                        const int vp = ctr[u + v * DD_PITCH], vm = ctr[u - v * DD_PITCH];
+                        m10 += u * (vp + vm);
+                        m01 += v * (vp - vm);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m01 += __shfl_xor(m01, o); m10 += __shfl_xor(m10, o); }
+        kp_angle = mis_fast_atan2((float)m01, (float)m10);
+        if (lane == 0) kps[i].angle = kp_angle;
+    }
+    float ang = kp_angle * (float)(3.14159265358979323846 / 180.f);
+    float sa, ca;
+    mis_sincosf(ang, &sa, &ca);
     const int b = lane & 31, h = lane >> 5;                  // lane b (and b + 32) of the wave builds byte b: four tests each
     const int8_t* pat = pattern + b * 32 + h * 16;
     // a row's seven taps are bytes a .. a + 6 of three aligned LDS dwords: two funnel shifts bring them into two dwords, two
     // v_dot4_u32_u8 against the packed kernel (18 34 48 56 | 48 34 18 0) give the row sum
     const unsigned* P32 = reinterpret_cast<const unsigned*>(P);
-    const int c0 = DD_P * DD_PITCH + DD_P + shift;               // byte offset of the keypoint's pixel
     auto blurred = [&](int ix, int iy) {
         const int a = c0 + (iy - 3) * DD_PITCH + (ix - 3);       // first tap of the first row
         // keypoints may sit 3 pixels from the edge (edgeThreshold 1): a sample outside the level reads the un-blurred border ring
@@ -1025,9 +1092,9 @@ int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatur
         hipLaunchKernelGGL(harris_kernel, dim3((L.d[0].cap1 + 255) / 256, L.n, nf), dim3(256), 0, st, L, W.pad, W.cnt1, W.cand_xy, W.cand_resp, ws);
     hipLaunchKernelGGL(select_rank_kernel, dim3(L.n, nf), dim3(1024), 0, st, L, W.cnt1, W.cand_xy, W.cand_resp, W.cnt2, W.fin_xy, W.fin_resp, W.flags,
                        use_harris, ws);
-    hipLaunchKernelGGL(assemble_angle_kernel, dim3((L.d[0].cap2 + 3) / 4, L.n, nf), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax, io, o->out_cap, ws);
+    hipLaunchKernelGGL(assemble_angle_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax, io, o->out_cap, ws, o->direct_describe ? 0 : 1);
     if (o->direct_describe) {
-        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, io, W.pattern, ws);
+        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, io, W.pattern, W.umax, ws);
     } else {
         // patterns that reach beyond the direct kernel's patch: the blurred pyramid, frame by frame (not the default parameters)
         for (int k = 0; k < ng; k++) {
