@@ -1683,7 +1683,7 @@ void homo_batch_release(HomoBatch* b) {
     b->mem = nullptr; b->bytes = 0;
 }
 
-int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases, hipStream_t stream) {
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases, hipStream_t stream, hipEvent_t ev_after_draw1, int ev_pos) {
     MIS_CHECK(ctx, max_iters >= 1 && max_iters <= b->max_iters, MIS_E_INVALID, "max_iters %d outside the reserved range", max_iters);
     MIS_CHECK(ctx, confidence > 0 && confidence < 1, MIS_E_INVALID, "confidence must be in (0,1)");
     RngTable rt;
@@ -1724,9 +1724,11 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
+        if (ev_after_draw1 && ev_pos == 0) MIS_HIP(ctx, hipEventRecord(ev_after_draw1, st));
         if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((max_iters - p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, p0, max_iters);
         else hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
+        if (ev_after_draw1 && ev_pos == 1) MIS_HIP(ctx, hipEventRecord(ev_after_draw1, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 6 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,

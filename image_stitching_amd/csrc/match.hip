@@ -761,6 +761,7 @@ struct MatchWorkspace : MisWorkspace {
     hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr, ev_phase1 = nullptr, ev_third_done = nullptr, ev_matches = nullptr;
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
+    hipEvent_t ev_draw1 = nullptr;
     hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
     hipEvent_t ev_lists = nullptr;                       // the early download of the match lists has landed
@@ -778,6 +779,7 @@ struct MatchWorkspace : MisWorkspace {
         if (ev_phase0) hipEventDestroy(ev_phase0);
         if (ev_side_done) hipEventDestroy(ev_side_done);
         if (ev_knn) hipEventDestroy(ev_knn);
+        if (ev_draw1) hipEventDestroy(ev_draw1);
     }
 };
 
@@ -958,7 +960,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // MIS_COMPOSE_GATE: 0 = a stream fenced by mis_match_knn_fence (the job's speculative composition) starts behind the 2-NN pass,
     // 1 = behind the first RANSAC phase of the first estimation (draw, 4-point solves, replay, masks: 0.7 ms of large workgroups
     // that wait for room once the composition's grids fill the device)
-    static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 1;
+    static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 2;
     auto enqueue_chains = [&]() -> int {
     static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 3;   // 2: the two-chain flow below
     if (chains != 3) {
@@ -1011,6 +1013,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase0, 0));
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 11, ws->third)) != MIS_OK) return rc;
+    if (compose_gate >= 2) {
+        // gate 2: behind the second phase's draw of the main chain -- by then the tails (third stream) and the second estimations
+        // (side stream), released together with it, hold their compute units
+        if (!ws->ev_draw1) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_draw1, hipEventDisableTiming));
+        if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st, ws->ev_draw1, compose_gate - 2)) != MIS_OK) return rc;
+        ws->ev_gate = ws->ev_draw1;
+    } else
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st)) != MIS_OK) return rc;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase1, st));

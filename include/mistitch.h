@@ -161,10 +161,10 @@ int mis_matches_free(MisMatchesInfo* m, int count);
 /* Ordering aid for a caller that overlaps other device work with a matcher call made by another host thread (the
  * job's speculative composition): mis_match_sequence = number of matcher calls this context has started;
  * mis_match_knn_fence(ctx, stream, mis_match_sequence(ctx) + 1 taken BEFORE the other thread calls the matcher, ms)
- * makes `stream` wait for the point of that call behind which other work shares the device well: the end of the first RANSAC
- * phase of the pairs' first estimation (0.7 ms behind the 2-NN pass: draws, 4-point solves, replay, masks -- large workgroups that
- * wait for room once another stream's grids fill the compute units), or the end of the 2-NN pass itself with MIS_COMPOSE_GATE=0
- * in the environment. */
+ * makes `stream` wait for the point of that call behind which other work shares the device well: by default the second draw of
+ * the main RANSAC chain, 0.9 ms behind the 2-NN pass (the chains' kernels are few large workgroups that wait for room once another
+ * stream's grids fill the compute units; from that point on they hold theirs).  MIS_COMPOSE_GATE in the environment moves it:
+ * 1 = the end of the first RANSAC phase, 0 = the end of the 2-NN pass. */
 long long mis_match_sequence(MisContext* ctx);
 int mis_match_knn_fence(MisContext* ctx, void* stream, long long target_seq, int timeout_ms);
 /* The same without a second host thread: a one-shot hook of this context's NEXT matcher call.  fn(user) runs on the thread that
