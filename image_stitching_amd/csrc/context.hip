@@ -41,7 +41,13 @@ int mis_host_stage(MisContext* ctx, size_t bytes, void** out) {
 
 int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out) {
     MIS_CHECK(ctx, k == 0 || k == 1, MIS_E_INVALID, "auxiliary stream index %d", k);
-    if (!ctx->aux[k]) MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking));
+    if (!ctx->aux[k]) {
+        // MIS_AUX_PRIO=1: the auxiliary streams (the matcher's side chains) at the device's most urgent priority
+        static const bool urgent = getenv("MIS_AUX_PRIO") && atoi(getenv("MIS_AUX_PRIO")) > 0;
+        int least = 0, greatest = 0;
+        if (urgent && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) MIS_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux[k], hipStreamNonBlocking, greatest));
+        else MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking));
+    }
     *out = ctx->aux[k];
     return MIS_OK;
 }
@@ -94,6 +100,7 @@ extern "C" int mis_stream_create(int device, int priority, void** out) {
     if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return MIS_E_HIP;
+    if (getenv("MIS_STREAM_PRIO")) priority = atoi(getenv("MIS_STREAM_PRIO"));     // diagnostics: > 0 the least urgent, < 0 the most urgent
     const int pr = priority > 0 ? least : (priority < 0 ? greatest : 0);   // HIP: numerically smaller = more urgent
     hipStream_t s = nullptr;
     // MIS_STREAM_CU_FRACTION = f in (0, 1): the stream's kernels are confined to the first f of the device's compute units (the
