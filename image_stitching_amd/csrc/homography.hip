@@ -172,6 +172,9 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
 #ifndef MIS_HYP_QUAD
 #define MIS_HYP_QUAD 1          // the 4-point solves on four lanes each (hyp_quad_kernel); 0: one thread each (hyp_kernel)
 #endif
+#ifdef MIS_TAIL_PROF
+__device__ unsigned long long g_draw_prof[12];   // per phase p (0, 1): [4p] chunks (all problems), [4p+1] most chunks of a problem, [4p+2] longest problem (wall ticks), [4p+3] problems with work
+#endif
 // ---------------------------------------------------------------- draw_kernel ------------------
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
@@ -238,6 +241,9 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
     __shared__ int s_big, s_firstvis, s_lastaccvis;
     __shared__ long long s_endpos;
     const int b = blockIdx.x, t = threadIdx.x;
+#ifdef MIS_TAIL_PROF
+    const unsigned long long dpk = wall_clock64();
+#endif
     const HomoCall c = calls[b];
     RansacState* st = states + b;
     if (phase == 0) {
@@ -294,12 +300,24 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
             }
             any |= check_subset(ms1, ms2) ? 1 : 0;
         }
-        if (!__syncthreads_or(any)) {
+        const int found = __syncthreads_or(any);
+#ifdef MIS_TAIL_PROF
+        if (t == 0) { atomicMax(&g_draw_prof[8], wall_clock64() - dpk); atomicAdd(&g_draw_prof[9], 1ull); }     // longest exhaustive test of a tiny problem (from the kernel's start), their number
+#endif
+        if (!found) {
             if (t == 0) { st->draw_fail = 1; st->n_sub = 0; st->draw_k = 0; }
             return;
         }
     }
+#ifdef MIS_TAIL_PROF
+    const unsigned long long dp0 = wall_clock64();
+    int dp_chunks = 0;
+    if (t == 0 && phase == 0) atomicMax(&g_draw_prof[10], dp0 - dpk);      // longest prologue of a phase-0 problem
+#endif
     while (s_more) {
+#ifdef MIS_TAIL_PROF
+        dp_chunks++;
+#endif
         const long long base = s_pos;
         for (int o = t; o < DRAW_CHUNK; o += DRAW_TB) {
             int idx[4];
@@ -411,6 +429,13 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
         }
         __syncthreads();
     }
+#ifdef MIS_TAIL_PROF
+    if (t == 0 && dp_chunks) {
+        const int ph = phase ? 4 : 0;
+        atomicAdd(&g_draw_prof[ph], (unsigned long long)dp_chunks); atomicMax(&g_draw_prof[ph + 1], (unsigned long long)dp_chunks);
+        atomicMax(&g_draw_prof[ph + 2], wall_clock64() - dp0); atomicAdd(&g_draw_prof[ph + 3], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- hyp_kernel -------------------
@@ -1647,6 +1672,12 @@ extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(unsigned long long) * 12);
     if (reset) { unsigned long long z[12] = {0}; z[8] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
+    return 0;
+}
+extern "C" int mis_debug_draw_prof(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_draw_prof), sizeof(unsigned long long) * 12);
+    if (reset) { unsigned long long z[12] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_draw_prof), z, sizeof(z)); }
     return 0;
 }
 extern "C" int mis_debug_hyp_prof(unsigned long long* out, int reset) {

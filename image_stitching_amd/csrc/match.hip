@@ -690,6 +690,26 @@ __global__ void first_calls_kernel(const PairDesc* pairs, int np, const int* n_m
 // `want` selects the problems whose first estimation finished in that RANSAC phase (fin1[k]); the others get an
 // inactive call and their PairOut entry is left alone (the launch for the other phase owns it)
 
+// The match lists of a call, packed pair after pair (pair k at the sum of the counts before it) straight into the pinned host
+// staging, with the counts: 16 bytes per match that exists instead of a device-to-host copy of the capacity-sized arrays (15 MB
+// for 16 x 4000 features, 5 % of it used).  That copy ran as a blit kernel on the compute units, under the first draw_kernel --
+// whose 1024-thread workgroups need a compute unit each to themselves: 120 us of work took 360 us.
+__global__ __launch_bounds__(256) void pack_lists_kernel(const PairDesc* pairs, int np, const int* nm, const MisDMatch* matches, MisDMatch* host_m, int* host_nm) {
+    __shared__ int red[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    int part = 0;
+    for (int q = t; q < k; q += 256) part += nm[q];
+    red[t] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const int off = red[0], cnt = nm[k];
+    if (t == 0) host_nm[k] = cnt;
+    const uint4* s = reinterpret_cast<const uint4*>(matches + pairs[k].m_off);
+    uint4* d = reinterpret_cast<uint4*>(host_m + off);
+    static_assert(sizeof(MisDMatch) == 16, "one 16-byte store per match");
+    for (int i = t; i < cnt; i += 256) d[i] = s[i];
+}
+
 // The small per-pair results of a matcher call written straight into the pinned (device-visible) host staging: one launch
 // instead of six device-to-host copies of a few kilobytes each (~15 us apiece on the tail of the call).
 struct CopySegs { const uint8_t* src[8]; uint8_t* dst[8]; unsigned bytes[8]; int n; };
@@ -954,7 +974,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_done, hipEventDisableTiming));
     }
     const double rt = p->ransac_thresh, cf = p->confidence;
-    bool early_lists = false;
+    bool early_lists = false, packed_lists = false;     // packed: pair k's matches sit at the sum of the counts before it (pack_lists_kernel)
     // everything between the forks to the auxiliary streams and their joins runs inside one scope: an error in there must not
     // leave those streams with work pending (they are the context's, shared with the feature finders) or a copy in flight
     // MIS_COMPOSE_GATE: 0 = a stream fenced by mis_match_knn_fence (the job's speculative composition) starts behind the 2-NN pass,
@@ -998,10 +1018,10 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // RANSAC chains, instead of behind them (0.3 ms at the end of the call)
     MIS_HIP(ctx, hipEventRecord(ws->ev_matches, st));
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_matches, 0));
-    MIS_HIP(ctx, hipMemcpyAsync(Hh + h_nm, d_nm, sizeof(int) * np, hipMemcpyDeviceToHost, ws->third));
-    MIS_HIP(ctx, hipMemcpyAsync(Hh + h_m, d_matches, sizeof(MisDMatch) * m_total, hipMemcpyDeviceToHost, ws->third));
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(np), dim3(256), 0, ws->third, (const PairDesc*)d_pairs, np, (const int*)d_nm, (const MisDMatch*)d_matches,
+                       (MisDMatch*)(Hh + h_m), (int*)(Hh + h_nm));
     MIS_HIP(ctx, hipEventRecord(ws->ev_lists, ws->third));
-    early_lists = true;
+    early_lists = true; packed_lists = true;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 10, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
@@ -1082,6 +1102,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     const auto tq = std::chrono::steady_clock::now();
     // MatchesInfo (host), part 1 under the RANSAC chains: the match lists and their mirrors
     auto lists = [&]() {
+        size_t packed_off = 0;
         for (int k = 0; k < np; k++) {
             const PairDesc& pd = pairs[k];
             MisMatchesInfo* a = &out[pd.i * n + pd.j];
@@ -1089,7 +1110,8 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             a->src_img_idx = pd.i; a->dst_img_idx = pd.j;
             a->n_matches = nm[k];
             a->matches = (MisDMatch*)malloc(sizeof(MisDMatch) * (size_t)(nm[k] + 1));
-            memcpy(a->matches, hm + pd.m_off, sizeof(MisDMatch) * (size_t)nm[k]);
+            memcpy(a->matches, hm + (packed_lists ? packed_off : pd.m_off), sizeof(MisDMatch) * (size_t)nm[k]);
+            packed_off += (size_t)nm[k];
             b->matches = (MisDMatch*)malloc(sizeof(MisDMatch) * (size_t)(nm[k] + 1));
             for (int q = 0; q < nm[k]; q++) {
                 b->matches[q] = a->matches[q];

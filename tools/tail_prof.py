@@ -16,8 +16,17 @@ jp = (C.c_ulonglong * 8)()
 ctx.lib.mis_debug_tail_prof(out, 1)
 ctx.lib.mis_debug_jac_prof(jp, 1)
 hp = (C.c_ulonglong * 8)()
+dp = (C.c_ulonglong * 12)()
 ctx.lib.mis_debug_hyp_prof(hp, 1)
+ctx.lib.mis_debug_draw_prof(dp, 1)
 step()
+ctx.lib.mis_debug_draw_prof(dp, 1)
+dd = list(dp)
+print("draw_kernel, phase 0: longest prologue %.1f us; %d exhaustive tests of tiny problems, the longest done %.1f us after its workgroup started" % (dd[10] * 0.01, dd[9], dd[8] * 0.01))
+for ph in (0, 1):
+    if dd[4 * ph + 3]:
+        print("draw_kernel launches of phase %d (all estimations): %d problems, %d chunks of 4096 stream positions in all, at most %d for one problem, longest problem %.1f us"
+              % (ph, dd[4 * ph + 3], dd[4 * ph], dd[4 * ph + 1], dd[4 * ph + 2] * 0.01))
 ctx.lib.mis_debug_hyp_prof(hp, 1)
 h = list(hp)
 print("phase-1 replays: %.1f us in total, longest %.1f us" % (h[6] * 0.01, h[7] * 0.01))
