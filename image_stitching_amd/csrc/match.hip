@@ -782,6 +782,7 @@ struct MatchWorkspace : MisWorkspace {
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
     hipEvent_t ev_draw1 = nullptr;
+    hipEvent_t tev[8] = {nullptr};   // MIS_MATCH_TRACE: timing events (2-NN end, phase 0 end, draw 1 end, main chain end, side end, third end, tails of phase 0 end)
     hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
     hipEvent_t ev_lists = nullptr;                       // the early download of the match lists has landed
@@ -981,6 +982,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // 1 = behind the first RANSAC phase of the first estimation (draw, 4-point solves, replay, masks: 0.7 ms of large workgroups
     // that wait for room once the composition's grids fill the device)
     static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 2;
+    static const bool trace_ev = getenv("MIS_MATCH_TRACE") != nullptr;
+    auto mark = [&](int i, hipStream_t s_) {      // diagnostics: device time stamps of the chains (printed with the host's when MIS_MATCH_TRACE is set)
+        if (!trace_ev) return;
+        if (!ws->tev[i]) hipEventCreate(&ws->tev[i]);
+        hipEventRecord(ws->tev[i], s_);
+    };
+    mark(0, st);
     auto enqueue_chains = [&]() -> int {
     static const int chains = getenv("MIS_MATCH_CHAINS") ? atoi(getenv("MIS_MATCH_CHAINS")) : 3;   // 2: the two-chain flow below
     if (chains != 3) {
@@ -1025,14 +1033,17 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 3, st)) != MIS_OK) return rc;
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 10, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase0, st));
+    mark(1, st);
     if (compose_gate == 1) ws->ev_gate = ws->ev_phase0;
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out, 0);
     if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
+    mark(4, ws->side);
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase0, 0));
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 11, ws->third)) != MIS_OK) return rc;
+    mark(6, ws->third);
     if (compose_gate >= 2) {
         // gate 2: behind the second phase's draw of the main chain -- by then the tails (third stream) and the second estimations
         // (side stream), released together with it, hold their compute units
@@ -1047,11 +1058,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // refinement of the phase-0 finishers on the third stream it ended the matcher 0.6 ms later); their inlier-only second
     // estimation goes to the third stream instead
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 13, st)) != MIS_OK) return rc;
+    mark(3, st);
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase1, 0));
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->third, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 1, p->num_matches_thresh2, ws->b3.calls, d_out, 0);
     if ((rc = homo_batch_run(ctx, &ws->b3, rt, p->max_iters, cf, 2, ws->third)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_third_done, ws->third));
+    mark(5, ws->third);
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_third_done, 0));
     }
     MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_side_done, 0));
@@ -1185,6 +1198,12 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         const auto te = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
         fprintf(stderr, "match: enqueue %.0f us, device wait %.0f us, host assembly %.0f us\n", us(t_begin, tq), us(tq, ts), us(ts, te));
+        if (ws->tev[0] && ws->tev[1] && ws->tev[3] && ws->tev[4] && ws->tev[5] && ws->tev[6]) {
+            float e1 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0;
+            hipEventElapsedTime(&e1, ws->tev[0], ws->tev[1]); hipEventElapsedTime(&e3, ws->tev[0], ws->tev[3]); hipEventElapsedTime(&e4, ws->tev[0], ws->tev[4]);
+            hipEventElapsedTime(&e5, ws->tev[0], ws->tev[5]); hipEventElapsedTime(&e6, ws->tev[0], ws->tev[6]);
+            fprintf(stderr, "match chains, ms after the 2-NN pass was enqueued-behind (device events): first phase done %.2f | tails of its finishers done %.2f | main chain done %.2f | side chain done %.2f | third chain done %.2f\n", e1, e6, e3, e4, e5);
+        }
     }
     return MIS_OK;
 }
