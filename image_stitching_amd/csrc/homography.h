@@ -50,5 +50,8 @@ void homo_batch_release(HomoBatch* b);
 // 3 / 6 = like 0 / 1 without the tails (left pending), 4 = the pending tails of phase 0 (any stream, concurrently with a phases = 1 run);
 // 10 + 2 w / 11 + 2 w = the pending tails of phase w in two steps: mask + inlier compaction / DLT + LM refinement.
 // `stream` = nullptr: the context's stream.
+// Optional ordering hooks of a run: rec is recorded behind the second phase's draw_kernel (rec_pos 0), its 4-point solves (1) or the
+// FIRST phase's draw (2); rec_hyp0 behind the first phase's solves; the second phase's solves wait for wait_hyp1.
+struct HomoSync { hipEvent_t rec = nullptr; int rec_pos = 0; hipEvent_t rec_hyp0 = nullptr; hipEvent_t wait_hyp1 = nullptr; };
 int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases = 2, hipStream_t stream = nullptr,
-                   hipEvent_t ev_after_draw1 = nullptr, int ev_pos = 0);   // ev_after_draw1: recorded behind the second phase's draw_kernel (ev_pos 0) or its 4-point solves (1) (phases 1, 2, 6)
+                   const HomoSync* sync = nullptr);

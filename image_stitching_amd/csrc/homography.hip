@@ -1714,7 +1714,9 @@ void homo_batch_release(HomoBatch* b) {
     b->mem = nullptr; b->bytes = 0;
 }
 
-int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases, hipStream_t stream, hipEvent_t ev_after_draw1, int ev_pos) {
+int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, double confidence, int phases, hipStream_t stream, const HomoSync* sync) {
+    const HomoSync none;
+    const HomoSync& sy = sync ? *sync : none;
     MIS_CHECK(ctx, max_iters >= 1 && max_iters <= b->max_iters, MIS_E_INVALID, "max_iters %d outside the reserved range", max_iters);
     MIS_CHECK(ctx, confidence > 0 && confidence < 1, MIS_E_INVALID, "confidence must be in (0,1)");
     RngTable rt;
@@ -1738,9 +1740,11 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
+        if (sy.rec && sy.rec_pos == 2) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
         if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, 0, max_iters);
         else hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
                            b->good, 0, max_iters, thr);
+        if (sy.rec_hyp0) MIS_HIP(ctx, hipEventRecord(sy.rec_hyp0, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 3 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
                            max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0, tail_cap(phases == 3 ? 1 : 0));
@@ -1755,11 +1759,12 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
-        if (ev_after_draw1 && ev_pos == 0) MIS_HIP(ctx, hipEventRecord(ev_after_draw1, st));
+        if (sy.rec && sy.rec_pos == 0) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
+        if (sy.wait_hyp1) MIS_HIP(ctx, hipStreamWaitEvent(st, sy.wait_hyp1, 0));
         if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((max_iters - p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, p0, max_iters);
         else hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
                            b->Hc, b->valid, b->good, p0, max_iters, thr);
-        if (ev_after_draw1 && ev_pos == 1) MIS_HIP(ctx, hipEventRecord(ev_after_draw1, st));
+        if (sy.rec && sy.rec_pos == 1) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 6 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,

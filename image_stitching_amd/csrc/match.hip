@@ -781,7 +781,7 @@ struct MatchWorkspace : MisWorkspace {
     hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr, ev_phase1 = nullptr, ev_third_done = nullptr, ev_matches = nullptr;
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
-    hipEvent_t ev_draw1 = nullptr;
+    hipEvent_t ev_draw1 = nullptr, ev_side_hyp0 = nullptr;
     hipEvent_t tev[8] = {nullptr};   // MIS_MATCH_TRACE: timing events (2-NN end, phase 0 end, draw 1 end, main chain end, side end, third end, tails of phase 0 end)
     hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
@@ -801,6 +801,7 @@ struct MatchWorkspace : MisWorkspace {
         if (ev_side_done) hipEventDestroy(ev_side_done);
         if (ev_knn) hipEventDestroy(ev_knn);
         if (ev_draw1) hipEventDestroy(ev_draw1);
+        if (ev_side_hyp0) hipEventDestroy(ev_side_hyp0);
     }
 };
 
@@ -1038,20 +1039,30 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_phase0, 0));
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->side, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
                        (const float*)ws->b1.scr, (const int*)ws->b1.fin, 0, p->num_matches_thresh2, ws->b2.calls, d_out, 0);
-    if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side)) != MIS_OK) return rc;
+    // MIS_HYP_ORDER=1 (experiment): the main chain's second-phase solves wait for the side chain's first solves.  Measured: the side
+    // chain ends where it did (+ 2.65 ms behind the 2-NN pass: its solves are not slowed by the others'), the main chain 0.55 ms later.
+    static const int hyp_order = getenv("MIS_HYP_ORDER") ? atoi(getenv("MIS_HYP_ORDER")) : 0;
+    if (!ws->ev_draw1) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_draw1, hipEventDisableTiming));
+    if (!ws->ev_side_hyp0) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_hyp0, hipEventDisableTiming));
+    {
+        HomoSync sy;
+        if (compose_gate == 4) { sy.rec = ws->ev_draw1; sy.rec_pos = 2; ws->ev_gate = ws->ev_draw1; }      // gate 4 (experiment): behind the side chain's first draw
+        if (hyp_order) sy.rec_hyp0 = ws->ev_side_hyp0;
+        if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side, &sy)) != MIS_OK) return rc;
+    }
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
     mark(4, ws->side);
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase0, 0));
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 11, ws->third)) != MIS_OK) return rc;
     mark(6, ws->third);
-    if (compose_gate >= 2) {
+    {
         // gate 2: behind the second phase's draw of the main chain -- by then the tails (third stream) and the second estimations
         // (side stream), released together with it, hold their compute units
-        if (!ws->ev_draw1) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_draw1, hipEventDisableTiming));
-        if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st, ws->ev_draw1, compose_gate - 2)) != MIS_OK) return rc;
-        ws->ev_gate = ws->ev_draw1;
-    } else
-    if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st)) != MIS_OK) return rc;
+        HomoSync sy;
+        if (compose_gate == 2 || compose_gate == 3) { sy.rec = ws->ev_draw1; sy.rec_pos = compose_gate - 2; ws->ev_gate = ws->ev_draw1; }
+        if (hyp_order) sy.wait_hyp1 = ws->ev_side_hyp0;
+        if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st, &sy)) != MIS_OK) return rc;
+    }
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase1, st));
     // the refinement of the phase-1 finishers' first H stays on this stream (1.7 ms of latency-bound work: behind the 2 ms
