@@ -179,12 +179,18 @@ __device__ unsigned long long g_draw_prof[12];   // per phase p (0, 1): [4p] chu
 // cv::RNG multiply-with-carry stream: U[s] is the (s+1)-th output from seed (uint64)-1
 struct DrawCtx {
     const unsigned* U;
+    const unsigned* lds_u = nullptr;   // stream positions lds_base .. lds_base + lds_n - 1 staged in LDS (the current chunk of draw_kernel + the reach of an attempt)
+    long long lds_base = 0;
+    int lds_n = 0;
+    bool lds_mod = false;              // the staged values are draw % n
     unsigned long long state_T;  // generator state after RNG_TABLE draws
     // serial continuation beyond the table (positions are visited in increasing order)
     unsigned long long cur_state;
     long long cur_pos;
 };
 __device__ __forceinline__ unsigned draw_at(DrawCtx& d, long long pos) {
+    const long long rel = pos - d.lds_base;
+    if (rel >= 0 && rel < d.lds_n) return d.lds_u[rel];
     if (pos < RNG_TABLE) return d.U[pos];
     unsigned v = 0;
     while (d.cur_pos <= pos) {
@@ -193,6 +199,40 @@ __device__ __forceinline__ unsigned draw_at(DrawCtx& d, long long pos) {
         d.cur_pos++;
     }
     return v;
+}
+
+// draw % n at a stream position: the staged positions hold the remainder already (draw_kernel reduces a chunk's numbers once, as it
+// stages them -- an attempt reads four or more consecutive positions and every position is read by the attempts of four starts)
+__device__ __forceinline__ int draw_mod_at(DrawCtx& d, long long pos, int n) {
+    const long long rel = pos - d.lds_base;
+    if (d.lds_mod && rel >= 0 && rel < d.lds_n) return (int)d.lds_u[rel];
+    return (int)(draw_at(d, pos) % (unsigned)n);
+}
+
+// The draws of ONE getSubset attempt starting at stream position pos: four distinct indices (redraw on duplicates).  Returns the
+// end position.  Every stream position is a possible start, one in ~4.5 is a real one: the chunk loop of draw_kernel finds the
+// real ones from the lengths alone and runs checkSubset (150 f64 operations) on those only.
+__device__ __forceinline__ long long attempt_len(DrawCtx& d, long long pos, int n, int* idx) {
+    for (int i = 0; i < 4; i++) {
+        int idx_i;
+        bool dup;
+        do {
+            idx_i = draw_mod_at(d, pos++, n);
+            dup = false;
+            for (int q = 0; q < i; q++) dup |= idx[q] == idx_i;
+        } while (dup);
+        idx[i] = idx_i;
+    }
+    return pos;
+}
+__device__ __forceinline__ bool subset_passes(const float* src, const float* dst, const int* idx) {
+    float ms1[8], ms2[8];
+    for (int i = 0; i < 4; i++) {
+        const float2 ps = reinterpret_cast<const float2*>(src)[idx[i]], pd = reinterpret_cast<const float2*>(dst)[idx[i]];
+        ms1[2 * i] = ps.x; ms1[2 * i + 1] = ps.y;
+        ms2[2 * i] = pd.x; ms2[2 * i + 1] = pd.y;
+    }
+    return check_subset(ms1, ms2);
 }
 
 // ONE getSubset attempt starting at stream position pos: four distinct indices (redraw on duplicates),
@@ -237,6 +277,7 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
     __shared__ unsigned short acc_o[DRAW_CHUNK / 4];  // chunk offsets of the accepted attempts (serial path)
     __shared__ unsigned short nxtA[DRAW_CHUNK + 1], nxtB[DRAW_CHUNK + 1];  // J^(2^r): start of the attempt 2^r hops ahead
     __shared__ unsigned char reach[DRAW_CHUNK];
+    __shared__ unsigned su[DRAW_CHUNK + 128];
     __shared__ int scan[DRAW_TB];
     __shared__ int s_big, s_firstvis, s_lastaccvis;
     __shared__ long long s_endpos;
@@ -260,7 +301,8 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
     const int k_hi = min(k_hi_arg, phase == 0 ? max_iters : st->niters);
     if (t == 0) { s_pos = st->draw_pos; s_k = st->draw_k; s_attempts = 0; s_more = s_k < k_hi; }
     __syncthreads();
-    DrawCtx d{U, state_T, state_T, RNG_TABLE};
+    DrawCtx d;
+    d.U = U; d.state_T = state_T; d.cur_state = state_T; d.cur_pos = RNG_TABLE;
     const float* psrc = c.src;
     const float* pdst = c.dst;
     if (c.n <= DRAW_PTS) {
@@ -302,7 +344,7 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
         }
         const int found = __syncthreads_or(any);
 #ifdef MIS_TAIL_PROF
-        if (t == 0) { atomicMax(&g_draw_prof[8], wall_clock64() - dpk); atomicAdd(&g_draw_prof[9], 1ull); }     // longest exhaustive test of a tiny problem (from the kernel's start), their number
+        (void)dpk;
 #endif
         if (!found) {
             if (t == 0) { st->draw_fail = 1; st->n_sub = 0; st->draw_k = 0; }
@@ -311,24 +353,32 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
     }
 #ifdef MIS_TAIL_PROF
     const unsigned long long dp0 = wall_clock64();
+    unsigned long long dp_last = dp0;
     int dp_chunks = 0;
-    if (t == 0 && phase == 0) atomicMax(&g_draw_prof[10], dp0 - dpk);      // longest prologue of a phase-0 problem
+
 #endif
     while (s_more) {
 #ifdef MIS_TAIL_PROF
         dp_chunks++;
 #endif
         const long long base = s_pos;
-        for (int o = t; o < DRAW_CHUNK; o += DRAW_TB) {
+        // the chunk's random numbers (+ the 127 positions an attempt can reach past it) staged in LDS: an attempt is a chain of
+        // draw -> modulo -> duplicate test -> next draw, and from the table in global memory every link was a memory latency
+        // (17 of a chunk's 31 us)
+        __syncthreads();        // (the previous chunk's serial path may still read the staging)
+        for (int o = t; o < DRAW_CHUNK + 128; o += DRAW_TB) su[o] = (base + o < RNG_TABLE ? U[base + o] : 0u) % (unsigned)c.n;
+        d.lds_u = su; d.lds_base = base; d.lds_n = (int)max(0ll, min((long long)(DRAW_CHUNK + 128), (long long)RNG_TABLE - base)); d.lds_mod = true;
+        __syncthreads();
+        for (int o = t; o < DRAW_CHUNK; o += DRAW_TB) {      // lengths only; the verdicts of the visited attempts follow the chase
             int idx[4];
-            bool pass;
-            long long e = attempt_at(d, base + o, psrc, pdst, c.n, idx, &pass);
-            long long delta = e - (base + o);
-            tab[o] = (unsigned char)((delta > 127 ? 127 : delta) | (pass ? 0x80 : 0));
-            *reinterpret_cast<int4*>(didx + 4 * o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            const long long delta = attempt_len(d, base + o, c.n, idx) - (base + o);
+            tab[o] = (unsigned char)(delta > 127 ? 127 : delta);
         }
         if (t == 0) s_big = 0;
         __syncthreads();
+#ifdef MIS_TAIL_PROF
+        const unsigned long long cs1 = wall_clock64();
+#endif
         // ---- which attempts does the sequential chain visit?  start -> end -> ... by pointer doubling ----
         constexpr int C = DRAW_CHUNK;
         for (int q = t; q < C; q += DRAW_TB) {
@@ -349,9 +399,22 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
                 __syncthreads();
                 unsigned short* tmp = cur; cur = oth; oth = tmp;
             }
-            // ranks of the visited / accepted attempts in stream order (each thread owns 16 consecutive positions)
-            int lv = 0, la = 0;
+#ifdef MIS_TAIL_PROF
+            const unsigned long long cs2 = wall_clock64();
+#endif
+            // checkSubset of the visited attempts: hops are >= 4 positions, so a thread's C / DRAW_TB = 4 consecutive positions hold at
+            // most one (every thread has at most one attempt to test)
             const int q0 = t * (C / DRAW_TB);
+            int qv = -1;
+            for (int q = q0; q < q0 + C / DRAW_TB; q++) qv = reach[q] ? q : qv;
+            if (qv >= 0) {       // outside the loop: inside it the wave would run the test once per loop trip, a quarter of its lanes each time
+                int idx[4];
+                attempt_len(d, base + qv, c.n, idx);
+                if (subset_passes(psrc, pdst, idx)) tab[qv] |= 0x80;
+                *reinterpret_cast<int4*>(didx + 4 * qv) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            }
+            // ranks of the visited / accepted attempts in stream order (each thread owns C / DRAW_TB consecutive positions)
+            int lv = 0, la = 0;
             for (int q = q0; q < q0 + C / DRAW_TB; q++) { const int rv = reach[q]; lv += rv; la += rv && (tab[q] & 0x80); }
             scan[t] = (lv << 16) | la;
             __syncthreads();
@@ -392,9 +455,25 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
                 s_pos = s_endpos; s_k = k; s_attempts = attempts;
                 s_more = !fail && k < k_hi;
                 if (!s_more) { st->draw_pos = s_pos; st->draw_k = k; st->draw_fail = fail; st->n_sub = k; }
+#ifdef MIS_TAIL_PROF
+                const unsigned long long cs3 = wall_clock64();
+                atomicAdd(&g_draw_prof[8], cs1 - (dp_last)); atomicAdd(&g_draw_prof[9], cs2 - cs1); atomicAdd(&g_draw_prof[10], cs3 - cs2); atomicAdd(&g_draw_prof[11], 1ull);
+#endif
             }
             __syncthreads();
+#ifdef MIS_TAIL_PROF
+            dp_last = wall_clock64();
+#endif
             continue;
+        }
+        __syncthreads();
+        // serial path (an attempt of the chunk consumed > 126 draws: tiny n): the verdict of every position, then one thread walks
+        for (int o = t; o < DRAW_CHUNK; o += DRAW_TB) {
+            if ((tab[o] & 0x7f) == 127) continue;
+            int idx[4];
+            attempt_len(d, base + o, c.n, idx);
+            if (subset_passes(psrc, pdst, idx)) tab[o] |= 0x80;
+            *reinterpret_cast<int4*>(didx + 4 * o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
         }
         __syncthreads();
         if (t == 0) {

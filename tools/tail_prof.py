@@ -22,7 +22,8 @@ ctx.lib.mis_debug_draw_prof(dp, 1)
 step()
 ctx.lib.mis_debug_draw_prof(dp, 1)
 dd = list(dp)
-print("draw_kernel, phase 0: longest prologue %.1f us; %d exhaustive tests of tiny problems, the longest done %.1f us after its workgroup started" % (dd[10] * 0.01, dd[9], dd[8] * 0.01))
+if dd[11]:
+    print("draw_kernel, per chunk of the parallel path (%d chunks): attempt simulation %.1f us, pointer doubling %.1f us, ranks + copy %.1f us" % (dd[11], dd[8] * 0.01 / dd[11], dd[9] * 0.01 / dd[11], dd[10] * 0.01 / dd[11]))
 for ph in (0, 1):
     if dd[4 * ph + 3]:
         print("draw_kernel launches of phase %d (all estimations): %d problems, %d chunks of 4096 stream positions in all, at most %d for one problem, longest problem %.1f us"
