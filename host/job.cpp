@@ -117,6 +117,16 @@ void StitchJob::hook(void* self_) {
     }
 }
 
+void StitchJob::prep_hook(void* self_) {
+    StitchJob* self = static_cast<StitchJob*>(self_);
+    self->prep_ran_ = true;
+    try {
+        std::vector<int> everyone(self->n_);
+        std::iota(everyone.begin(), everyone.end(), 0);
+        self->prepare(everyone);
+    } catch (const std::exception& e) { self->prep_error_ = e.what(); }
+}
+
 JobOutput StitchJob::run(const std::vector<MisImage>& frames) {
     if ((int)frames.size() != n_) throw std::runtime_error("StitchJob::run: one frame per camera");
     JobOutput out;
@@ -124,12 +134,18 @@ JobOutput StitchJob::run(const std::vector<MisImage>& frames) {
     std::iota(everyone.begin(), everyone.end(), 0);
     // the compose stream is non-blocking: order it behind whatever produced the frames on the main context's stream
     check(cctx_, mis_context_wait(cctx_, ctx_), "mis_context_wait");
-    // sizing + zeroing of the panorama pyramids depends on the cameras only: it runs under the feature stage
-    prepare(everyone);
+    // sizing + zeroing of the panorama pyramids depends on the cameras only: it runs from the finder's hook, once the feature batch is
+    // enqueued (warpRoi ends in a synchronisation of the compose stream: in front of the features it kept the main stream idle)
+    prep_ran_ = false; prep_error_.clear();
+    check(ctx_, mis_orb_on_enqueued(orb_, &StitchJob::prep_hook, this), "mis_orb_on_enqueued");
     // ---- features (:567-622) ----
     std::vector<MisFeatures> feats(n_);
     std::memset(feats.data(), 0, sizeof(MisFeatures) * n_);
-    check(ctx_, mis_orb_detect_batch(orb_, frames.data(), n_, feats.data()), "mis_orb_detect_batch");
+    const int rc_f = mis_orb_detect_batch(orb_, frames.data(), n_, feats.data());
+    mis_orb_on_enqueued(orb_, nullptr, nullptr);
+    check(ctx_, rc_f, "mis_orb_detect_batch");
+    if (!prep_ran_) prep_hook(this);     // a batch that returned before its hook
+    if (!prep_error_.empty()) throw std::runtime_error(prep_error_);
     for (int i = 0; i < n_; i++) { feats[i].img_idx = i; out.num_features.push_back(feats[i].n); }
     // ---- matching (:647-653) with the speculative composition enqueued from its hook ----
     if (!pairwise_.empty()) { mis_matches_free(pairwise_.data(), (int)pairwise_.size()); pairwise_.clear(); }

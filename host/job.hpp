@@ -44,6 +44,7 @@ private:
     void compose(const std::vector<MisImage>& frames, const std::vector<int>& idx);
     void finalize();
     static void hook(void* self);
+    static void prep_hook(void* self);      // the finder's hook (mis_orb_on_enqueued): prepare() under the feature stage
 
     int w_, h_, n_;
     std::vector<CameraParams> cams_;
@@ -62,6 +63,8 @@ private:
     const std::vector<MisImage>* hook_frames_ = nullptr;
     bool hook_ran_ = false;
     std::string hook_error_;
+    bool prep_ran_ = false;
+    std::string prep_error_;
 };
 
 }  // namespace mis

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "mis_orb_destroy": (_i, [_vp]),
     "mis_orb_detect": (_i, [_vp, _P(MisImage), _P(MisFeatures)]),
     "mis_orb_detect_batch": (_i, [_vp, _P(MisImage), _i, _P(MisFeatures)]),
+    "mis_orb_on_enqueued": (_i, [_vp, _vp, _vp]),
     "mis_features_download": (_i, [_vp, _P(MisFeatures), _vp, _vp]),
     "mis_features_upload": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _P(MisFeatures)]),
     "mis_features_free": (_i, [_vp, _P(MisFeatures)]),

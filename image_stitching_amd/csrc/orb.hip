@@ -942,6 +942,8 @@ __global__ void gather_ints_kernel(GatherPtrs g, int n, int* __restrict__ out) {
 
 struct MisOrb {
     MisContext* ctx = nullptr;
+    void (*enqueued_cb)(void*) = nullptr;      // mis_orb_on_enqueued: one-shot hook of the next batch call
+    void* enqueued_user = nullptr;
     MisOrbParams p;
     int max_w = 0, max_h = 0;
     int cur_w = 0, cur_h = 0;
@@ -1284,6 +1286,15 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
         if ((rc = enqueue_detect_group(o, &dimg[g0], imgs[0].width, imgs[0].height, &out[g0], ng)) != MIS_OK) return fail(rc);
     }
     if (trace) fprintf(stderr, "orb batch: %d frames enqueued in %.0f us\n", n, (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_enq0).count());
+    // one-shot hook (mis_orb_on_enqueued): the caller's own host work -- e.g. the job's warpRoi + blender sizing, which end in a
+    // synchronisation of ANOTHER stream -- runs here, under the batch's 2 ms of device work, on the thread that would only wait
+    if (o->enqueued_cb) {
+        void (*cb)(void*) = o->enqueued_cb;
+        void* user = o->enqueued_user;
+        o->enqueued_cb = nullptr; o->enqueued_user = nullptr;
+        cb(user);
+        MIS_HIP(ctx, hipSetDevice(ctx->device));
+    }
     // one synchronisation for the whole batch: counts + the workspaces' overflow flags
     std::vector<int> counts(n);
     const int nl = o->ws_frames;
@@ -1311,6 +1322,12 @@ extern "C" int mis_orb_detect_batch(MisOrb* o, const MisImage* imgs, int n, MisF
 }
 
 extern "C" int mis_orb_detect(MisOrb* o, const MisImage* bgr, MisFeatures* out) { return mis_orb_detect_batch(o, bgr, 1, out); }
+
+extern "C" int mis_orb_on_enqueued(MisOrb* o, void (*fn)(void*), void* user) {
+    if (!o) return MIS_E_INVALID;
+    o->enqueued_cb = fn; o->enqueued_user = user;
+    return MIS_OK;
+}
 
 extern "C" int mis_features_download(MisContext* ctx, const MisFeatures* f, MisKeyPoint* kps, void* desc) {
     if (!ctx || !f) return MIS_E_INVALID;

@@ -664,11 +664,36 @@ class StitchJob:
             # the compose stream is non-blocking: order it behind whatever produced `frames` on the caller's stream
             side.wait_stream(torch.cuda.current_stream(self.engine.ctx.device))
         if spec:
-            # the blender's prepare (sizing + zeroing ~200 MB of panorama pyramids, ~1.2 ms) depends on the cameras only:
-            # it goes to the compose stream before anything else and runs under the feature stage
-            with torch.cuda.stream(self.engine.compose_stream):
-                prepared = self.stage_compose_prepare(list(range(self.n)))
-        feats = self.stage_gather(self.stage_features(frames))
+            # the blender's prepare (warpRoi of all cameras: a kernel + a synchronisation of the compose stream; sizing; zeroing ~200 MB
+            # of panorama pyramids) depends on the cameras only.  With an ORB finder it runs from the finder's hook, once the feature
+            # batch is enqueued (in front of the features it kept the main stream idle for 0.13 ms of every step); otherwise before them
+            finder = getattr(self.engine, "finder", None)
+            box0 = {}
+
+            def prep():
+                try:
+                    with torch.cuda.stream(self.engine.compose_stream):
+                        box0["p"] = self.stage_compose_prepare(list(range(self.n)))
+                except BaseException as e:   # re-raised on the caller's thread
+                    box0["e"] = e
+            hooked = hasattr(finder, "on_enqueued") and len(self.my_frames) > 0
+            if hooked:
+                finder.on_enqueued(prep)
+            else:
+                prep()
+            try:
+                local = self.stage_features(frames)
+            finally:
+                if hooked:
+                    finder.on_enqueued(None)
+            if "p" not in box0 and "e" not in box0:
+                prep()              # the finder returned before its hook
+            if "e" in box0:
+                raise box0["e"]
+            prepared = box0["p"]
+            feats = self.stage_gather(local)
+        else:
+            feats = self.stage_gather(self.stage_features(frames))
         mark("features")
         if spec:
             # Speculation: almost always every frame survives the pruning, and warp + blend do not depend on the

@@ -573,6 +573,17 @@ class OrbFeatureFinder:
         self.ctx.check(self.ctx.lib.mis_orb_detect(self.h, C.byref(i), C.byref(raw)))
         return ImageFeatures(self.ctx, raw)
 
+    def on_enqueued(self, fn):
+        """fn() runs inside this finder's NEXT detect_batch call, on the calling thread, once the batch's device work is enqueued
+        (mis_orb_on_enqueued).  fn=None clears a pending hook."""
+        if fn is None:
+            self._enqueued_cb = None
+            self.ctx.lib.mis_orb_on_enqueued(self.h, None, None)
+            return
+        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())
+        self._enqueued_cb = cb          # alive until it has run
+        self.ctx.check(self.ctx.lib.mis_orb_on_enqueued(self.h, C.cast(cb, C.c_void_p), None))
+
     def detect_batch(self, imgs):
         n = len(imgs)
         arr = (capi.MisImage * n)(*[as_image(i) for i in imgs])

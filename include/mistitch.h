@@ -111,6 +111,10 @@ int mis_orb_destroy(MisOrb* orb);
 int mis_orb_detect(MisOrb* orb, const MisImage* bgr, MisFeatures* out);
 /* same, for a batch of frames of one size with a single host synchronisation at the end */
 int mis_orb_detect_batch(MisOrb* orb, const MisImage* bgr, int n_images, MisFeatures* out);
+/* One-shot hook of this finder's NEXT mis_orb_detect_batch call: fn(user) runs on the calling thread once the batch's device work
+ * is enqueued and before the call waits for it (fn = NULL clears a pending hook).  The job sizes its blender there (warpRoi of all
+ * cameras: a kernel and a synchronisation on the compose stream), under the feature stage instead of in front of it. */
+int mis_orb_on_enqueued(MisOrb* orb, void (*fn)(void*), void* user);
 int mis_features_download(MisContext* ctx, const MisFeatures* f, MisKeyPoint* kps_host, void* desc_host);
 /* wrap caller-provided (host) keypoints/descriptors as device-resident features */
 int mis_features_upload(MisContext* ctx, int img_w, int img_h, int n, const MisKeyPoint* kps_host,
