@@ -827,7 +827,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Levels L, const uint8_t* 
 // inside the level are blurred (their taps may reach into the reflected border ring), samples in the ring are not: the reference
 // blurs the level's ROI of the bordered pyramid only.
 constexpr int DD_R = 28, DD_P = DD_R + 3, DD_N = 2 * DD_P + 1, DD_ROW_DW = (DD_N + 3 + 3) / 4, DD_PITCH = 4 * DD_ROW_DW + 4;
-__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, OrbIO io, const int8_t* pattern, const int* umax, size_t ws) {
+struct UMax16 { int v[16]; };      // the disc's row limits umax[0 .. 15] by value: scalar loads from the kernel arguments
+__global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const uint8_t* pad, OrbIO io, const int8_t* pattern, const int* umax, UMax16 um16, size_t ws) {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4][DD_N * DD_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave, fr = blockIdx.y;
@@ -846,9 +847,6 @@ __global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const ui
     const int shift = (int)((uintptr_t)org & 3);
     const uint8_t* abase = org - shift;   // rows are copied as aligned dwords; the patch starts `shift` bytes into an LDS row
     uint8_t* P = patch[wave];
-    int um[16];
-#pragma unroll
-    for (int v = 1; v <= 15; ++v) um[v] = umax[min(v, L.half_patch)];
     for (int k = lane; k < DD_N * DD_ROW_DW; k += 64) {
         const int r = k / DD_ROW_DW, c = k - r * DD_ROW_DW;
         reinterpret_cast<unsigned*>(P + r * DD_PITCH)[c] = *reinterpret_cast<const unsigned*>(abase + (size_t)r * pp + 4 * c);
@@ -867,11 +865,10 @@ __global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const ui
         if (lane <= 2 * hp) {
             m10 = u * ctr[u];
             if (hp <= 15) {
-#pragma unroll
-                for (int v = 1; v <= 15; ++v) {      // (um[]: the disc's row limits, loaded before the patch was staged)
-                    const int vv = min(v, hp);
-                    const int vp = ctr[u + vv * DD_PITCH], vm = ctr[u - vv * DD_PITCH];
-                    const bool in = v <= hp && abs(u) <= um[v];
+#pragma unroll 3
+                for (int v = 1; v <= hp; ++v) {      // (three rows in flight: unrolled 15 times the 30 pixels held the kernel at 169 registers, 3 waves per SIMD)
+                    const int vp = ctr[u + v * DD_PITCH], vm = ctr[u - v * DD_PITCH];
+                    const bool in = abs(u) <= um16.v[v];
                     m10 += in ? u * (vp + vm) : 0;
                     m01 += in ? v * (vp - vm) : 0;
                 }
@@ -917,7 +914,10 @@ __global__ __launch_bounds__(256) void describe_direct_kernel(Levels L, const ui
         return inside ? (int)((acc + (1u << 15)) >> 16) : (int)centre;
     };
     int val = 0;
-#pragma unroll
+#ifndef DD_UNROLL
+#define DD_UNROLL 1
+#endif
+#pragma unroll DD_UNROLL
     for (int bit = 0; bit < 4; bit++) {
         float x0 = (float)pat[4 * bit], y0 = (float)pat[4 * bit + 1], x1 = (float)pat[4 * bit + 2], y1 = (float)pat[4 * bit + 3];
         int ix0 = mis_round_f(x0 * ca - y0 * sa), iy0 = mis_round_f(x0 * sa + y0 * ca);
@@ -1096,7 +1096,9 @@ int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatur
                        use_harris, ws);
     hipLaunchKernelGGL(assemble_angle_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, W.cnt2, W.fin_xy, W.fin_resp, W.umax, io, o->out_cap, ws, o->direct_describe ? 0 : 1);
     if (o->direct_describe) {
-        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, io, W.pattern, W.umax, ws);
+        UMax16 um16;
+        for (int v = 0; v < 16; v++) um16.v[v] = o->umax_host[v];
+        hipLaunchKernelGGL(describe_direct_kernel, dim3((o->out_cap + 3) / 4, nf), dim3(256), 0, st, L, W.pad, io, W.pattern, W.umax, um16, ws);
     } else {
         // patterns that reach beyond the direct kernel's patch: the blurred pyramid, frame by frame (not the default parameters)
         for (int k = 0; k < ng; k++) {
