@@ -170,9 +170,19 @@ __global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad, siz
     const int B = ORB_BORDER, pw = d.w + 2 * B, ph = d.h + 2 * B;
     int px, py;
     if (!SIDES) {
-        px = blockIdx.x * 256 + threadIdx.x;
+        // four columns per thread: a dword whose columns all lie over the level's interior is the same dword of the mirrored row
+        // (the row pitch and the border are multiples of 4); the dwords over the side strips go byte by byte
+        const int px4 = (blockIdx.x * 256 + threadIdx.x) * 4;
         py = blockIdx.y < B ? blockIdx.y : ph - 2 * B + blockIdx.y;
-        if (px >= pw) return;
+        if (px4 >= pw) return;
+        uint8_t* p4 = pad + d.pad_off;
+        const size_t srow = (size_t)(mis_reflect101(py - B, d.h) + B) * d.pp, drow = (size_t)py * d.pp;
+        if (px4 >= B && px4 + 3 < B + d.w) {
+            *reinterpret_cast<unsigned*>(p4 + drow + px4) = *reinterpret_cast<const unsigned*>(p4 + srow + px4);
+        } else {
+            for (int k = 0; k < 4 && px4 + k < pw; k++) p4[drow + px4 + k] = p4[srow + mis_reflect101(px4 + k - B, d.w) + B];
+        }
+        return;
     } else {
         const int row = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
         if (row >= d.h) return;
@@ -1085,7 +1095,7 @@ int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatur
     }
     const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
     hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h + 3) / 4, 1, L.n * nf), dim3(256), 0, st, L, W.pad, ws);   // sides first: the corners mirror them
-    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 255) / 256, 2 * ORB_BORDER, L.n * nf), dim3(256), 0, st, L, W.pad, ws);
+    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 1023) / 1024, 2 * ORB_BORDER, L.n * nf), dim3(256), 0, st, L, W.pad, ws);
     dim3 gmap((d0.w + FT_COLS - 1) / FT_COLS, (d0.h + FT_ROWS - 1) / FT_ROWS, L.n * nf);
     hipLaunchKernelGGL(fast_nms_kernel, gmap, dim3(256), 0, st, L, W.pad, W.hist, W.tile_cnt, W.surv_xy, W.surv_sc, ws);
     hipLaunchKernelGGL(fast_cut_kernel, dim3(L.n, nf), dim3(256), 0, st, L, W.hist, W.thr, W.flags, ws);
