@@ -781,7 +781,7 @@ struct MatchWorkspace : MisWorkspace {
     hipEvent_t ev_phase0 = nullptr, ev_side_done = nullptr, ev_phase1 = nullptr, ev_third_done = nullptr, ev_matches = nullptr;
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
-    hipEvent_t ev_draw1 = nullptr, ev_side_hyp0 = nullptr;
+    hipEvent_t ev_draw1 = nullptr, ev_side_hyp0 = nullptr, ev_b2_replay = nullptr;
     hipEvent_t tev[8] = {nullptr};   // MIS_MATCH_TRACE: timing events (2-NN end, phase 0 end, draw 1 end, main chain end, side end, third end, tails of phase 0 end)
     hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
@@ -802,6 +802,7 @@ struct MatchWorkspace : MisWorkspace {
         if (ev_knn) hipEventDestroy(ev_knn);
         if (ev_draw1) hipEventDestroy(ev_draw1);
         if (ev_side_hyp0) hipEventDestroy(ev_side_hyp0);
+        if (ev_b2_replay) hipEventDestroy(ev_b2_replay);
     }
 };
 
@@ -1042,12 +1043,26 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // MIS_HYP_ORDER=1 (experiment): the main chain's second-phase solves wait for the side chain's first solves.  Measured: the side
     // chain ends where it did (+ 2.65 ms behind the 2-NN pass: its solves are not slowed by the others'), the main chain 0.55 ms later.
     static const int hyp_order = getenv("MIS_HYP_ORDER") ? atoi(getenv("MIS_HYP_ORDER")) : 0;
+    // MIS_B2_SPLIT (experiment, default 0): the side chain's second phase -- a handful of problems with few points that run all 2000
+    // iterations, 0.5 ms -- taken off it (the replay alone first) and run behind the main chain (1) or behind the first estimation's
+    // tails on the third stream (2).  Measured: the side chain then ends at + 2.27 ms instead of + 2.66, and the chain that took the
+    // second phase at + 2.65: the matcher ends where it did.
+    static const int b2_split = getenv("MIS_B2_SPLIT") ? atoi(getenv("MIS_B2_SPLIT")) : 0;
     if (!ws->ev_draw1) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_draw1, hipEventDisableTiming));
     if (!ws->ev_side_hyp0) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_hyp0, hipEventDisableTiming));
     {
         HomoSync sy;
         if (compose_gate == 4) { sy.rec = ws->ev_draw1; sy.rec_pos = 2; ws->ev_gate = ws->ev_draw1; }      // gate 4 (experiment): behind the side chain's first draw
         if (hyp_order) sy.rec_hyp0 = ws->ev_side_hyp0;
+        if (b2_split) {
+            // the side chain was the longest (+ 2.66 ms behind the 2-NN pass): its second phase -- a handful of problems with few
+            // points that run all 2000 iterations -- waited behind the 1.3 ms tails of the finishers although it only needs the
+            // replay's verdict.  The replay alone first; the second phase goes behind the main chain, which ends first
+            if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 3, ws->side, &sy)) != MIS_OK) return rc;
+            if (!ws->ev_b2_replay) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_b2_replay, hipEventDisableTiming));
+            MIS_HIP(ctx, hipEventRecord(ws->ev_b2_replay, ws->side));
+            if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 4, ws->side)) != MIS_OK) return rc;
+        } else
         if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 2, ws->side, &sy)) != MIS_OK) return rc;
     }
     MIS_HIP(ctx, hipEventRecord(ws->ev_side_done, ws->side));
@@ -1055,6 +1070,10 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase0, 0));
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 11, ws->third)) != MIS_OK) return rc;
     mark(6, ws->third);
+    if (b2_split == 2) {      // (experiment: behind the first estimation's tails on the third stream -- that chain then ends at + 2.65 ms)
+        MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_b2_replay, 0));
+        if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 1, ws->third)) != MIS_OK) return rc;
+    }
     {
         // gate 2: behind the second phase's draw of the main chain -- by then the tails (third stream) and the second estimations
         // (side stream), released together with it, hold their compute units
@@ -1069,6 +1088,10 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // refinement of the phase-0 finishers on the third stream it ended the matcher 0.6 ms later); their inlier-only second
     // estimation goes to the third stream instead
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 13, st)) != MIS_OK) return rc;
+    if (b2_split == 1) {      // the side chain's second phase, behind the main chain (which ends first: + 2.17 ms)
+        MIS_HIP(ctx, hipStreamWaitEvent(st, ws->ev_b2_replay, 0));
+        if ((rc = homo_batch_run(ctx, &ws->b2, rt, p->max_iters, cf, 1, st)) != MIS_OK) return rc;
+    }
     mark(3, st);
     MIS_HIP(ctx, hipStreamWaitEvent(ws->third, ws->ev_phase1, 0));
     hipLaunchKernelGGL(second_calls_kernel, dim3((np + 127) / 128), dim3(128), 0, ws->third, np, (const HomoCall*)ws->b1.calls, (const HomoResult*)ws->b1.results,
