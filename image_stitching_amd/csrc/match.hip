@@ -351,6 +351,127 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* 
     }
 }
 
+// The same pass with the train tiles copied global -> LDS by LDS-DMA (knn2_hamming_mfma4_kernel): no staging registers, no ds_write,
+// the copy of tile t + 2 runs beside tile t's MFMAs.  A DMA instruction writes 64 x 16 bytes to consecutive LDS addresses, so the
+// image has a 256-byte pitch and its 16-byte slots are XOR-swizzled (slot s of row R at position s ^ (R & 15): the fragment reads
+// of a ds_read_b128 lane group -- 16 rows, one slot -- fall in 16 different positions); each lane fetches the slot its LDS
+// position holds.  The instructions are inline assembly (the compiler would wait for every copy before the next LDS read); the
+// wait is the s_waitcnt vmcnt(0) in front of the tile's barrier.
+__device__ __forceinline__ void hm_dma(const int8_t* base, unsigned voff, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_off) : "memory", "m0");
+}
+template <bool UPD>
+__device__ __forceinline__ void hm_tile4(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16i& cb, v4i* a, const v4i (&bq)[2][8], HmKeys& K,
+                                         const int8_t* lds_next, uint32_t lds_store, const int8_t* gnext, const unsigned (&voff)[2], const unsigned (&aoff)[8]) {
+    hm_dma(gnext, voff[0], lds_store);              // tile t + 2 into the buffer tile t left (its fragments were read during tile t - 1)
+    hm_dma(gnext, voff[1], lds_store + 1024);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int slot = 2 * s8 + half;
+            if (half == 0) { if (s8 == 0) HM_MFMA_FIRST(accA, a[0], bq[0][0], cb); else HM_MFMA_ACC(accA, a[s8], bq[0][s8]); }
+            else {
+                if (s8 == 0) HM_MFMA_FIRST(accB, a[0], bq[1][0], cb); else HM_MFMA_ACC(accB, a[s8], bq[1][s8]);
+                a[s8] = *reinterpret_cast<const v4i*>(lds_next + aoff[s8]);      // the next tile's fragment
+            }
+            if (slot >= 2) {
+                if (UPD) {
+                    const int lo = (slot - 2) * 32 / 14, hi = (slot - 1) * 32 / 14;
+#pragma unroll
+                    for (int i = lo; i < hi; i++) hm_update(K, i >> 4, i < 16 ? prevA[i] : prevB[i - 16]);
+                }
+                if (slot >= 4) {
+                    const int lo = (slot - 4) * 16 / 12, hi = (slot - 3) * 16 / 12;
+#pragma unroll
+                    for (int g = lo; g < hi; g++) cb[g] += 32;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void knn2_hamming_mfma4_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
+                                                                 float* dist2, const HmJob* jobs) {
+    __shared__ __attribute__((aligned(1024))) int8_t tr[2][32 * 256];
+    const HmJob job = jobs[blockIdx.x];
+    if (job.pair < 0) return;                       // padding of the XCD interleave
+    const PairDesc pd = pairs[job.pair];
+    const bool fwd = job.dir == 0;
+    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
+    const int nq = feats[qi].n, nt = feats[ti].n;
+    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
+    const int q0 = job.q0;
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int8_t* qx = xp + fr[qi].query_off;
+    const int8_t* tx = xp + fr[ti].train_off;
+    HmKeys K;
+    K.k0[0] = K.k0[1] = K.k1[0] = K.k1[1] = HM_NONE;
+    const int ntiles = (nt + 31) / 32;
+    if (ntiles > 0) {
+        v4i bq[2][8];
+#pragma unroll
+        for (int set = 0; set < 2; set++)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++)
+                bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
+        v16i cb;
+#pragma unroll
+        for (int g = 0; g < 16; g++) cb[g] = HM_FBIAS + (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        // the wave's two copy instructions of a tile: rows 8 wave + 4 j + (lane >> 4), LDS position lane & 15 <- global slot position ^ (row & 15)
+        unsigned voff[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int R = 8 * wave + 4 * j + (lane >> 4);
+            voff[j] = (unsigned)(R * 256 + 16 * ((lane & 15) ^ (R & 15)));
+        }
+        // fragment s8 of lane (r, h): slot 2 s8 + h of row r
+        unsigned aoff[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) aoff[s8] = (unsigned)(r * 256 + 16 * ((2 * s8 + h) ^ (r & 15)));
+        const uint32_t lds0 = (uint32_t)(uintptr_t)&tr[0][0] + (uint32_t)(8 * wave) * 256, lds1 = (uint32_t)(uintptr_t)&tr[1][0] + (uint32_t)(8 * wave) * 256;
+        auto gtile = [&](int t) { return tx + (size_t)min(t, ntiles - 1) * 32 * 256; };      // (the blocks are padded: any tile of the set is readable)
+        hm_dma(gtile(0), voff[0], lds0); hm_dma(gtile(0), voff[1], lds0 + 1024);
+        hm_dma(gtile(1), voff[0], lds1); hm_dma(gtile(1), voff[1], lds1 + 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        v4i a[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][aoff[s8]]);
+        v16i A0, B0, A1, B1;
+        hm_tile4<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(2), voff, aoff);
+        int t = 1;
+        for (; t + 1 < ntiles; t += 2) {
+            hm_tile4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff);
+            hm_tile4<true>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(t + 3), voff, aoff);
+        }
+        const bool odd_last = t < ntiles;
+        if (odd_last) hm_tile4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff);
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int ka = odd_last ? A1[g] : A0[g], kb = odd_last ? B1[g] : B0[g];
+            hm_update(K, 0, (ka & (HM_MAX_TRAINS - 1)) < nt ? ka : HM_NONE);
+            hm_update(K, 1, (kb & (HM_MAX_TRAINS - 1)) < nt ? kb : HM_NONE);
+        }
+    }
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+        const int o0 = __shfl_xor(K.k0[set], 32), o1 = __shfl_xor(K.k1[set], 32);
+        const int b0 = min(K.k0[set], o0), b1 = min(max(K.k0[set], o0), min(K.k1[set], o1));
+        const int q = q0 + wave * 64 + set * 32 + r;
+        if (h == 0 && q < nq) {
+            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
+            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
+            dist2[(off + q) * 2] = (float)(v0 ? (b0 - HM_FBIAS) >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? (b1 - HM_FBIAS) >> 13 : 1 << 30);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K8: exact 2-NN, L2 on MFMA ----
 // SIFT descriptors are integer valued (0..255, stored as f32): they are exact in fp16, every dot
 // product of two 128-D descriptors is an integer < 2^24 and therefore exact in the f32 accumulator of
@@ -938,7 +1059,8 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         } else {
             memcpy(Hh + h_jobs, hm_jobs.data(), sizeof(HmJob) * hm_jobs.size());
             MIS_HIP(ctx, hipMemcpyAsync(L + o_jobs, Hh + h_jobs, sizeof(HmJob) * hm_jobs.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+            static const bool hm_dma_on = getenv("MIS_KNN_DMA") ? atoi(getenv("MIS_KNN_DMA")) != 0 : true;      // MIS_KNN_DMA=0: the form that stages the train tiles through registers (0.645 ms; 0.58 with LDS-DMA)
+            hipLaunchKernelGGL(hm_dma_on ? knn2_hamming_mfma4_kernel : knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
                                (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist, (const HmJob*)(L + o_jobs));
         }
     } else {
