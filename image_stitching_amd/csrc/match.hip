@@ -1105,7 +1105,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // MIS_COMPOSE_GATE: 0 = a stream fenced by mis_match_knn_fence (the job's speculative composition) starts behind the 2-NN pass,
     // 1 = behind the first RANSAC phase of the first estimation (draw, 4-point solves, replay, masks: 0.7 ms of large workgroups
     // that wait for room once the composition's grids fill the device)
-    static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 2;
+    static const int compose_gate = getenv("MIS_COMPOSE_GATE") ? atoi(getenv("MIS_COMPOSE_GATE")) : 4;
     static const bool trace_ev = getenv("MIS_MATCH_TRACE") != nullptr;
     auto mark = [&](int i, hipStream_t s_) {      // diagnostics: device time stamps of the chains (printed with the host's when MIS_MATCH_TRACE is set)
         if (!trace_ev) return;
@@ -1174,7 +1174,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     if (!ws->ev_side_hyp0) MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_side_hyp0, hipEventDisableTiming));
     {
         HomoSync sy;
-        if (compose_gate == 4) { sy.rec = ws->ev_draw1; sy.rec_pos = 2; ws->ev_gate = ws->ev_draw1; }      // gate 4 (experiment): behind the side chain's first draw
+        if (compose_gate == 4) { sy.rec = ws->ev_draw1; sy.rec_pos = 2; ws->ev_gate = ws->ev_draw1; }      // gate 4 (the default): behind the side chain's first draw, 0.05 - 0.1 ms behind the first phase -- the tails and that draw hold their compute units by then
         if (hyp_order) sy.rec_hyp0 = ws->ev_side_hyp0;
         if (b2_split) {
             // the side chain was the longest (+ 2.66 ms behind the 2-NN pass): its second phase -- a handful of problems with few

@@ -165,8 +165,8 @@ int mis_matches_free(MisMatchesInfo* m, int count);
 /* Ordering aid for a caller that overlaps other device work with a matcher call made by another host thread (the
  * job's speculative composition): mis_match_sequence = number of matcher calls this context has started;
  * mis_match_knn_fence(ctx, stream, mis_match_sequence(ctx) + 1 taken BEFORE the other thread calls the matcher, ms)
- * makes `stream` wait for the point of that call behind which other work shares the device well: by default the second draw of
- * the main RANSAC chain, 0.9 ms behind the 2-NN pass (the chains' kernels are few large workgroups that wait for room once another
+ * makes `stream` wait for the point of that call behind which other work shares the device well: by default the first draw of
+ * the side RANSAC chain, 0.55 ms behind the 2-NN pass (the chains' kernels are few large workgroups that wait for room once another
  * stream's grids fill the compute units; from that point on they hold theirs).  MIS_COMPOSE_GATE in the environment moves it:
  * 1 = the end of the first RANSAC phase, 0 = the end of the 2-NN pass. */
 long long mis_match_sequence(MisContext* ctx);
