@@ -781,8 +781,11 @@ __global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, con
 // lane computes c, s, t), the lane's share of the rotation, four quad arg-max re-scans over the rotated values in registers.
 // A wave holds 16 solves and a workgroup 64 (66 KB of LDS: the same 128 solves per compute unit, on eight waves instead of
 // two).  Arithmetic per element and visiting order of every scan are those of the serial loops.
-constexpr int HQ_HYPS = 64;           // solves per workgroup (4 lanes each)
-constexpr int HQ_STRIDE = 65;         // doubles between consecutive elements of a solve (solve h at + h): the quad's lanes, same h, different elements, fall in different banks
+#ifndef MIS_HQ_HYPS
+#define MIS_HQ_HYPS 64
+#endif
+constexpr int HQ_HYPS = MIS_HQ_HYPS;  // solves per workgroup (4 lanes each)
+constexpr int HQ_STRIDE = HQ_HYPS + 1;         // doubles between consecutive elements of a solve (solve h at + h): the quad's lanes, same h, different elements, fall in different banks
 constexpr int HQ_ELEMS = 127;         // 36 (strict upper triangle) + 9 (W) + 81 (V) + 1 (a dummy element: the target of the pairs that do not exist)
 struct QSlot {
     double* base;
