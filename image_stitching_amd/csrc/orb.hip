@@ -140,8 +140,13 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             const int o = xs[k] - base, mx1 = ms[k], mx0 = 256 - mx1;
             const bool ok = k < nvalid;
             const int oo = ok ? o : 0;
-            const unsigned h0 = byte_at(a0, a1, a2, oo) * mx0 + byte_at(a0, a1, a2, oo + 1) * mx1;
-            const unsigned h1 = byte_at(b0, b1, b2, oo) * mx0 + byte_at(b0, b1, b2, oo + 1) * mx1;
+            // bytes oo, oo + 1 of the 12 loaded (oo <= 10): one funnel shift of the dword pair that holds them
+            const bool p1 = oo >= 4, p2 = oo >= 8;
+            const unsigned alo = p2 ? a2 : (p1 ? a1 : a0), ahi = p2 ? 0u : (p1 ? a2 : a1);
+            const unsigned blo = p2 ? b2 : (p1 ? b1 : b0), bhi = p2 ? 0u : (p1 ? b2 : b1);
+            const unsigned ta = __builtin_amdgcn_alignbyte(ahi, alo, (unsigned)oo & 3u), tb = __builtin_amdgcn_alignbyte(bhi, blo, (unsigned)oo & 3u);
+            const unsigned h0 = (ta & 255u) * mx0 + ((ta >> 8) & 255u) * mx1;
+            const unsigned h1 = (tb & 255u) * mx0 + ((tb >> 8) & 255u) * mx1;
             res |= ok ? ((h0 * my0 + h1 * my1 + (1u << 15)) >> 16) << (8 * k) : 0u;
         }
     } else {
