@@ -442,6 +442,9 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma4_kernel(const FeatDev* 
         v4i a[8];
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][aoff[s8]]);
+        // every wave has tile 0's fragments in registers before any wave's copy of tile 2 lands on them (a wave that leaves the
+        // barrier above late -- the older waves of the CU's other workgroups hold the issue slots -- would read rows of tile 2)
+        __syncthreads();
         v16i A0, B0, A1, B1;
         hm_tile4<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(2), voff, aoff);
         int t = 1;
@@ -468,6 +471,163 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma4_kernel(const FeatDev* 
             const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
             idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
             dist2[(off + q) * 2] = (float)(v0 ? (b0 - HM_FBIAS) >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? (b1 - HM_FBIAS) >> 13 : 1 << 30);
+        }
+    }
+}
+
+// The same pass on the fp4 path of the matrix cores (knn2_hamming_fp4_kernel): v_mfma_scale_f32_32x32x64_f8f6f4 multiplies 64
+// E2M1 values per lane pair and instruction in the time the int8 instruction takes for 32, so a 32 x 32 tile of distances is 4
+// instructions per query set instead of 8.  A descriptor bit becomes one nibble: +4 (0x6) where a train bit is set, -4 (0xE) where
+// it is clear, the opposite signs for a query; both operands carry the block scale 2^4, so a product is -4096 where the bits agree
+// and +4096 where they differ, and a row of 256 sums to 8192 hamming - 2^20.  The seed of the accumulator is the float 2^20 +
+// trainIdx: every partial sum is an integer below 2^24, exact in f32, and the result is the float 8192 hamming + trainIdx -- ordered
+// like the int8 kernel's keys, and v_min_f32 / v_med3_f32 take it as it is.  Expanded rows are 128 bytes (a tile of 32 trains =
+// 4 KB = one LDS-DMA instruction per wave); slot s of row R sits at position s ^ ((R >> 1) & 7) of its row, which spreads the
+// fragment reads of 16 consecutive rows (two rows per 256 bytes) over 16 different 16-byte positions.
+__global__ __launch_bounds__(256) void hamming_expand4_kernel(const FeatDev* feats, const HmFrame* fr, int8_t* out) {
+    const FeatDev F = feats[blockIdx.y];
+    const int npad = (F.n + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
+    const int item = blockIdx.x * 256 + threadIdx.x, d = item >> 3, w = item & 7;
+    if (d >= npad) return;
+    const bool live = d < F.n;
+    const unsigned x = live ? reinterpret_cast<const unsigned*>(F.desc)[(size_t)d * 8 + w] : 0u;
+    unsigned tq[4], qq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned t = (x >> (8 * k)) & 255u;                 // bit i -> bit 4 i + 3 (the sign of nibble i)
+        t = (t | (t << 12)) & 0x000F000Fu;
+        t = (t | (t << 6)) & 0x03030303u;
+        t = (t | (t << 3)) & 0x11111111u;
+        tq[k] = live ? (0xEEEEEEEEu ^ (t << 3)) : 0u;       // +4 (set) / -4 (clear)
+        qq[k] = live ? (0x66666666u ^ (t << 3)) : 0u;       // -4 (set) / +4 (clear)
+    }
+    *reinterpret_cast<uint4*>(out + fr[blockIdx.y].train_off + (size_t)d * 128 + 16 * w) = make_uint4(tq[0], tq[1], tq[2], tq[3]);
+    *reinterpret_cast<uint4*>(out + fr[blockIdx.y].query_off + (size_t)d * 128 + 16 * w) = make_uint4(qq[0], qq[1], qq[2], qq[3]);
+}
+#define HM4_MFMA_FIRST(D, A, B, C, SA, SB) \
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&v"(D) : "v"(A), "v"(B), "v"(C), "v"(SA), "v"(SB))
+#define HM4_MFMA_ACC(D, A, B, SA, SB) \
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(D) : "v"(A), "v"(B), "v"(SA), "v"(SB))
+typedef float v16f __attribute__((ext_vector_type(16)));
+// Two or three keys of each query set in a single statement: between two statements of inline assembly of which the second reads
+// a register the first wrote the compiler pads a wait state (s_nop) that plain vector instructions do not need -- 16 of them per
+// tile beside 72 instructions.
+#define HM_UPD_PAIR(KA, KB) "v_med3_f32 %1, %0, %1, " KA "\n\tv_min_f32 %0, %0, " KA "\n\tv_med3_f32 %3, %2, %3, " KB "\n\tv_min_f32 %2, %2, " KB "\n\t"
+__device__ __forceinline__ void hm_update_pairs2(HmKeys& K, int a0, int b0, int a1, int b1) {
+    asm volatile(HM_UPD_PAIR("%4", "%5") HM_UPD_PAIR("%6", "%7") : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+__device__ __forceinline__ void hm_update_pairs3(HmKeys& K, int a0, int b0, int a1, int b1, int a2, int b2) {
+    asm volatile(HM_UPD_PAIR("%4", "%5") HM_UPD_PAIR("%6", "%7") HM_UPD_PAIR("%8", "%9")
+                 : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
+}
+template <bool UPD>
+__device__ __forceinline__ void hm_tile_fp4(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16f& cb, v4i* a, const v4i (&bq)[2][4], HmKeys& K,
+                                            const int8_t* lds_next, uint32_t lds_store, const int8_t* gnext, unsigned voff, const unsigned (&aoff)[4], int sa, int sb) {
+    hm_dma(gnext, voff, lds_store);                 // tile t + 2 into the buffer tile t left
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int slot = 2 * s4 + half;
+            if (half == 0) { if (s4 == 0) HM4_MFMA_FIRST(accA, a[0], bq[0][0], cb, sa, sb); else HM4_MFMA_ACC(accA, a[s4], bq[0][s4], sa, sb); }
+            else {
+                if (s4 == 0) HM4_MFMA_FIRST(accB, a[0], bq[1][0], cb, sa, sb); else HM4_MFMA_ACC(accB, a[s4], bq[1][s4], sa, sb);
+                a[s4] = *reinterpret_cast<const v4i*>(lds_next + aoff[s4]);      // the next tile's fragment
+            }
+            // the previous tile's 32 keys over slots 2 .. 7 (its chains ended in its slots 6 and 7), the two query sets in turn (a
+            // set's next update reads the minimum its last one wrote: back to back that is a wait state); the seeds advance in slots 4 .. 7
+            if (slot >= 2) {
+                if (UPD) {
+                    const int lo = (slot - 2) * 16 / 6, hi = (slot - 1) * 16 / 6;       // key registers lo .. hi - 1 of both sets: 2 or 3
+                    if (hi - lo == 2) hm_update_pairs2(K, prevA[lo], prevB[lo], prevA[lo + 1], prevB[lo + 1]);
+                    else hm_update_pairs3(K, prevA[lo], prevB[lo], prevA[lo + 1], prevB[lo + 1], prevA[lo + 2], prevB[lo + 2]);
+                }
+                if (slot >= 4) {
+#pragma unroll
+                    for (int g = (slot - 4) * 4; g < (slot - 3) * 4; g++) cb[g] += 32.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void knn2_hamming_fp4_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
+                                                               float* dist2, const HmJob* jobs) {
+    __shared__ __attribute__((aligned(1024))) int8_t tr[2][32 * 128];
+    const HmJob job = jobs[blockIdx.x];
+    if (job.pair < 0) return;                       // padding of the XCD interleave
+    const PairDesc pd = pairs[job.pair];
+    const bool fwd = job.dir == 0;
+    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
+    const int nq = feats[qi].n, nt = feats[ti].n;
+    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
+    const int q0 = job.q0;
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int8_t* qx = xp + fr[qi].query_off;
+    const int8_t* tx = xp + fr[ti].train_off;
+    HmKeys K;
+    K.k0[0] = K.k0[1] = K.k1[0] = K.k1[1] = HM_NONE;           // (as a float: 1.7e38)
+    const int ntiles = (nt + 31) / 32;
+    if (ntiles > 0) {
+        // the wave's 2 x 32 queries as B fragments (step s, lane (r, h): nibbles 64 s + 32 h .. + 31 of query r)
+        v4i bq[2][4];
+#pragma unroll
+        for (int set = 0; set < 2; set++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+                bq[set][s4] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 128 + 32 * s4 + 16 * h);
+        v16f cb;
+#pragma unroll
+        for (int g = 0; g < 16; g++) cb[g] = (float)((1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h);
+        const int sa = 127 + 4, sb = 127 + 4;       // E8M0 block scales 2^4 (byte 0 of the scale operands)
+        // the wave's copy instruction of a tile: row 8 wave + (lane >> 3), LDS position lane & 7 <- global slot position ^ ((row >> 1) & 7)
+        const int R = 8 * wave + (lane >> 3);
+        const unsigned voff = (unsigned)(R * 128 + 16 * ((lane & 7) ^ ((R >> 1) & 7)));
+        unsigned aoff[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) aoff[s4] = (unsigned)(r * 128 + 16 * ((2 * s4 + h) ^ ((r >> 1) & 7)));
+        const uint32_t lds0 = (uint32_t)(uintptr_t)&tr[0][0] + (uint32_t)wave * 1024, lds1 = (uint32_t)(uintptr_t)&tr[1][0] + (uint32_t)wave * 1024;
+        auto gtile = [&](int t) { return tx + (size_t)min(t, ntiles - 1) * 32 * 128; };      // (the blocks are padded: any tile of the set is readable)
+        hm_dma(gtile(0), voff, lds0);
+        hm_dma(gtile(1), voff, lds1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        v4i a[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) a[s4] = *reinterpret_cast<const v4i*>(&tr[0][aoff[s4]]);
+        __syncthreads();                            // (as in knn2_hamming_mfma4_kernel: tile 0 is in every wave's registers before tile 2 is copied over it)
+        v16i A0, B0, A1, B1;
+        hm_tile_fp4<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(2), voff, aoff, sa, sb);
+        int t = 1;
+        for (; t + 1 < ntiles; t += 2) {
+            hm_tile_fp4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff, sa, sb);
+            hm_tile_fp4<true>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(t + 3), voff, aoff, sa, sb);
+        }
+        const bool odd_last = t < ntiles;
+        if (odd_last) hm_tile_fp4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff, sa, sb);
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int ka = odd_last ? A1[g] : A0[g], kb = odd_last ? B1[g] : B0[g];
+            hm_update(K, 0, ((int)__int_as_float(ka) & (HM_MAX_TRAINS - 1)) < nt ? ka : HM_NONE);
+            hm_update(K, 1, ((int)__int_as_float(kb) & (HM_MAX_TRAINS - 1)) < nt ? kb : HM_NONE);
+        }
+    }
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+        // (bit patterns of non-negative floats order like the floats)
+        const int o0 = __shfl_xor(K.k0[set], 32), o1 = __shfl_xor(K.k1[set], 32);
+        const int b0 = min(K.k0[set], o0), b1 = min(max(K.k0[set], o0), min(K.k1[set], o1));
+        const int q = q0 + wave * 64 + set * 32 + r;
+        if (h == 0 && q < nq) {
+            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
+            const int i0 = v0 ? (int)__int_as_float(b0) : 0, i1 = v1 ? (int)__int_as_float(b1) : 0;
+            idx2[(off + q) * 2] = v0 ? (i0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (i1 & (HM_MAX_TRAINS - 1)) : -1;
+            dist2[(off + q) * 2] = (float)(v0 ? i0 >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? i1 >> 13 : 1 << 30);
         }
     }
 }
@@ -1041,9 +1201,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         std::vector<HmFrame> hf(n);
         Carver lc;
         const size_t o_fr = lc.take(sizeof(HmFrame) * n), o_jobs = lc.take(sizeof(HmJob) * std::max<size_t>(hm_jobs.size(), 1));
+        static const bool hm_v1 = getenv("MIS_KNN_MFMA_V1") != nullptr;     // diagnostics: round 2's form of the pass
+        static const bool hm_fp4_env = getenv("MIS_KNN_FP4") ? atoi(getenv("MIS_KNN_FP4")) != 0 : true;      // MIS_KNN_FP4=0: the int8 forms of the pass
+        const bool hm_fp4 = hm_fp4_env && !hm_v1 && !hm_jobs.empty();
+        const size_t row_bytes = hm_fp4 ? 128 : 256;
         for (int i = 0; i < n; i++) {
             const size_t rows = (size_t)(std::max(feats[i].n, 1) + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
-            hf[i].train_off = lc.take(rows * 256); hf[i].query_off = lc.take(rows * 256);
+            hf[i].train_off = lc.take(rows * row_bytes); hf[i].query_off = lc.take(rows * row_bytes);
         }
         MIS_HIP(ctx, ws->l2.reserve(lc.off));
         uint8_t* L = (uint8_t*)ws->l2.p;
@@ -1051,8 +1215,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         memcpy(h_fr, hf.data(), sizeof(HmFrame) * n);
         MIS_HIP(ctx, hipMemcpyAsync(L + o_fr, h_fr, sizeof(HmFrame) * n, hipMemcpyHostToDevice, st));
         const int maxpad = (maxq + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
-        hipLaunchKernelGGL(hamming_expand_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
-        static const bool hm_v1 = getenv("MIS_KNN_MFMA_V1") != nullptr;     // diagnostics: round 2's form of the pass
+        hipLaunchKernelGGL(hm_fp4 ? hamming_expand4_kernel : hamming_expand_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
         if (hm_v1 || hm_jobs.empty()) {
             hipLaunchKernelGGL(knn2_hamming_mfma_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
                                (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist);
@@ -1060,7 +1223,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             memcpy(Hh + h_jobs, hm_jobs.data(), sizeof(HmJob) * hm_jobs.size());
             MIS_HIP(ctx, hipMemcpyAsync(L + o_jobs, Hh + h_jobs, sizeof(HmJob) * hm_jobs.size(), hipMemcpyHostToDevice, st));
             static const bool hm_dma_on = getenv("MIS_KNN_DMA") ? atoi(getenv("MIS_KNN_DMA")) != 0 : true;      // MIS_KNN_DMA=0: the form that stages the train tiles through registers (0.645 ms; 0.58 with LDS-DMA)
-            hipLaunchKernelGGL(hm_dma_on ? knn2_hamming_mfma4_kernel : knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+            hipLaunchKernelGGL(hm_fp4 ? knn2_hamming_fp4_kernel : hm_dma_on ? knn2_hamming_mfma4_kernel : knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
                                (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist, (const HmJob*)(L + o_jobs));
         }
     } else {

@@ -138,6 +138,39 @@ def test_match_empty_and_tiny_feature_sets(ctx, oracle_mod):
         _compare_matches_info(g, o)
 
 
+def test_match_full_size_sets_repeatable_and_exact(ctx, oracle_mod):
+    """8 frames x 4096 descriptors (128 train tiles per pass, every compute unit holding several workgroups of the matrix pass):
+    three runs give identical lists, and sampled pairs equal the oracle's.  Frame i holds a shared base set with a few bits flipped
+    per descriptor, so the ratio test passes and the lists are long; the first rows (train tile 0) are part of every list."""
+    import image_stitching_amd as isa
+    from image_stitching_amd.stitching import KP_DTYPE
+    rng = np.random.default_rng(97)
+    n, nf = 4096, 8
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sets = []
+    for i in range(nf):
+        d = base.copy()
+        flips = rng.integers(0, 256, (n, 6))              # up to 6 flipped bits per descriptor
+        for c in range(6):
+            d[np.arange(n), flips[:, c] >> 3] ^= (1 << (flips[:, c] & 7)).astype(np.uint8)
+        d = d[rng.permutation(n)] if i else d
+        k = np.zeros(n, KP_DTYPE)
+        k["x"] = rng.uniform(0, 3840, n)
+        k["y"] = rng.uniform(0, 2160, n)
+        sets.append((k, d))
+    feats = [isa.ImageFeatures.upload(ctx, (3840, 2160), k, d, i) for i, (k, d) in enumerate(sets)]
+    runs = [isa.BestOf2NearestMatcher(ctx, 0.32)(feats) for _ in range(3)]
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a.matches, b.matches) and a.confidence == b.confidence
+    for i, j in ((0, 1), (0, 7), (2, 5), (3, 4), (6, 7), (1, 6)):
+        o = oracle_mod.match_pair(_feat_dict(*sets[i], (3840, 2160)), _feat_dict(*sets[j], (3840, 2160)))
+        g = runs[0][i * nf + j]
+        assert len(g.matches) > 2000
+        assert np.array_equal(g.matches, o["matches"].astype(g.matches.dtype))
+        assert np.array_equal(g.inliers_mask, o["inliers_mask"]) and g.confidence == o["confidence"]
+
+
 def _sift_like(rng, n):
     """SIFT-style descriptors: integer valued 0..255 stored as f32 (SURVEY config 5 surrogate)."""
     d = rng.gamma(0.6, 30.0, (n, 128))
