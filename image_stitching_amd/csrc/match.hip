@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* 
         v4i a[8];
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][r * HM_PITCH + 32 * s8 + 16 * h]);
+        __syncthreads();                            // tile 0 is in every wave's registers before the first tile body stores tile 2 over it
         v16i A0, B0, A1, B1;
         hm_tile<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], tr[0], gtile(2), r, h, prow, pcol);
         int t = 1;
