@@ -510,16 +510,26 @@ __global__ __launch_bounds__(256) void hamming_expand4_kernel(const FeatDev* fea
 #define HM4_MFMA_ACC(D, A, B, SA, SB) \
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(D) : "v"(A), "v"(B), "v"(SA), "v"(SB))
 typedef float v16f __attribute__((ext_vector_type(16)));
-// Two or three keys of each query set in a single statement: between two statements of inline assembly of which the second reads
-// a register the first wrote the compiler pads a wait state (s_nop) that plain vector instructions do not need -- 16 of them per
-// tile beside 72 instructions.
-#define HM_UPD_PAIR(KA, KB) "v_med3_f32 %1, %0, %1, " KA "\n\tv_min_f32 %0, %0, " KA "\n\tv_med3_f32 %3, %2, %3, " KB "\n\tv_min_f32 %2, %2, " KB "\n\t"
-__device__ __forceinline__ void hm_update_pairs2(HmKeys& K, int a0, int b0, int a1, int b1) {
-    asm volatile(HM_UPD_PAIR("%4", "%5") HM_UPD_PAIR("%6", "%7") : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+// The key selections of the fp4 pass, three keys of each query set at a time: of (x, y, z) only the minimum m1 and the median m2 can
+// enter a query's best two (the keys of a query are distinct: they carry the train index), and merging the sorted pair (m1, m2)
+// into the sorted pair (k0, k1) is k1' = med3(k0, m1, min(k1, m2)) -- min(k1, m2) is never below min(k0, m1), so the median is
+// min(max(k0, m1), min(k1, m2)), the second smallest of the four -- and k0' = min(k0, m1): 5 instructions for 3 keys where the
+// key-by-key form takes 6.  One statement per group of both sets: between two statements of inline assembly of which the second
+// reads a register the first wrote the compiler pads a wait state (s_nop) that plain vector instructions do not need.
+__device__ __forceinline__ void hm_update_triples(HmKeys& K, int x0, int x1, int x2, int y0, int y1, int y2) {
+    int t0, t1, u0, u1;
+    asm volatile(
+        "v_min3_f32 %4, %8, %9, %10\n\tv_med3_f32 %5, %8, %9, %10\n\tv_min3_f32 %6, %11, %12, %13\n\tv_med3_f32 %7, %11, %12, %13\n\t"
+        "v_min_f32 %5, %1, %5\n\tv_min_f32 %7, %3, %7\n\t"
+        "v_med3_f32 %1, %0, %4, %5\n\tv_med3_f32 %3, %2, %6, %7\n\t"
+        "v_min_f32 %0, %0, %4\n\tv_min_f32 %2, %2, %6"
+        : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2));
 }
-__device__ __forceinline__ void hm_update_pairs3(HmKeys& K, int a0, int b0, int a1, int b1, int a2, int b2) {
-    asm volatile(HM_UPD_PAIR("%4", "%5") HM_UPD_PAIR("%6", "%7") HM_UPD_PAIR("%8", "%9")
-                 : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
+// one key of each query set
+__device__ __forceinline__ void hm_update_both(HmKeys& K, int a, int b) {
+    asm volatile("v_med3_f32 %1, %0, %1, %4\n\tv_min_f32 %0, %0, %4\n\tv_med3_f32 %3, %2, %3, %5\n\tv_min_f32 %2, %2, %5"
+                 : "+v"(K.k0[0]), "+v"(K.k1[0]), "+v"(K.k0[1]), "+v"(K.k1[1]) : "v"(a), "v"(b));
 }
 template <bool UPD>
 __device__ __forceinline__ void hm_tile_fp4(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16f& cb, v4i* a, const v4i (&bq)[2][4], HmKeys& K,
@@ -535,13 +545,13 @@ __device__ __forceinline__ void hm_tile_fp4(v16i& accA, v16i& accB, const v16i& 
                 if (s4 == 0) HM4_MFMA_FIRST(accB, a[0], bq[1][0], cb, sa, sb); else HM4_MFMA_ACC(accB, a[s4], bq[1][s4], sa, sb);
                 a[s4] = *reinterpret_cast<const v4i*>(lds_next + aoff[s4]);      // the next tile's fragment
             }
-            // the previous tile's 32 keys over slots 2 .. 7 (its chains ended in its slots 6 and 7), the two query sets in turn (a
-            // set's next update reads the minimum its last one wrote: back to back that is a wait state); the seeds advance in slots 4 .. 7
+            // the previous tile's 32 keys over slots 2 .. 7 (its chains ended in its slots 6 and 7): keys 3 j .. 3 j + 2 of both query
+            // sets in slot 2 + j, key 15 in slot 7; the seeds advance in slots 4 .. 7
             if (slot >= 2) {
                 if (UPD) {
-                    const int lo = (slot - 2) * 16 / 6, hi = (slot - 1) * 16 / 6;       // key registers lo .. hi - 1 of both sets: 2 or 3
-                    if (hi - lo == 2) hm_update_pairs2(K, prevA[lo], prevB[lo], prevA[lo + 1], prevB[lo + 1]);
-                    else hm_update_pairs3(K, prevA[lo], prevB[lo], prevA[lo + 1], prevB[lo + 1], prevA[lo + 2], prevB[lo + 2]);
+                    const int j = slot - 2;
+                    if (j < 5) hm_update_triples(K, prevA[3 * j], prevA[3 * j + 1], prevA[3 * j + 2], prevB[3 * j], prevB[3 * j + 1], prevB[3 * j + 2]);
+                    else hm_update_both(K, prevA[15], prevB[15]);
                 }
                 if (slot >= 4) {
 #pragma unroll
