@@ -113,28 +113,49 @@ __device__ __forceinline__ unsigned byte_at(unsigned w0, unsigned w1, unsigned w
     const unsigned long long lo = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
     return (o < 8 ? (unsigned)(lo >> (8 * o)) : (w2 >> (8 * (o - 8)))) & 255u;
 }
+#ifndef MIS_RS_ROWS
+#define MIS_RS_ROWS 4
+#endif
+constexpr int RS_ROWS = MIS_RS_ROWS;     // output rows per wave
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spp, uint8_t* __restrict__ dst, int dw, int dh, int dpp,
                                                      const int* __restrict__ tab, size_t ws) {
-    // a workgroup = 256 columns x 4 rows (a wave per row): levels 1072 .. 3200 wide fill 84 - 100 % of their workgroups; one row of
-    // 1024 columns per workgroup filled 52 - 90 %
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
+    // a workgroup = 256 columns x 4 RS_ROWS rows, a wave = 256 columns x RS_ROWS rows: the column tables are loaded once for the rows,
+    // every row's source loads are in flight before the first is used, and a level is a quarter of the waves a row per wave made
+    // (level 1 of 16 frames was 374 000 waves of ~ 100 instructions each: started more slowly than they ran -- 123 us; 4 rows per
+    // wave: 70 us, 8 rows: 68 us at 86 registers; the seven levels 358 -> 240 us)
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int ybase = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS);
+    if (x >= dw || ybase >= dh) return;
     WS_OFF(src, blockIdx.z, ws); WS_OFF(dst, blockIdx.z, ws);
     const int dw4 = (dw + 3) & ~3;
     const int *xo = tab, *xm = tab + dw4, *yo = tab + 2 * dw4, *ym = tab + 2 * dw4 + dh;
     const int4 o4 = *reinterpret_cast<const int4*>(xo + x), m4 = *reinterpret_cast<const int4*>(xm + x);   // entries past dw are zero
-    const int y0 = yo[y], y1 = y0 + 1 < sh ? y0 + 1 : y0, my1 = ym[y], my0 = 256 - my1;
-    const uint8_t* r0 = src + (size_t)(y0 + ORB_BORDER) * spp + ORB_BORDER;
-    const uint8_t* r1 = src + (size_t)(y1 + ORB_BORDER) * spp + ORB_BORDER;
     const int xs[4] = {o4.x, o4.y, o4.z, o4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
-    uint8_t* out = dst + (size_t)(y + ORB_BORDER) * dpp + ORB_BORDER + x;
-    const int nvalid = min(4, dw - x);
+    const int nvalid = min(4, dw - x), nrows = min(RS_ROWS, dh - ybase);
     const int base = xs[0] & ~3, last = xs[nvalid - 1] + 1 - base;   // the right neighbour of the last column has weight 0 and lies in the padding
-    unsigned res = 0;
+    const uint8_t* r0[RS_ROWS];
+    const uint8_t* r1[RS_ROWS];
+    int my1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int y = min(ybase + r, dh - 1);                        // (rows past the level repeat its last row and are not stored)
+        const int y0 = yo[y], y1 = y0 + 1 < sh ? y0 + 1 : y0;
+        my1[r] = ym[y];
+        r0[r] = src + (size_t)(y0 + ORB_BORDER) * spp + ORB_BORDER;
+        r1[r] = src + (size_t)(y1 + ORB_BORDER) * spp + ORB_BORDER;
+    }
+    uint8_t* out = dst + (size_t)(ybase + ORB_BORDER) * dpp + ORB_BORDER + x;
+    unsigned res[RS_ROWS];
     if (last <= 11) {
-        const unsigned* p0 = reinterpret_cast<const unsigned*>(r0 + base);
-        const unsigned* p1 = reinterpret_cast<const unsigned*>(r1 + base);
-        const unsigned a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        unsigned a[RS_ROWS][3], b[RS_ROWS][3];
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; r++) {
+            const unsigned* p0 = reinterpret_cast<const unsigned*>(r0[r] + base);
+            const unsigned* p1 = reinterpret_cast<const unsigned*>(r1[r] + base);
+            a[r][0] = p0[0]; a[r][1] = p0[1]; a[r][2] = p0[2]; b[r][0] = p1[0]; b[r][1] = p1[1]; b[r][2] = p1[2];
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; r++) res[r] = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int o = xs[k] - base, mx1 = ms[k], mx0 = 256 - mx1;
@@ -142,26 +163,38 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             const int oo = ok ? o : 0;
             // bytes oo, oo + 1 of the 12 loaded (oo <= 10): one funnel shift of the dword pair that holds them
             const bool p1 = oo >= 4, p2 = oo >= 8;
-            const unsigned alo = p2 ? a2 : (p1 ? a1 : a0), ahi = p2 ? 0u : (p1 ? a2 : a1);
-            const unsigned blo = p2 ? b2 : (p1 ? b1 : b0), bhi = p2 ? 0u : (p1 ? b2 : b1);
-            const unsigned ta = __builtin_amdgcn_alignbyte(ahi, alo, (unsigned)oo & 3u), tb = __builtin_amdgcn_alignbyte(bhi, blo, (unsigned)oo & 3u);
-            const unsigned h0 = (ta & 255u) * mx0 + ((ta >> 8) & 255u) * mx1;
-            const unsigned h1 = (tb & 255u) * mx0 + ((tb >> 8) & 255u) * mx1;
-            res |= ok ? ((h0 * my0 + h1 * my1 + (1u << 15)) >> 16) << (8 * k) : 0u;
+#pragma unroll
+            for (int r = 0; r < RS_ROWS; r++) {
+                const unsigned alo = p2 ? a[r][2] : (p1 ? a[r][1] : a[r][0]), ahi = p2 ? 0u : (p1 ? a[r][2] : a[r][1]);
+                const unsigned blo = p2 ? b[r][2] : (p1 ? b[r][1] : b[r][0]), bhi = p2 ? 0u : (p1 ? b[r][2] : b[r][1]);
+                const unsigned ta = __builtin_amdgcn_alignbyte(ahi, alo, (unsigned)oo & 3u), tb = __builtin_amdgcn_alignbyte(bhi, blo, (unsigned)oo & 3u);
+                const unsigned h0 = (ta & 255u) * mx0 + ((ta >> 8) & 255u) * mx1;
+                const unsigned h1 = (tb & 255u) * mx0 + ((tb >> 8) & 255u) * mx1;
+                res[r] |= ok ? ((h0 * (256 - my1[r]) + h1 * my1[r] + (1u << 15)) >> 16) << (8 * k) : 0u;
+            }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k >= nvalid) break;
-            const int x0 = xs[k], x1 = x0 + 1 < sw ? x0 + 1 : x0, mx1 = ms[k], mx0 = 256 - mx1;
-            const unsigned h0 = (unsigned)r0[x0] * mx0 + (unsigned)r0[x1] * mx1;
-            const unsigned h1 = (unsigned)r1[x0] * mx0 + (unsigned)r1[x1] * mx1;
-            res |= ((h0 * my0 + h1 * my1 + (1u << 15)) >> 16) << (8 * k);
+        for (int r = 0; r < RS_ROWS; r++) {
+            res[r] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= nvalid) break;
+                const int x0 = xs[k], x1 = x0 + 1 < sw ? x0 + 1 : x0, mx1 = ms[k], mx0 = 256 - mx1;
+                const unsigned h0 = (unsigned)r0[r][x0] * mx0 + (unsigned)r0[r][x1] * mx1;
+                const unsigned h1 = (unsigned)r1[r][x0] * mx0 + (unsigned)r1[r][x1] * mx1;
+                res[r] |= ((h0 * (256 - my1[r]) + h1 * my1[r] + (1u << 15)) >> 16) << (8 * k);
+            }
         }
     }
-    if (nvalid == 4) *reinterpret_cast<unsigned*>(out) = res;
-    else
-        for (int k = 0; k < nvalid; k++) out[k] = (uint8_t)(res >> (8 * k));
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        if (r >= nrows) break;
+        uint8_t* o = out + (size_t)r * dpp;
+        if (nvalid == 4) *reinterpret_cast<unsigned*>(o) = res[r];
+        else
+            for (int k = 0; k < nvalid; k++) o[k] = (uint8_t)(res[r] >> (8 * k));
+    }
 }
 
 // copyMakeBorder(BORDER_REFLECT_101) of every level (grid.z = level); only the border ring is visited:
@@ -1095,7 +1128,7 @@ int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatur
     hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h, nf), dim3(256), 0, st, io, w, h, W.pad + d0.pad_off, d0.pp, ws);
     for (int l = 1; l < L.n; l++) {
         const LevelDesc &s = L.d[l - 1], &d = L.d[l];
-        hipLaunchKernelGGL(resize_kernel, dim3((d.w + 255) / 256, (d.h + 3) / 4, nf), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
+        hipLaunchKernelGGL(resize_kernel, dim3((d.w + 255) / 256, (d.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nf), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
                            d.h, d.pp, W.tab + d.tab_off, ws);
     }
     const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
