@@ -79,26 +79,38 @@ struct OrbIO {      // per-frame inputs / outputs of a batch group (not at a reg
 
 // ---------------------------------------------------------------- K1 gray --------------------
 // cvtColor BGR2GRAY, 15-bit coefficients (RGB2Gray<uchar> of OpenCV 4.x: BY15 3735, GY15 19235, RY15 9798, gray_shift 15): (B*3735 + G*19235 + R*9798 + 16384) >> 15, written into the padded level 0
+constexpr int GRAY_ROWS = 4;     // rows per thread (a row per thread was 553 000 waves of 3 loads and a store per 16 frames)
 __global__ __launch_bounds__(256) void gray_kernel(OrbIO io, int w, int h, uint8_t* dst, int pp, size_t ws) {
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = blockIdx.y * GRAY_ROWS, f = blockIdx.z;
     if (x >= w) return;
     const uint8_t* bgr = io.src[f];
     const size_t stride = io.sstride[f];
     const int aligned = io.aligned[f];
     WS_OFF(dst, f, ws);
-    const uint8_t* s = bgr + (size_t)y * stride + 3 * (size_t)x;
-    uint8_t* o = dst + (size_t)(y + ORB_BORDER) * pp + ORB_BORDER + x;
+    const int nrows = min(GRAY_ROWS, h - y0);
     if (aligned && x + 4 <= w) {
         // 12 bytes = 4 BGR pixels in three dwords; the destination is dword aligned (border 32, pitch % 64 == 0)
-        const unsigned* sp = reinterpret_cast<const unsigned*>(s);
-        const unsigned w0 = sp[0], w1 = sp[1], w2 = sp[2];
-        const unsigned g0 = ((w0 & 255) * 3735 + ((w0 >> 8) & 255) * 19235 + ((w0 >> 16) & 255) * 9798 + (1 << 14)) >> 15;
-        const unsigned g1 = ((w0 >> 24) * 3735 + (w1 & 255) * 19235 + ((w1 >> 8) & 255) * 9798 + (1 << 14)) >> 15;
-        const unsigned g2 = (((w1 >> 16) & 255) * 3735 + (w1 >> 24) * 19235 + (w2 & 255) * 9798 + (1 << 14)) >> 15;
-        const unsigned g3 = (((w2 >> 8) & 255) * 3735 + ((w2 >> 16) & 255) * 19235 + (w2 >> 24) * 9798 + (1 << 14)) >> 15;
-        *reinterpret_cast<unsigned*>(o) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        unsigned w0[GRAY_ROWS], w1[GRAY_ROWS], w2[GRAY_ROWS];
+#pragma unroll
+        for (int r = 0; r < GRAY_ROWS; r++) {
+            const unsigned* sp = reinterpret_cast<const unsigned*>(bgr + (size_t)min(y0 + r, h - 1) * stride + 3 * (size_t)x);
+            w0[r] = sp[0]; w1[r] = sp[1]; w2[r] = sp[2];
+        }
+#pragma unroll
+        for (int r = 0; r < GRAY_ROWS; r++) {
+            if (r >= nrows) break;
+            const unsigned g0 = ((w0[r] & 255) * 3735 + ((w0[r] >> 8) & 255) * 19235 + ((w0[r] >> 16) & 255) * 9798 + (1 << 14)) >> 15;
+            const unsigned g1 = ((w0[r] >> 24) * 3735 + (w1[r] & 255) * 19235 + ((w1[r] >> 8) & 255) * 9798 + (1 << 14)) >> 15;
+            const unsigned g2 = (((w1[r] >> 16) & 255) * 3735 + (w1[r] >> 24) * 19235 + (w2[r] & 255) * 9798 + (1 << 14)) >> 15;
+            const unsigned g3 = (((w2[r] >> 8) & 255) * 3735 + ((w2[r] >> 16) & 255) * 19235 + (w2[r] >> 24) * 9798 + (1 << 14)) >> 15;
+            *reinterpret_cast<unsigned*>(dst + (size_t)(y0 + r + ORB_BORDER) * pp + ORB_BORDER + x) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        }
     } else {
-        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)((s[3 * k] * 3735 + s[3 * k + 1] * 19235 + s[3 * k + 2] * 9798 + (1 << 14)) >> 15);
+        for (int r = 0; r < nrows; r++) {
+            const uint8_t* s = bgr + (size_t)(y0 + r) * stride + 3 * (size_t)x;
+            uint8_t* o = dst + (size_t)(y0 + r + ORB_BORDER) * pp + ORB_BORDER + x;
+            for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)((s[3 * k] * 3735 + s[3 * k + 1] * 19235 + s[3 * k + 2] * 9798 + (1 << 14)) >> 15);
+        }
     }
 }
 
@@ -206,30 +218,45 @@ __global__ __launch_bounds__(256) void border_kernel(Levels L, uint8_t* pad, siz
     const LevelDesc& d = L.d[blockIdx.z - f * L.n];
     WS_OFF(pad, f, ws);
     const int B = ORB_BORDER, pw = d.w + 2 * B, ph = d.h + 2 * B;
-    int px, py;
+    uint8_t* p = pad + d.pad_off;
     if (!SIDES) {
-        // four columns per thread: a dword whose columns all lie over the level's interior is the same dword of the mirrored row
-        // (the row pitch and the border are multiples of 4); the dwords over the side strips go byte by byte
+        // four columns x four rows per thread: a dword whose columns all lie over the level's interior is the same dword of the
+        // mirrored row (the row pitch and the border are multiples of 4); the dwords over the side strips go byte by byte.
+        // (one dword per thread was 131 000 waves of a load and a store each: 40 us for 16 MB)
         const int px4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-        py = blockIdx.y < B ? blockIdx.y : ph - 2 * B + blockIdx.y;
         if (px4 >= pw) return;
-        uint8_t* p4 = pad + d.pad_off;
-        const size_t srow = (size_t)(mis_reflect101(py - B, d.h) + B) * d.pp, drow = (size_t)py * d.pp;
-        if (px4 >= B && px4 + 3 < B + d.w) {
-            *reinterpret_cast<unsigned*>(p4 + drow + px4) = *reinterpret_cast<const unsigned*>(p4 + srow + px4);
+        const bool inner = px4 >= B && px4 + 3 < B + d.w;
+        unsigned v[4];
+        size_t drow[4], srow[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int yy = blockIdx.y * 4 + r, py = yy < B ? yy : ph - 2 * B + yy;
+            srow[r] = (size_t)(mis_reflect101(py - B, d.h) + B) * d.pp; drow[r] = (size_t)py * d.pp;
+        }
+        if (inner) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = *reinterpret_cast<const unsigned*>(p + srow[r] + px4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) *reinterpret_cast<unsigned*>(p + drow[r] + px4) = v[r];
         } else {
-            for (int k = 0; k < 4 && px4 + k < pw; k++) p4[drow + px4 + k] = p4[srow + mis_reflect101(px4 + k - B, d.w) + B];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                for (int k = 0; k < 4 && px4 + k < pw; k++) p[drow[r] + px4 + k] = p[srow[r] + mis_reflect101(px4 + k - B, d.w) + B];
         }
         return;
-    } else {
-        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
-        if (row >= d.h) return;
-        py = row + B;
-        px = c < B ? c : pw - 2 * B + c;
     }
-    const int x = px - B, y = py - B;
-    uint8_t* p = pad + d.pad_off;
-    p[(size_t)py * d.pp + px] = p[(size_t)(mis_reflect101(y, d.h) + B) * d.pp + mis_reflect101(x, d.w) + B];
+    // sides: a thread = four columns of one row's left or right strip (16 threads per row; a byte per thread was 276 000 waves: 54 us)
+    const int t = blockIdx.x * 256 + threadIdx.x, row = t >> 4, g = t & 15;
+    if (row >= d.h) return;
+    const int px = g < 8 ? 4 * g : pw - B + 4 * (g - 8);
+    const size_t ro = (size_t)(row + B) * d.pp;
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (unsigned)p[ro + mis_reflect101(px + k - B, d.w) + B] << (8 * k);
+    if ((px & 3) == 0) *reinterpret_cast<unsigned*>(p + ro + px) = v;      // (the right strip starts at w + B: a dword boundary when 4 | w)
+    else
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[ro + px + k] = (uint8_t)(v >> (8 * k));
 }
 
 // ---------------------------------------------------------------- K3 FAST-9/16 ---------------
@@ -563,13 +590,30 @@ __global__ __launch_bounds__(256) void harris_kernel(Levels L, const uint8_t* pa
     uint32_t xy = cand_xy[d.cand_off + i];
     int x = xy & 0xffff, y = xy >> 16;
     const int pp = d.pp;
-    const uint8_t* p0 = pad + d.pad_off + (size_t)(y + ORB_BORDER - 3) * pp + (x + ORB_BORDER - 3);
+    // the 9 x 9 neighbourhood as three aligned dwords per row (the 9 bytes start at byte 0 .. 3 of them) and funnel shifts: 27 loads
+    // per thread where byte loads were 81 -- a wave's loads go to 64 different lines each, and the address unit was what the kernel
+    // waited for (89 us per 16 frames)
+    const uint8_t* q0 = pad + d.pad_off + (size_t)(y + ORB_BORDER - 4) * pp + (x + ORB_BORDER - 4);
+    const unsigned sh = (unsigned)((uintptr_t)q0 & 3u);
+    const uint8_t* a0 = q0 - sh;                       // (pad, pad_off and the pitch are multiples of 4)
+    int px[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const unsigned* row = reinterpret_cast<const unsigned*>(a0 + (size_t)r * pp);
+        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
+        const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh), w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[r][k] = (int)((w0 >> (8 * k)) & 255u); px[r][4 + k] = (int)((w1 >> (8 * k)) & 255u); }
+        px[r][8] = (int)(w2 & 255u);
+    }
     int a = 0, b = 0, c = 0;
+#pragma unroll
     for (int by = 0; by < 7; by++)
+#pragma unroll
         for (int bx = 0; bx < 7; bx++) {
-            const uint8_t* p = p0 + by * pp + bx;
-            int Ix = (p[1] - p[-1]) * 2 + (p[-pp + 1] - p[-pp - 1]) + (p[pp + 1] - p[pp - 1]);
-            int Iy = (p[pp] - p[-pp]) * 2 + (p[pp - 1] - p[-pp - 1]) + (p[pp + 1] - p[-pp + 1]);
+            // p = px[by + 1][bx + 1]
+            const int Ix = (px[by + 1][bx + 2] - px[by + 1][bx]) * 2 + (px[by][bx + 2] - px[by][bx]) + (px[by + 2][bx + 2] - px[by + 2][bx]);
+            const int Iy = (px[by + 2][bx + 1] - px[by][bx + 1]) * 2 + (px[by + 2][bx] - px[by][bx]) + (px[by + 2][bx + 2] - px[by][bx + 2]);
             a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
         }
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
@@ -1125,15 +1169,15 @@ int enqueue_detect_group(MisOrb* o, const DevImage* img, int w, int h, MisFeatur
     // hist, thr, cnt0, cnt1, cnt2 of every frame of the group (same offset in each workspace)
     MIS_HIP(ctx, hipMemset2DAsync(W.hist, ws ? ws : sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), 0,
                                   sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS), nf, st));
-    hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, h, nf), dim3(256), 0, st, io, w, h, W.pad + d0.pad_off, d0.pp, ws);
+    hipLaunchKernelGGL(gray_kernel, dim3((w + 1023) / 1024, (h + GRAY_ROWS - 1) / GRAY_ROWS, nf), dim3(256), 0, st, io, w, h, W.pad + d0.pad_off, d0.pp, ws);
     for (int l = 1; l < L.n; l++) {
         const LevelDesc &s = L.d[l - 1], &d = L.d[l];
         hipLaunchKernelGGL(resize_kernel, dim3((d.w + 255) / 256, (d.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nf), dim3(256), 0, st, W.pad + s.pad_off, s.w, s.h, s.pp, W.pad + d.pad_off, d.w,
                            d.h, d.pp, W.tab + d.tab_off, ws);
     }
     const int pw0 = d0.w + 2 * ORB_BORDER, ph0 = d0.h + 2 * ORB_BORDER;
-    hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h + 3) / 4, 1, L.n * nf), dim3(256), 0, st, L, W.pad, ws);   // sides first: the corners mirror them
-    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 1023) / 1024, 2 * ORB_BORDER, L.n * nf), dim3(256), 0, st, L, W.pad, ws);
+    hipLaunchKernelGGL((border_kernel<true>), dim3((d0.h * 16 + 255) / 256, 1, L.n * nf), dim3(256), 0, st, L, W.pad, ws);   // sides first: the corners mirror them
+    hipLaunchKernelGGL((border_kernel<false>), dim3((pw0 + 1023) / 1024, 2 * ORB_BORDER / 4, L.n * nf), dim3(256), 0, st, L, W.pad, ws);
     dim3 gmap((d0.w + FT_COLS - 1) / FT_COLS, (d0.h + FT_ROWS - 1) / FT_ROWS, L.n * nf);
     hipLaunchKernelGGL(fast_nms_kernel, gmap, dim3(256), 0, st, L, W.pad, W.hist, W.tile_cnt, W.surv_xy, W.surv_sc, ws);
     hipLaunchKernelGGL(fast_cut_kernel, dim3(L.n, nf), dim3(256), 0, st, L, W.hist, W.thr, W.flags, ws);
