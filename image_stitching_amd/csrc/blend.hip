@@ -793,45 +793,158 @@ __global__ __launch_bounds__(256) void feed_plain_kernel(const int16_t* img, siz
     dmask[o] |= (uint8_t)m;
 }
 
-// ---- FeatherBlender: L1 distance transform (exact city-block distance to the nearest zero pixel,
-// clamped at 8192) as two separable min-plus sweeps; rows then columns, one thread per line ----
-__global__ void dist_rows_kernel(const uint8_t* mask, size_t mstride, int w, int h, int* d) {
-    int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= h) return;
-    const int INF = 8192;
-    int run = INF;
-    int* r = d + (size_t)y * w;
-    for (int x = 0; x < w; x++) { run = mask[(size_t)y * mstride + x] ? min(run + 1, INF) : 0; r[x] = run; }
-    run = INF;
-    for (int x = w - 1; x >= 0; x--) { run = mask[(size_t)y * mstride + x] ? min(run + 1, INF) : 0; r[x] = min(r[x], run); }
+// ---- FeatherBlender (K15): createWeightMap = min(1, sharpness * distanceTransform(mask, DIST_L1, 3)), then
+// dst += (short)(src * w), wsum += w (image_stitching.cpp:1186-1190, :1218).  The 3 x 3 L1 chamfer transform is the exact city-block
+// distance to the nearest zero pixel, clamped at 8192, and separates into two min-plus sweeps: along rows
+//     g(x, y) = min(8192, distance to the nearest zero of row y),
+// then along columns  d(x, y) = min over y' of g(x, y') + |y - y'|.  Both are run as parallel scans, all in integers (exact):
+//   feather_rows_kernel    a workgroup per row: 16 pixels per thread, "last zero at or before" / "first zero at or after" by a
+//                          block-wide max / min scan; g as u16 (16-byte mask loads, 32-byte stores per thread);
+//   feather_colseg_kernel  columns cut into segments of FS_SEG rows: per (segment, column) the sweep's value at the segment's
+//                          last row (forward) and first row (backward) when started from "infinity" -- the only thing a later
+//                          segment needs to know about this one;
+//   feather_feed_kernel    per (segment, 256 columns): carries from the segments above / below (a min-plus chain over their
+//                          end values), the two sweeps of the segment in registers, weight = min(1, d * sharpness), and the
+//                          accumulation into the panorama in the same kernel -- the weight map never exists in memory.
+// Values are capped at 8192 wherever they are stored: a capped value can only reach pixels whose result is the cap anyway.
+constexpr int FT_INF = 8192, FT_PX = 16, FT_TB = 256, FS_SEG = 32, FT_MAXCHUNK = 16;    // rows up to 65536 pixels
+
+__device__ __forceinline__ int wave_scan_max_incl(int v) {     // inclusive max scan over the wave's lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v = max(v, o); }
+    return v;
 }
-__global__ void dist_cols_weight_kernel(int* d, int w, int h, float sharpness, float* wm) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= w) return;
-    const int INF = 8192;
-    int run = INF;
-    for (int y = 0; y < h; y++) { int v = d[(size_t)y * w + x]; run = min(run + 1, v); d[(size_t)y * w + x] = run; }
-    run = INF;
-    for (int y = h - 1; y >= 0; y--) {
-        int v = d[(size_t)y * w + x];
-        run = min(run + 1, v);
-        int t = min(run, INF);
-        float wv = (float)t * sharpness;  // createWeightMap: multiply, then THRESH_TRUNC at 1
-        wm[(size_t)y * w + x] = wv > 1.f ? 1.f : wv;
+__device__ __forceinline__ int wave_scan_min_incl_rev(int v) {  // inclusive min scan from the last lane down
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_down(v, d); if ((int)(threadIdx.x & 63) + d < 64) v = min(v, o); }
+    return v;
+}
+
+__global__ __launch_bounds__(FT_TB) void feather_rows_kernel(const uint8_t* __restrict__ mask, size_t mstride, int w, int h, uint16_t* __restrict__ g, int gp) {
+    __shared__ int s_last[FT_TB / 64], s_first[FT_TB / 64], s_cfirst[FT_MAXCHUNK];
+    const int y = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint8_t* row = mask + (size_t)y * mstride;
+    uint16_t* grow = g + (size_t)y * gp;
+    const bool vec_in = (((uintptr_t)mask | mstride) & 15) == 0;
+    constexpr int NONE_L = -(1 << 20), NONE_R = 1 << 20;
+    // chunks of 4096 pixels, left to right; what a chunk needs from the others: the last zero before it (carried forward) and the
+    // first zero behind it (found first, by a backward walk over the chunks' "first zero" values)
+    const int nchunk = (w + FT_TB * FT_PX - 1) / (FT_TB * FT_PX);
+    if (nchunk > 1) {       // rows wider than one chunk (8K frames): every chunk's first zero, in a pass of its own
+        for (int c = t; c < FT_MAXCHUNK; c += FT_TB) s_cfirst[c] = NONE_R;
+        __syncthreads();
+        for (int c = 1; c < nchunk; c++) {
+            const int x0 = c * FT_TB * FT_PX + t * FT_PX;
+            int first = NONE_R;
+            for (int i = FT_PX - 1; i >= 0; i--) if (x0 + i < w && row[x0 + i] == 0) first = x0 + i;
+            first = wave_scan_min_incl_rev(first);
+            if (lane == 0 && first != NONE_R) atomicMin(&s_cfirst[c], first);
+        }
+        __syncthreads();
+    }
+    int carry_last = NONE_L;
+    for (int c = 0; c < nchunk; c++) {
+        const int x0 = c * FT_TB * FT_PX + t * FT_PX;
+        unsigned m[FT_PX];
+        if (vec_in && x0 + FT_PX <= w) {
+            const uint4 q = *reinterpret_cast<const uint4*>(row + x0);
+            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < FT_PX; i++) m[i] = (qq[i >> 2] >> (8 * (i & 3))) & 255u;
+        } else {
+#pragma unroll
+            for (int i = 0; i < FT_PX; i++) m[i] = x0 + i < w ? row[x0 + i] : 1u;      // beyond the row: not a zero
+        }
+        int last = NONE_L, first = NONE_R;
+#pragma unroll
+        for (int i = 0; i < FT_PX; i++) if (m[i] == 0 && x0 + i < w) { last = x0 + i; first = min(first, x0 + i); }
+        // exclusive scans over the block: the last zero before this thread's pixels, the first zero behind them
+        int il = wave_scan_max_incl(last), ir = wave_scan_min_incl_rev(first);
+        if (lane == 63) s_last[wv] = il;
+        if (lane == 0) s_first[wv] = ir;
+        __syncthreads();
+        int before = carry_last, behind = NONE_R;
+        for (int k = 0; k < wv; k++) before = max(before, s_last[k]);
+        for (int k = wv + 1; k < FT_TB / 64; k++) behind = min(behind, s_first[k]);
+        const int pl = __shfl_up(il, 1), pr = __shfl_down(ir, 1);
+        if (lane > 0) before = max(before, pl);
+        if (lane < 63) behind = min(behind, pr);
+        int chunk_last = carry_last;
+        for (int k = 0; k < FT_TB / 64; k++) chunk_last = max(chunk_last, s_last[k]);
+        for (int k = c + 1; k < nchunk; k++) behind = min(behind, s_cfirst[k]);      // zeros of the later chunks (rows wider than one chunk)
+        __syncthreads();
+        carry_last = chunk_last;
+        // the thread's pixels: distance to the last zero at or before, the first zero at or behind
+        int lz = before;
+        int dl[FT_PX];
+#pragma unroll
+        for (int i = 0; i < FT_PX; i++) { if (m[i] == 0) lz = x0 + i; dl[i] = min(x0 + i - lz, FT_INF); }
+        int rz = behind;
+        unsigned out[FT_PX];
+#pragma unroll
+        for (int i = FT_PX - 1; i >= 0; i--) { if (m[i] == 0) rz = x0 + i; out[i] = (unsigned)min(dl[i], min(rz - (x0 + i), FT_INF)); }
+        if (x0 + FT_PX <= w && (gp & 7) == 0) {
+            uint4 o0, o1;
+            o0.x = out[0] | (out[1] << 16); o0.y = out[2] | (out[3] << 16); o0.z = out[4] | (out[5] << 16); o0.w = out[6] | (out[7] << 16);
+            o1.x = out[8] | (out[9] << 16); o1.y = out[10] | (out[11] << 16); o1.z = out[12] | (out[13] << 16); o1.w = out[14] | (out[15] << 16);
+            reinterpret_cast<uint4*>(grow + x0)[0] = o0; reinterpret_cast<uint4*>(grow + x0)[1] = o1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < FT_PX; i++) if (x0 + i < w) grow[x0 + i] = (uint16_t)out[i];
+        }
     }
 }
-__global__ __launch_bounds__(256) void feed_feather_kernel(const int16_t* img, size_t istride, const float* wm, int w, int h, int16_t* dst,
-                                                           float* dwgt, int pw, int dx, int dy) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    float wv = wm[(size_t)y * w + x];
-    size_t o = (size_t)(dy + y) * pw + dx + x;
-    const int16_t* s = img + (size_t)y * istride + 3 * (size_t)x;
-    int16_t* d = dst + o * 3;
-    d[0] = (int16_t)(d[0] + (int16_t)((float)s[0] * wv));
-    d[1] = (int16_t)(d[1] + (int16_t)((float)s[1] * wv));
-    d[2] = (int16_t)(d[2] + (int16_t)((float)s[2] * wv));
-    dwgt[o] += wv;
+
+// per (segment, column): F = the forward sweep's value at the segment's last row, B = the backward sweep's value at its first row,
+// both started from infinity:  F = min_i g[i] + (n - 1 - i),  B = min_i g[i] + i  (capped)
+__global__ __launch_bounds__(FT_TB) void feather_colseg_kernel(const uint16_t* __restrict__ g, int gp, int w, int h, uint16_t* __restrict__ F, uint16_t* __restrict__ B) {
+    const int x = blockIdx.x * FT_TB + threadIdx.x, s = blockIdx.y;
+    if (x >= w) return;
+    const int y0 = s * FS_SEG, n = min(FS_SEG, h - y0);
+    int f = FT_INF, b = FT_INF;
+    unsigned v[FS_SEG];
+#pragma unroll
+    for (int i = 0; i < FS_SEG; i++) v[i] = g[(size_t)min(y0 + i, h - 1) * gp + x];     // all loads in flight together
+#pragma unroll
+    for (int i = 0; i < FS_SEG; i++) if (i < n) { f = min(f + 1, (int)v[i]); b = min(b, (int)v[i] + i); }
+    F[(size_t)s * w + x] = (uint16_t)min(f, FT_INF);
+    B[(size_t)s * w + x] = (uint16_t)min(b, FT_INF);
+}
+
+__global__ __launch_bounds__(FT_TB) void feather_feed_kernel(const uint16_t* __restrict__ g, int gp, const uint16_t* __restrict__ F, const uint16_t* __restrict__ B, int nseg,
+                                                            const int16_t* __restrict__ img, size_t istride, int w, int h, float sharpness,
+                                                            int16_t* __restrict__ dst, float* __restrict__ dwgt, int pw, int dx, int dy) {
+    const int x = blockIdx.x * FT_TB + threadIdx.x, s = blockIdx.y;
+    if (x >= w) return;
+    const int y0 = s * FS_SEG, n = min(FS_SEG, h - y0);
+    // the sweeps' values just outside the segment: forward at row y0 - 1, backward at row y0 + n
+    int cf = FT_INF, cb = FT_INF;
+    for (int k = 0; k < s; k++) cf = min((int)F[(size_t)k * w + x], cf + FS_SEG);                       // segments above are full
+    for (int k = nseg - 1; k > s; k--) cb = min((int)B[(size_t)k * w + x], cb + min(FS_SEG, h - k * FS_SEG));
+    cf = min(cf, FT_INF); cb = min(cb, FT_INF);
+    int d[FS_SEG];
+#pragma unroll
+    for (int i = 0; i < FS_SEG; i++) d[i] = g[(size_t)min(y0 + i, h - 1) * gp + x];
+    int run = cf;
+#pragma unroll
+    for (int i = 0; i < FS_SEG; i++) { run = min(run + 1, d[i]); d[i] = run; }
+    run = cb;
+#pragma unroll
+    for (int i = FS_SEG - 1; i >= 0; i--) if (i < n) { run = min(run + 1, d[i]); d[i] = run; }
+#pragma unroll
+    for (int i = 0; i < FS_SEG; i++) {
+        if (i >= n) break;
+        const float wv0 = (float)min(d[i], FT_INF) * sharpness;      // createWeightMap: multiply, then THRESH_TRUNC at 1
+        const float wv = wv0 > 1.f ? 1.f : wv0;
+        const int y = y0 + i;
+        const size_t o = (size_t)(dy + y) * pw + dx + x;
+        const int16_t* sp = img + (size_t)y * istride + 3 * (size_t)x;
+        int16_t* dp = dst + o * 3;
+        dp[0] = (int16_t)(dp[0] + (int16_t)((float)sp[0] * wv));
+        dp[1] = (int16_t)(dp[1] + (int16_t)((float)sp[1] * wv));
+        dp[2] = (int16_t)(dp[2] + (int16_t)((float)sp[2] * wv));
+        dwgt[o] += wv;
+    }
 }
 
 inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
@@ -990,15 +1103,20 @@ int feed_multiband_batch(MisBlender* b, const MisImage* imgs, const DevImage* di
 
 int feed_feather(MisBlender* b, const DevImage& dimg, const DevImage& dmask, int w, int h, MisPoint tl) {
     MisContext* ctx = b->ctx;
-    size_t n = (size_t)w * h;
-    int rc = ensure_scratch(b, mis_align_up(n * 4, 256) * 2);
+    MIS_CHECK(ctx, w <= FT_MAXCHUNK * FT_TB * FT_PX, MIS_E_UNSUPPORTED, "feather blender: frames wider than %d pixels", FT_MAXCHUNK * FT_TB * FT_PX);
+    const int gp = (w + 7) & ~7;                                   // u16 row pitch of g: rows start on 16 bytes
+    const int nseg = (h + FS_SEG - 1) / FS_SEG;
+    const size_t g_bytes = mis_align_up((size_t)gp * h * 2, 256), e_bytes = mis_align_up((size_t)nseg * w * 2, 256);
+    int rc = ensure_scratch(b, g_bytes + 2 * e_bytes);
     if (rc != MIS_OK) return rc;
-    int* d = (int*)b->scratch;
-    float* wm = (float*)((uint8_t*)b->scratch + mis_align_up(n * 4, 256));
-    hipLaunchKernelGGL(dist_rows_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)dmask.data, dmask.stride, w, h, d);
-    hipLaunchKernelGGL(dist_cols_weight_kernel, dim3((w + 63) / 64), dim3(64), 0, ctx->stream, d, w, h, b->sharpness, wm);
-    hipLaunchKernelGGL(feed_feather_kernel, grid2d(w, h), dim3(256), 0, ctx->stream, (const int16_t*)dimg.data, dimg.stride / 2, wm, w, h,
-                       b->lap[0], b->wgt[0], b->lw[0], tl.x - b->roi.x, tl.y - b->roi.y);
+    uint16_t* g = (uint16_t*)b->scratch;
+    uint16_t* F = (uint16_t*)((uint8_t*)b->scratch + g_bytes);
+    uint16_t* B = (uint16_t*)((uint8_t*)b->scratch + g_bytes + e_bytes);
+    hipLaunchKernelGGL(feather_rows_kernel, dim3(h), dim3(FT_TB), 0, ctx->stream, (const uint8_t*)dmask.data, dmask.stride, w, h, g, gp);
+    const dim3 cg((w + FT_TB - 1) / FT_TB, nseg);
+    hipLaunchKernelGGL(feather_colseg_kernel, cg, dim3(FT_TB), 0, ctx->stream, (const uint16_t*)g, gp, w, h, F, B);
+    hipLaunchKernelGGL(feather_feed_kernel, cg, dim3(FT_TB), 0, ctx->stream, (const uint16_t*)g, gp, (const uint16_t*)F, (const uint16_t*)B, nseg,
+                       (const int16_t*)dimg.data, dimg.stride / 2, w, h, b->sharpness, b->lap[0], b->wgt[0], b->lw[0], tl.x - b->roi.x, tl.y - b->roi.y);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }

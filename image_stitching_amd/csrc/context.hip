@@ -100,23 +100,10 @@ extern "C" int mis_stream_create(int device, int priority, void** out) {
     if (hipSetDevice(device) != hipSuccess) return MIS_E_HIP;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return MIS_E_HIP;
-    if (getenv("MIS_STREAM_PRIO")) priority = atoi(getenv("MIS_STREAM_PRIO"));     // diagnostics: > 0 the least urgent, < 0 the most urgent
     const int pr = priority > 0 ? least : (priority < 0 ? greatest : 0);   // HIP: numerically smaller = more urgent
     hipStream_t s = nullptr;
-    // MIS_STREAM_CU_FRACTION = f in (0, 1): the stream's kernels are confined to the first f of the device's compute units (the
-    // mask's bits are dealt round-robin over the XCDs, so every XCD keeps its share).  The job's composition stream is created
-    // here: its bandwidth-bound grids otherwise fill every compute unit, and the matcher's RANSAC chains -- a few large
-    // workgroups per launch, each a link of a latency chain -- wait for room (a 50 us replay kernel took 340 us beside them).
-    static const double frac = getenv("MIS_STREAM_CU_FRACTION") ? atof(getenv("MIS_STREAM_CU_FRACTION")) : 0.0;
-    int cu = 0;
-    if (frac > 0.0 && frac < 1.0 && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu >= 8) {
-        const int keep = (int)(cu * frac);
-        std::vector<uint32_t> mask((cu + 31) / 32, 0u);
-        for (int i = 0; i < keep; i++) mask[i >> 5] |= 1u << (i & 31);
-        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) return MIS_E_HIP;
-        *out = (void*)s;
-        return MIS_OK;
-    }
+    // (Round 3 measured two more knobs here -- a compute-unit mask for the composition stream and a priority override -- slower
+    // at every setting / no effect; both are gone.)
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr) != hipSuccess) return MIS_E_HIP;
     *out = (void*)s;
     return MIS_OK;

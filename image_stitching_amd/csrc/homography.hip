@@ -10,8 +10,8 @@
 //                     consumes (duplicate redraws) and whether it passes checkSubset.  Every stream
 //                     position is simulated as the start of ONE attempt in parallel, then one thread
 //                     chases start -> end -> ... through the table: the exact sequential sequence.
-//   hyp_kernel        one thread per hypothesis (128 LDS slots per workgroup): 4-point normalised DLT,
-//                     9x9 Jacobi on the upper triangle, inlier count.
+//   hyp_quad_kernel   four lanes per hypothesis: 4-point normalised DLT, 9x9 Jacobi on the upper triangle;
+//   hyp_count_kernel  one wave per hypothesis: its inlier count.
 //   scan_tail_kernel  sequential replay of the adaptive loop (niters update) over the scored
 //                     hypotheses; when the loop ends: inlier mask, ordered compaction, DLT on all
 //                     inliers, 10-iteration LM.  f64 sums keep the CPU's order: per-point terms in
@@ -25,8 +25,6 @@
 
 namespace {
 
-constexpr int HYP_TPB = 128;      // hypotheses (threads) per workgroup of hyp_kernel
-constexpr int SLOT_DOUBLES = 126; // 36 (strict upper triangle) + 9 (diagonal / eigenvalues) + 81 (eigenvectors)
 #ifndef MIS_PHASE0
 #define MIS_PHASE0 128
 #endif
@@ -168,9 +166,6 @@ __device__ void dlt_denormalise(const double* H0, const double* nrm /* cmx cmy c
 
 #ifndef MIS_CHAIN_PRIO
 #define MIS_CHAIN_PRIO 3
-#endif
-#ifndef MIS_HYP_QUAD
-#define MIS_HYP_QUAD 1          // the 4-point solves on four lanes each (hyp_quad_kernel); 0: one thread each (hyp_kernel)
 #endif
 #ifdef MIS_TAIL_PROF
 __device__ unsigned long long g_draw_prof[12];   // per phase p (0, 1): [4p] chunks (all problems), [4p+1] most chunks of a problem, [4p+2] longest problem (wall ticks), [4p+3] problems with work
@@ -517,263 +512,12 @@ __global__ __launch_bounds__(DRAW_TB) void draw_kernel(const HomoCall* calls, Ra
 #endif
 }
 
-// ---------------------------------------------------------------- hyp_kernel -------------------
-// per-thread 9x9 symmetric eigen-problem in LDS: element e of the thread's slot at sl[e * HYP_TPB + t]
-struct CSlot {
-    double* base;
-    __device__ __forceinline__ double& u(int r, int c) const { return base[(r * 9 - r * (r + 1) / 2 + (c - r - 1)) * HYP_TPB]; }  // r < c
-    __device__ __forceinline__ double& w(int k) const { return base[(36 + k) * HYP_TPB]; }
-    __device__ __forceinline__ double& v(int e) const { return base[(45 + e) * HYP_TPB]; }
-};
-
 #ifdef MIS_TAIL_PROF
-__device__ unsigned long long g_hyp_prof[8];    // rotations (all threads), threads, max rotations of a thread, shader cycles of lane 0's solve (summed over waves), waves
+__device__ unsigned long long g_hyp_prof[8];    // [6], [7]: summed / longest replay of a second phase (scan_tail_kernel)
 #endif
-// core/src/lapack.cpp JacobiImpl_<double> for n = 9; the algorithm only ever touches the strict upper
-// triangle and the diagonal (kept in w), eigenvectors are the rows of v, eigenvalues sorted descending
-// One thread = one 9 x 9 problem (JacobiImpl_ of lapack.cpp, the arithmetic and the visiting order of the serial
-// loops).  The kernel is bound by the latency of a rotation (126 doubles of LDS per problem: two waves per compute unit), so a
-// rotation makes ONE LDS round trip:
-//  * the two index tables are nibble-packed in registers and the candidates' signed VALUES (A[i][indR[i]], A[indC[i]][i]) are
-//    register arrays with static indices (every loop over i is unrolled): the pivot search reads no memory;
-//  * all operands of the rotation (W[k], W[l], the 7 element pairs of A, the 9 pairs of V) are read as soon as k, l are known,
-//    before the arithmetic chain of c and s, at addresses that only depend on k, l (an index that does not exist, i = k or
-//    i = l, reads the pivot element and writes a zero there);
-//  * the four re-scans (indR[k], indC[k], indR[l], indC[l]) run over the rotated values in registers -- they ARE the new rows and
-//    columns k, l -- and the candidates of the other rows / columns follow the rotation by selects.
-// Round 2's form read its 16 candidates, then p and W, then the pairs, then the four scans: five dependent LDS round trips and
-// 32 more loads per rotation.
-__device__ void jacobi9_compact(const CSlot s) {
-    constexpr int n = 9;
-    const double eps = DBL_EPSILON;
-    unsigned long long IR = 0, IC = 0;   // indR[k] / indC[k] in bits 4k .. 4k+3
-    auto get = [](unsigned long long t, int k) { return (int)((t >> (4 * k)) & 15ull); };
-    auto set = [](unsigned long long& t, int k, int v) { t = (t & ~(15ull << (4 * k))) | ((unsigned long long)v << (4 * k)); };
-    // set-up only: max |u(idx, i)| over i in (idx, n) / max |u(i, idx)| over i in [0, idx): first maximum, as the serial scan
-    auto row_arg = [&](int idx) {
-        double vals[n];
-#pragma unroll
-        for (int i = 1; i < n; i++) vals[i] = fabs(s.u(idx, max(i, idx + 1)));
-        int m = idx + 1;
-        double mv = -1.;
-#pragma unroll
-        for (int i = 1; i < n; i++)
-            if (i > idx && mv < vals[i]) mv = vals[i], m = i;
-        return m;
-    };
-    auto col_arg = [&](int idx) {
-        double vals[n];
-#pragma unroll
-        for (int i = 0; i < n - 1; i++) vals[i] = fabs(s.u(min(i, idx - 1), idx));
-        int m = 0;
-        double mv = -1.;
-#pragma unroll
-        for (int i = 0; i < n - 1; i++)
-            if (i < idx && mv < vals[i]) mv = vals[i], m = i;
-        return m;
-    };
-#pragma unroll
-    for (int i = 0; i < n * n; i++) s.v(i) = (i / n == i % n) ? 1. : 0.;
-    double rv[n], cv[n];      // signed candidate values: rv[i] = u(i, indR[i]) (i < n - 1), cv[i] = u(indC[i], i) (i >= 1)
-#pragma unroll
-    for (int k = 0; k < n; k++) {
-        rv[k] = 0; cv[k] = 0;
-        if (k < n - 1) { const int m = row_arg(k); set(IR, k, m); rv[k] = s.u(k, m); }
-        if (k > 0) { const int m = col_arg(k); set(IC, k, m); cv[k] = s.u(m, k); }
-    }
-    // element (r, c), r < c, of the strict upper triangle sits at slot index T(r) + c with T(r) = r (17 - r) / 2 - r - 1
-    auto T = [](int r) { return (r * (17 - r)) / 2 - r - 1; };
-#ifdef MIS_TAIL_PROF
-    const unsigned long long hp0 = __builtin_readcyclecounter();
-#endif
-    int iters = 0;
-    for (; iters < n * n * 30; iters++) {
-        // pivot: first maximum over the row candidates 0 .. n-2, then the column candidates 1 .. n-1
-        int k = 0, l = get(IR, 0);
-        double p = rv[0], mv = fabs(rv[0]);
-#pragma unroll
-        for (int i = 1; i < n - 1; i++) {
-            const double a = fabs(rv[i]);
-            const bool up = mv < a;
-            mv = up ? a : mv; p = up ? rv[i] : p; k = up ? i : k; l = up ? get(IR, i) : l;
-        }
-#pragma unroll
-        for (int i = 1; i < n; i++) {
-            const double a = fabs(cv[i]);
-            const bool up = mv < a;
-            mv = up ? a : mv; p = up ? cv[i] : p; k = up ? get(IC, i) : k; l = up ? i : l;
-        }
-        if (fabs(p) <= eps) break;
-        // every operand of the rotation, at addresses that depend on k and l only
-        const int Tk = T(k), Tl = T(l), kl = Tk + l;
-        double* Xp[n]; double* Yp[n];
-        double a0[n], b0[n], va[n], vb[n];
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const int ox = i == k ? kl : (i < k ? T(i) + k : Tk + i);
-            const int oy = i == l ? kl : (i < l ? T(i) + l : Tl + i);
-            Xp[i] = s.base + ox * HYP_TPB; Yp[i] = s.base + oy * HYP_TPB;
-        }
-        const double wk = s.w(k), wl = s.w(l);
-#pragma unroll
-        for (int i = 0; i < n; i++) { a0[i] = *Xp[i]; b0[i] = *Yp[i]; }
-#pragma unroll
-        for (int i = 0; i < n; i++) { va[i] = s.v(n * k + i); vb[i] = s.v(n * l + i); }
-        const double y = (wl - wk) * 0.5;
-        double t, sn, c;
-        if (__all(jd_mid(__double2hiint(p)) & jd_mid(__double2hiint(y)))) jacobi_rotation<true>(p, y, &c, &sn, &t);     // uniform branch
-        else jacobi_rotation<false>(p, y, &c, &sn, &t);
-        s.w(k) = wk - t; s.w(l) = wl + t;
-        double xa[n], ya[n];
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const bool pair = (i != k) & (i != l);
-            xa[i] = a0[i] * c - b0[i] * sn;
-            ya[i] = a0[i] * sn + b0[i] * c;
-            *Xp[i] = pair ? xa[i] : 0.;       // i = k, l: the pivot element
-            *Yp[i] = pair ? ya[i] : 0.;
-        }
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            s.v(n * k + i) = va[i] * c - vb[i] * sn;
-            s.v(n * l + i) = va[i] * sn + vb[i] * c;
-        }
-        // the candidates of the rows / columns other than k, l keep their (stale) indices; their VALUES follow the rotation
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const bool pair = (i != k) & (i != l);
-            const int iri = get(IR, i), ici = get(IC, i);
-            rv[i] = (pair & (i < k) & (iri == k)) ? xa[i] : rv[i];
-            rv[i] = (pair & (i < l) & (iri == l)) ? ya[i] : rv[i];
-            cv[i] = (pair & (i > k) & (ici == k)) ? xa[i] : cv[i];
-            cv[i] = (pair & (i > l) & (ici == l)) ? ya[i] : cv[i];
-        }
-        // indR[k], indC[k], indR[l], indC[l]: first maxima over the rotated rows / columns (element i of row / column k is xa[i],
-        // of row / column l ya[i]; the pivot element is zero)
-        int rk = k + 1, ck = 0, rl = l + 1, cl = 0;
-        double rkv = 0, ckv = 0, rlv = 0, clv = 0, m0 = -1., m1 = -1., m2 = -1., m3 = -1.;
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            const double ek = i == l ? 0. : xa[i], el = i == k ? 0. : ya[i];
-            const double aek = fabs(ek), ael = fabs(el);
-            const bool u0 = (i > k) & (m0 < aek), u1 = (i < k) & (m1 < aek), u2 = (i > l) & (m2 < ael), u3 = (i < l) & (m3 < ael);
-            m0 = u0 ? aek : m0; rk = u0 ? i : rk; rkv = u0 ? ek : rkv;
-            m1 = u1 ? aek : m1; ck = u1 ? i : ck; ckv = u1 ? ek : ckv;
-            m2 = u2 ? ael : m2; rl = u2 ? i : rl; rlv = u2 ? el : rlv;
-            m3 = u3 ? ael : m3; cl = u3 ? i : cl; clv = u3 ? el : clv;
-        }
-        if (k < n - 1) set(IR, k, rk);
-        if (k > 0) set(IC, k, ck);
-        if (l < n - 1) set(IR, l, rl);
-        if (l > 0) set(IC, l, cl);
-#pragma unroll
-        for (int i = 0; i < n; i++) {
-            rv[i] = ((i == k) & (k < n - 1)) ? rkv : (((i == l) & (l < n - 1)) ? rlv : rv[i]);
-            cv[i] = ((i == k) & (k > 0)) ? ckv : ((i == l) ? clv : cv[i]);
-        }
-    }
-#ifdef MIS_TAIL_PROF
-    {
-        atomicAdd(&g_hyp_prof[0], (unsigned long long)iters); atomicAdd(&g_hyp_prof[1], 1ull); atomicMax(&g_hyp_prof[2], (unsigned long long)iters);
-        int wmax = 0;
-        for (unsigned long long mm = __ballot(1); mm; mm &= mm - 1) wmax = max(wmax, __builtin_amdgcn_readlane(iters, __builtin_ctzll(mm)));
-        if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) { atomicAdd(&g_hyp_prof[3], __builtin_readcyclecounter() - hp0); atomicAdd(&g_hyp_prof[4], 1ull); atomicAdd(&g_hyp_prof[5], (unsigned long long)wmax); }
-    }
-#endif
-    // sort the eigenvalues (and vectors) in descending order: selection sort of the serial code
-    for (int k = 0; k < n - 1; k++) {
-        int m = k;
-        for (int i = k + 1; i < n; i++) if (s.w(m) < s.w(i)) m = i;
-        if (k != m) {
-            double tw = s.w(m); s.w(m) = s.w(k); s.w(k) = tw;
-            for (int i = 0; i < n; i++) { double tv = s.v(n * m + i); s.v(n * m + i) = s.v(n * k + i); s.v(n * k + i) = tv; }
-        }
-    }
-}
-
-// HomographyEstimatorCallback::runKernel on 4 correspondences by one thread
-__device__ int dlt4_compact(const float* M, const float* m, const CSlot s, double* H) {
-    const int count = 4;
-    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
-    for (int i = 0; i < count; i++) { cmx += m[2 * i]; cmy += m[2 * i + 1]; cMx += M[2 * i]; cMy += M[2 * i + 1]; }
-    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
-    for (int i = 0; i < count; i++) {
-        smx += fabs(m[2 * i] - cmx); smy += fabs(m[2 * i + 1] - cmy);
-        sMx += fabs(M[2 * i] - cMx); sMy += fabs(M[2 * i + 1] - cMy);
-    }
-    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
-    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
-    double LtL[45];  // upper triangle incl. diagonal, row-major; static indices only -> registers
-#pragma unroll
-    for (int e = 0; e < 45; e++) LtL[e] = 0;
-#pragma unroll
-    for (int i = 0; i < count; i++) {
-        const double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
-        const double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
-        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-        int e = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++)
-#pragma unroll
-            for (int k = j; k < 9; k++, e++) LtL[e] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
-    }
-    {
-        int e = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++)
-#pragma unroll
-            for (int k = j; k < 9; k++, e++) {
-                if (k == j) s.w(j) = LtL[e];
-                else s.u(j, k) = LtL[e];
-            }
-    }
-    jacobi9_compact(s);
-    double H0[9];
-    for (int i = 0; i < 9; i++) H0[i] = s.v(72 + i);
-    const double nrm[8] = {cmx, cmy, cMx, cMy, smx, smy, sMx, sMy};
-    dlt_denormalise(H0, nrm, H);
-    return 1;
-}
-
-__global__ __launch_bounds__(HYP_TPB) void hyp_kernel(const HomoCall* calls, const RansacState* states, const int* sub_idx, double* Hc, int* valid,
-                                                      int* good, int lo, int max_iters, float thr) {
-#if MIS_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
-#endif
-    extern __shared__ double sl[];
-    const int b = blockIdx.y, t = threadIdx.x;
-    const RansacState st = states[b];
-    if (st.mode != 2 || st.done) return;
-    const int limit = min(st.n_sub, st.niters);  // hypotheses at or beyond niters can never be replayed
-    const int k0 = lo + blockIdx.x * HYP_TPB;
-    if (k0 >= limit) return;
-    const int k = k0 + t;
-    if (k >= limit) return;
-    const HomoCall c = calls[b];
-    const int* id = sub_idx + ((size_t)b * max_iters + k) * 4;
-    float ms1[8], ms2[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int q = id[i];
-        ms1[2 * i] = c.src[2 * q]; ms1[2 * i + 1] = c.src[2 * q + 1];
-        ms2[2 * i] = c.dst[2 * q]; ms2[2 * i + 1] = c.dst[2 * q + 1];
-    }
-    double H[9];
-    const CSlot s{sl + t};
-    int ok = dlt4_compact(ms1, ms2, s, H);
-    if (ok) {
-        double* o = Hc + ((size_t)b * max_iters + k) * 9;
-#pragma unroll
-        for (int i = 0; i < 9; i++) o[i] = H[i];
-    }
-    valid[(size_t)b * max_iters + k] = ok;
-    (void)good; (void)thr;     // the inlier counts are hyp_count_kernel's
-}
-
 // ---------------------------------------------------------------- hyp_quad_kernel --------------
-// The same 4-point solves with FOUR lanes per hypothesis (a DPP quad).  One thread per solve (hyp_kernel above) runs ~1300
-// instructions per rotation on a wave that is alone on its SIMD (126 doubles of LDS per solve allow two waves per compute
+// The 4-point solves (normalised DLT + 9 x 9 Jacobi of every hypothesis) with FOUR lanes per hypothesis (a DPP quad).  One thread
+// per solve (rounds 1-2's hyp_kernel, removed in round 4) ran ~1300 instructions per rotation on a wave that is alone on its SIMD (126 doubles of LDS per solve allow two waves per compute
 // unit): 9500 cycles per rotation, 140 rotations, 0.6 ms per launch whatever its size, and three such launches sit on the
 // matcher's critical path.  Here lane q of a quad owns the indices i = q, q + 4, q + 8 (< 9): its element pairs of A, its
 // columns of V, the candidates of rows / columns i (index + |value| in registers).  A rotation is: quad arg-max of the
@@ -1808,9 +1552,8 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     const float thr = (float)(thresh * thresh);
     hipStream_t st = stream ? stream : ctx->stream;
     static bool attr_set[64] = {false};
-    const size_t hyp_lds = sizeof(double) * SLOT_DOUBLES * HYP_TPB, hq_lds = sizeof(double) * HQ_ELEMS * HQ_STRIDE;
+    const size_t hq_lds = sizeof(double) * HQ_ELEMS * HQ_STRIDE;
     if (!attr_set[ctx->device & 63]) {
-        MIS_HIP(ctx, hipFuncSetAttribute((const void*)hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
         MIS_HIP(ctx, hipFuncSetAttribute((const void*)hyp_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hq_lds));
         attr_set[ctx->device & 63] = true;
     }
@@ -1823,9 +1566,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
         if (sy.rec && sy.rec_pos == 2) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
-        if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, 0, max_iters);
-        else hipLaunchKernelGGL(hyp_kernel, dim3((p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid,
-                           b->good, 0, max_iters, thr);
+        hipLaunchKernelGGL(hyp_quad_kernel, dim3((p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, 0, max_iters);
         if (sy.rec_hyp0) MIS_HIP(ctx, hipEventRecord(sy.rec_hyp0, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 3 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
@@ -1843,9 +1584,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
         if (sy.rec && sy.rec_pos == 0) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
         if (sy.wait_hyp1) MIS_HIP(ctx, hipStreamWaitEvent(st, sy.wait_hyp1, 0));
-        if (MIS_HYP_QUAD) hipLaunchKernelGGL(hyp_quad_kernel, dim3((max_iters - p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, p0, max_iters);
-        else hipLaunchKernelGGL(hyp_kernel, dim3((max_iters - p0 + HYP_TPB - 1) / HYP_TPB, b->count), dim3(HYP_TPB), hyp_lds, st, b->calls, states, b->sub_idx,
-                           b->Hc, b->valid, b->good, p0, max_iters, thr);
+        hipLaunchKernelGGL(hyp_quad_kernel, dim3((max_iters - p0 + HQ_HYPS - 1) / HQ_HYPS, b->count), dim3(4 * HQ_HYPS), hq_lds, st, b->calls, states, b->sub_idx, b->Hc, b->valid, p0, max_iters);
         if (sy.rec && sy.rec_pos == 1) MIS_HIP(ctx, hipEventRecord(sy.rec, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);

@@ -89,139 +89,26 @@ __global__ __launch_bounds__(256) void knn2_hamming_kernel(const FeatDev* feats,
 }
 
 // ---------------------------------------------------------------- K7 on the matrix cores --------
-// Hamming-256 as an exact int8 GEMM (north star: "MFMA only if descriptor distance is cast as a dense GEMM").  Every bit
-// becomes one int8: trains +64 / -64, queries -64 / +64 (set / clear), so a product is -4096 where the bits agree and +4096
-// where they differ, and the 256-term dot product is 8192 * hamming - 2^20.  With the accumulator preloaded with
-// 2^20 + trainIdx the MFMA chain (8 x v_mfma_i32_32x32x32_i8) delivers the search key 8192 * hamming + trainIdx itself: the
-// running top two of a query are again a min and a median-of-three per candidate, nothing else.  The vector pipe of the scalar
-// kernel above paid 8 xor + 8 bcnt per distance (56 cycles per wave-distance, issue bound at 1.98 ms per 16 x 4K job); here a
-// 32 x 32 tile of distances costs 8 MFMAs (256 matrix-pipe cycles) + 32 vector instructions per lane.  Keys need
-// trainIdx < 8192: larger train sets take the scalar kernel.
+// Hamming-256 as an exact dense product on the matrix cores (north star: "MFMA only if descriptor distance is cast as a dense
+// GEMM").  Every descriptor bit becomes a signed element -- +v where a train bit is set, -v where it is clear, the opposite signs
+// for a query -- so a product is -v^2 where the bits agree and +v^2 where they differ, and the 256-term dot product is
+// 2 v^2 hamming - 256 v^2.  With v^2 = 4096 and the accumulator preloaded with 2^20 + trainIdx the chain delivers the search key
+// 8192 hamming + trainIdx itself: the running best two of a query are a minimum and a median of three per candidate, nothing
+// else.  Keys need trainIdx < 8192: larger train sets take the vector-pipe kernel above (56 cycles per wave-distance).
+// History: round 2 ran this on v_mfma_i32_32x32x32_i8 with bytes +-64 (0.83 ms per 16 x 4K job), round 3
+// paced it by the matrix pipe (VGPR accumulators that ping-pong between tiles, float-rate key selections, an XCD-ordered
+// workgroup table: 0.65 ms), staged the train tiles by LDS-DMA (0.58 ms) and moved it to the fp4 operands below (0.41 ms); the
+// int8 kernels were removed in round 4 once nothing selected them.
 // Layout: accumulator register g of lane (r, h) = query r (B column) x train (g & 3) + 8 (g >> 2) + 4 h (A row) of the tile;
 // a lane's two running keys per query set cover half of the trains, the halves are merged at the end.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int HM_PITCH = 272;          // LDS pitch of an expanded descriptor row (256 B + 16: the 16-byte fragment reads of 32 rows spread over the banks)
 constexpr int HM_ROWPAD = 256;         // expanded blocks are padded with zero rows to a multiple of this
 constexpr int HM_MAX_TRAINS = 8192;
 constexpr int HM_NONE = 0x7f000000;
 
 struct HmFrame { size_t train_off, query_off; };   // byte offsets of a frame's two expanded forms
 
-// one thread per (descriptor, 32-bit word): 32 bits -> 32 bytes of each form; rows >= n are zero (they contribute a dot product of 0)
-__global__ __launch_bounds__(256) void hamming_expand_kernel(const FeatDev* feats, const HmFrame* fr, int8_t* out) {
-    const FeatDev F = feats[blockIdx.y];
-    const int npad = (F.n + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
-    const int item = blockIdx.x * 256 + threadIdx.x, d = item >> 3, w = item & 7;
-    if (d >= npad) return;
-    const bool live = d < F.n;
-    const unsigned x = live ? reinterpret_cast<const unsigned*>(F.desc)[(size_t)d * 8 + w] : 0u;
-    unsigned tq[8], qq[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const unsigned s = (((x >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;    // bits 4k .. 4k+3 -> bit 0 of bytes 0 .. 3
-        tq[k] = live ? (0xC0C0C0C0u ^ (s * 0x80u)) : 0u;                                // +64 (set) / -64 (clear)
-        qq[k] = live ? (0x40404040u ^ (s * 0x80u)) : 0u;                                // -64 (set) / +64 (clear)
-    }
-    uint4* to = reinterpret_cast<uint4*>(out + fr[blockIdx.y].train_off + (size_t)d * 256 + 32 * w);
-    uint4* qo = reinterpret_cast<uint4*>(out + fr[blockIdx.y].query_off + (size_t)d * 256 + 32 * w);
-    to[0] = make_uint4(tq[0], tq[1], tq[2], tq[3]); to[1] = make_uint4(tq[4], tq[5], tq[6], tq[7]);
-    qo[0] = make_uint4(qq[0], qq[1], qq[2], qq[3]); qo[1] = make_uint4(qq[4], qq[5], qq[6], qq[7]);
-}
-
-__global__ __launch_bounds__(256) void knn2_hamming_mfma_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
-                                                                float* dist2) {
-    __shared__ __attribute__((aligned(16))) int8_t tr[2][32 * HM_PITCH];
-    const PairDesc pd = pairs[blockIdx.y >> 1];
-    const bool fwd = (blockIdx.y & 1) == 0;
-    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
-    const int nq = feats[qi].n, nt = feats[ti].n;
-    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
-    const int q0 = blockIdx.x * 256;
-    if (q0 >= nq) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int8_t* qx = xp + fr[qi].query_off;
-    const int8_t* tx = xp + fr[ti].train_off;
-    // the wave's 2 x 32 queries as B fragments (step s, lane (r, h): bytes 32 s + 16 h .. + 15 of query r), in registers for the whole pass
-    v4i bq[2][8];
-#pragma unroll
-    for (int set = 0; set < 2; set++)
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++)
-            bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
-    int cbase[16];
-#pragma unroll
-    for (int g = 0; g < 16; g++) cbase[g] = (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
-    int k0[2] = {HM_NONE, HM_NONE}, k1[2] = {HM_NONE, HM_NONE};
-    const int ntiles = (nt + 31) / 32;
-    // a tile = 32 expanded trains = 8 KB: two 16-byte pieces per thread, tile t + 1 fetched while tile t is multiplied
-    const int prow = threadIdx.x >> 3, pcol = (threadIdx.x & 7) * 32;
-    {
-        const v4i* g = reinterpret_cast<const v4i*>(tx + (size_t)prow * 256 + pcol);
-        v4i* l = reinterpret_cast<v4i*>(&tr[0][prow * HM_PITCH + pcol]);
-        l[0] = g[0]; l[1] = g[1];
-    }
-    __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
-        const int buf = t & 1, t0 = t * 32;
-        v4i pre0 = {0, 0, 0, 0}, pre1 = {0, 0, 0, 0};
-        if (t + 1 < ntiles) {
-            const v4i* g = reinterpret_cast<const v4i*>(tx + (size_t)(t0 + 32 + prow) * 256 + pcol);
-            pre0 = g[0]; pre1 = g[1];
-        }
-        v4i a[8];
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[buf][r * HM_PITCH + 32 * s8 + 16 * h]);
-        const bool full = t0 + 32 <= nt;    // wave-uniform: only the last tile can hold rows past the train set
-#pragma unroll
-        for (int set = 0; set < 2; set++) {
-            v16i acc;
-#pragma unroll
-            for (int g = 0; g < 16; g++) acc[g] = (full || (cbase[g] - (1 << 20)) + t0 < nt) ? cbase[g] + t0 : HM_NONE;
-#pragma unroll
-            for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s8], bq[set][s8], acc, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const int key = acc[g];
-                // k0 <= k1 always: the new second best is the median of (k0, k1, key), the new best the minimum
-                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(k1[set]) : "v"(k0[set]), "v"(k1[set]), "v"(key));
-                k0[set] = min(k0[set], key);
-            }
-        }
-        if (t + 1 < ntiles) {
-            v4i* l = reinterpret_cast<v4i*>(&tr[buf ^ 1][prow * HM_PITCH + pcol]);
-            l[0] = pre0; l[1] = pre1;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int set = 0; set < 2; set++) {
-        // the other half of the trains sits in lane (r, 1 - h)
-        const int o0 = __shfl_xor(k0[set], 32), o1 = __shfl_xor(k1[set], 32);
-        const int b0 = min(k0[set], o0), b1 = min(max(k0[set], o0), min(k1[set], o1));
-        const int q = q0 + wave * 64 + set * 32 + r;
-        if (h == 0 && q < nq) {
-            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
-            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
-            dist2[(off + q) * 2] = (float)(v0 ? b0 >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? b1 >> 13 : 1 << 30);
-        }
-    }
-}
-
-// Round 3: the same pass paced by the matrix pipe.  The first form issued a tile's 16 MFMAs back to back (into AGPRs), then
-// ~200 vector instructions (16 accumulator seeds per query set with the tail-tile test folded in, 32 v_accvgpr_read, 64 min /
-// med3): 1075 cycles per wave and tile against 512 of matrix work.  Here
-//  * the accumulators are VGPRs (inline-asm MFMAs with "v" operands) and ping-pong between tiles: the 64 key updates of tile
-//    t - 1 are spread over the 16 MFMA slots of tile t, four or five vector instructions per slot (an MFMA holds the SIMD's vector
-//    issue for 8 of its 32 cycles: up to six ride along for free);
-//  * the seeds are ONE set of 16 registers for both query sets (C operand of each chain's first MFMA), advanced by 32 per tile;
-//  * only the pass's last tile can hold rows past the train set: its keys are masked in the epilogue (trainIdx = key & 8191);
-//  * a tile's A fragments are re-read from LDS (next tile's image) right behind the two MFMAs that used them.
-// Hazards the assembler does not see inside inline assembly: a vector instruction reads an accumulator at least three MFMA
-// slots (96 cycles) after the chain's last MFMA was issued (16 passes = 64 cycles); the seeds are advanced from slot 4 on
-// (the chains' first MFMAs, which read them as srcC, are slots 0 and 1).
-#define HM_MFMA_FIRST(D, A, B, C) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C))
-#define HM_MFMA_ACC(D, A, B) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B))
 struct HmKeys { int k0[2], k1[2]; };
 // One workgroup of the pass: 256 queries of a directed pair against all trains.  The table is ordered so that workgroup L runs on
 // XCD L mod 8 (the dispatcher deals workgroups round-robin over the eight XCDs) and every XCD only ever sees the TRAIN sets of
@@ -241,244 +128,15 @@ __device__ __forceinline__ void hm_update(HmKeys& K, int set, int key) {
     asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(K.k1[set]) : "v"(K.k0[set]), "v"(K.k1[set]), "v"(key));
     asm volatile("v_min_f32 %0, %1, %2" : "=v"(K.k0[set]) : "v"(K.k0[set]), "v"(key));
 }
-template <bool UPD>
-__device__ __forceinline__ void hm_tile(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16i& cb, v4i* a, const v4i (&bq)[2][8], HmKeys& K,
-                                        const int8_t* lds_next, int8_t* lds_store, const int8_t* gnext, int r, int h, int prow, int pcol) {
-    const v4i* gp = reinterpret_cast<const v4i*>(gnext);
-    const v4i pre0 = gp[0], pre1 = gp[1];          // tile t + 2 (two 16-byte pieces per thread), stored into LDS at the end of this tile
-#pragma unroll
-    for (int s8 = 0; s8 < 8; s8++) {
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int slot = 2 * s8 + half;
-            if (half == 0) { if (s8 == 0) HM_MFMA_FIRST(accA, a[0], bq[0][0], cb); else HM_MFMA_ACC(accA, a[s8], bq[0][s8]); }
-            else {
-                if (s8 == 0) HM_MFMA_FIRST(accB, a[0], bq[1][0], cb); else HM_MFMA_ACC(accB, a[s8], bq[1][s8]);
-                a[s8] = *reinterpret_cast<const v4i*>(lds_next + r * HM_PITCH + 32 * s8 + 16 * h);      // the next tile's fragment
-            }
-            if (slot >= 2) {
-                if (UPD) {
-                    // keys 0 .. 15: set 0 (prevA), 16 .. 31: set 1 (prevB); 32 keys over slots 2 .. 15
-                    const int lo = (slot - 2) * 32 / 14, hi = (slot - 1) * 32 / 14;
-#pragma unroll
-                    for (int i = lo; i < hi; i++) hm_update(K, i >> 4, i < 16 ? prevA[i] : prevB[i - 16]);
-                }
-                if (slot >= 4) {
-                    const int lo = (slot - 4) * 16 / 12, hi = (slot - 3) * 16 / 12;
-#pragma unroll
-                    for (int g = lo; g < hi; g++) cb[g] += 32;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    v4i* l = reinterpret_cast<v4i*>(lds_store + prow * HM_PITCH + pcol);
-    l[0] = pre0; l[1] = pre1;
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void knn2_hamming_mfma2_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
-                                                                 float* dist2, const HmJob* jobs) {
-    __shared__ __attribute__((aligned(16))) int8_t tr[2][32 * HM_PITCH];
-    const HmJob job = jobs[blockIdx.x];
-    if (job.pair < 0) return;                       // padding of the XCD interleave
-    const PairDesc pd = pairs[job.pair];
-    const bool fwd = job.dir == 0;
-    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
-    const int nq = feats[qi].n, nt = feats[ti].n;
-    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
-    const int q0 = job.q0;
-    if (q0 >= nq) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int8_t* qx = xp + fr[qi].query_off;
-    const int8_t* tx = xp + fr[ti].train_off;
-    HmKeys K;
-    K.k0[0] = K.k0[1] = K.k1[0] = K.k1[1] = HM_NONE;
-    const int ntiles = (nt + 31) / 32;
-    if (ntiles > 0) {
-        // the wave's 2 x 32 queries as B fragments (step s, lane (r, h): bytes 32 s + 16 h .. + 15 of query r), in registers for the whole pass
-        v4i bq[2][8];
-#pragma unroll
-        for (int set = 0; set < 2; set++)
-#pragma unroll
-            for (int s8 = 0; s8 < 8; s8++)
-                bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
-        v16i cb;
-#pragma unroll
-        for (int g = 0; g < 16; g++) cb[g] = HM_FBIAS + (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        // a tile = 32 expanded trains = 8 KB: two 16-byte pieces per thread; tile t lives in tr[t & 1]
-        const int prow = threadIdx.x >> 3, pcol = (threadIdx.x & 7) * 32;
-        auto gtile = [&](int t) { return tx + (size_t)(min(t, ntiles - 1) * 32 + prow) * 256 + pcol; };      // (the blocks are padded: any tile of the set is readable)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const v4i* g = reinterpret_cast<const v4i*>(gtile(t));
-            v4i* l = reinterpret_cast<v4i*>(&tr[t][prow * HM_PITCH + pcol]);
-            l[0] = g[0]; l[1] = g[1];
-        }
-        __syncthreads();
-        v4i a[8];
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][r * HM_PITCH + 32 * s8 + 16 * h]);
-        __syncthreads();                            // tile 0 is in every wave's registers before the first tile body stores tile 2 over it
-        v16i A0, B0, A1, B1;
-        hm_tile<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], tr[0], gtile(2), r, h, prow, pcol);
-        int t = 1;
-        for (; t + 1 < ntiles; t += 2) {
-            hm_tile<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], tr[1], gtile(t + 2), r, h, prow, pcol);
-            hm_tile<true>(A0, B0, A1, B1, cb, a, bq, K, tr[1], tr[0], gtile(t + 3), r, h, prow, pcol);
-        }
-        const bool odd_last = t < ntiles;
-        if (odd_last) hm_tile<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], tr[1], gtile(t + 2), r, h, prow, pcol);
-        // the last tile's keys, masked against the train count (its chains' last MFMAs are two slots old at most)
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int ka = odd_last ? A1[g] : A0[g], kb = odd_last ? B1[g] : B0[g];      // (selected by value: a reference picked at run time would put the accumulators in memory)
-            hm_update(K, 0, (ka & (HM_MAX_TRAINS - 1)) < nt ? ka : HM_NONE);
-            hm_update(K, 1, (kb & (HM_MAX_TRAINS - 1)) < nt ? kb : HM_NONE);
-        }
-    }
-#pragma unroll
-    for (int set = 0; set < 2; set++) {
-        // the other half of the trains sits in lane (r, 1 - h)
-        const int o0 = __shfl_xor(K.k0[set], 32), o1 = __shfl_xor(K.k1[set], 32);
-        const int b0 = min(K.k0[set], o0), b1 = min(max(K.k0[set], o0), min(K.k1[set], o1));
-        const int q = q0 + wave * 64 + set * 32 + r;
-        if (h == 0 && q < nq) {
-            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
-            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
-            dist2[(off + q) * 2] = (float)(v0 ? (b0 - HM_FBIAS) >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? (b1 - HM_FBIAS) >> 13 : 1 << 30);
-        }
-    }
-}
-
-// The same pass with the train tiles copied global -> LDS by LDS-DMA (knn2_hamming_mfma4_kernel): no staging registers, no ds_write,
-// the copy of tile t + 2 runs beside tile t's MFMAs.  A DMA instruction writes 64 x 16 bytes to consecutive LDS addresses, so the
-// image has a 256-byte pitch and its 16-byte slots are XOR-swizzled (slot s of row R at position s ^ (R & 15): the fragment reads
-// of a ds_read_b128 lane group -- 16 rows, one slot -- fall in 16 different positions); each lane fetches the slot its LDS
-// position holds.  The instructions are inline assembly (the compiler would wait for every copy before the next LDS read); the
-// wait is the s_waitcnt vmcnt(0) in front of the tile's barrier.
+// Train tiles are copied global -> LDS by LDS-DMA: no staging registers, no ds_write, the copy of tile t + 2 runs beside tile t's
+// MFMAs.  A DMA instruction writes 64 x 16 bytes to consecutive LDS addresses, so the image's 16-byte slots are XOR-swizzled (below)
+// and each lane fetches the slot its LDS position holds.  The instructions are inline assembly (the compiler would wait for
+// every copy before the next LDS read); the wait is the s_waitcnt vmcnt(0) in front of the tile's barrier.
 __device__ __forceinline__ void hm_dma(const int8_t* base, unsigned voff, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_off) : "memory", "m0");
 }
-template <bool UPD>
-__device__ __forceinline__ void hm_tile4(v16i& accA, v16i& accB, const v16i& prevA, const v16i& prevB, v16i& cb, v4i* a, const v4i (&bq)[2][8], HmKeys& K,
-                                         const int8_t* lds_next, uint32_t lds_store, const int8_t* gnext, const unsigned (&voff)[2], const unsigned (&aoff)[8]) {
-    hm_dma(gnext, voff[0], lds_store);              // tile t + 2 into the buffer tile t left (its fragments were read during tile t - 1)
-    hm_dma(gnext, voff[1], lds_store + 1024);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; s8++) {
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int slot = 2 * s8 + half;
-            if (half == 0) { if (s8 == 0) HM_MFMA_FIRST(accA, a[0], bq[0][0], cb); else HM_MFMA_ACC(accA, a[s8], bq[0][s8]); }
-            else {
-                if (s8 == 0) HM_MFMA_FIRST(accB, a[0], bq[1][0], cb); else HM_MFMA_ACC(accB, a[s8], bq[1][s8]);
-                a[s8] = *reinterpret_cast<const v4i*>(lds_next + aoff[s8]);      // the next tile's fragment
-            }
-            if (slot >= 2) {
-                if (UPD) {
-                    const int lo = (slot - 2) * 32 / 14, hi = (slot - 1) * 32 / 14;
-#pragma unroll
-                    for (int i = lo; i < hi; i++) hm_update(K, i >> 4, i < 16 ? prevA[i] : prevB[i - 16]);
-                }
-                if (slot >= 4) {
-                    const int lo = (slot - 4) * 16 / 12, hi = (slot - 3) * 16 / 12;
-#pragma unroll
-                    for (int g = lo; g < hi; g++) cb[g] += 32;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void knn2_hamming_mfma4_kernel(const FeatDev* feats, const PairDesc* pairs, const HmFrame* fr, const int8_t* __restrict__ xp, int* idx2,
-                                                                 float* dist2, const HmJob* jobs) {
-    __shared__ __attribute__((aligned(1024))) int8_t tr[2][32 * 256];
-    const HmJob job = jobs[blockIdx.x];
-    if (job.pair < 0) return;                       // padding of the XCD interleave
-    const PairDesc pd = pairs[job.pair];
-    const bool fwd = job.dir == 0;
-    const int qi = fwd ? pd.i : pd.j, ti = fwd ? pd.j : pd.i;
-    const int nq = feats[qi].n, nt = feats[ti].n;
-    const size_t off = fwd ? pd.knn_off12 : pd.knn_off21;
-    const int q0 = job.q0;
-    if (q0 >= nq) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    const int8_t* qx = xp + fr[qi].query_off;
-    const int8_t* tx = xp + fr[ti].train_off;
-    HmKeys K;
-    K.k0[0] = K.k0[1] = K.k1[0] = K.k1[1] = HM_NONE;
-    const int ntiles = (nt + 31) / 32;
-    if (ntiles > 0) {
-        v4i bq[2][8];
-#pragma unroll
-        for (int set = 0; set < 2; set++)
-#pragma unroll
-            for (int s8 = 0; s8 < 8; s8++)
-                bq[set][s8] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + wave * 64 + set * 32 + r) * 256 + 32 * s8 + 16 * h);
-        v16i cb;
-#pragma unroll
-        for (int g = 0; g < 16; g++) cb[g] = HM_FBIAS + (1 << 20) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        // the wave's two copy instructions of a tile: rows 8 wave + 4 j + (lane >> 4), LDS position lane & 15 <- global slot position ^ (row & 15)
-        unsigned voff[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int R = 8 * wave + 4 * j + (lane >> 4);
-            voff[j] = (unsigned)(R * 256 + 16 * ((lane & 15) ^ (R & 15)));
-        }
-        // fragment s8 of lane (r, h): slot 2 s8 + h of row r
-        unsigned aoff[8];
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) aoff[s8] = (unsigned)(r * 256 + 16 * ((2 * s8 + h) ^ (r & 15)));
-        const uint32_t lds0 = (uint32_t)(uintptr_t)&tr[0][0] + (uint32_t)(8 * wave) * 256, lds1 = (uint32_t)(uintptr_t)&tr[1][0] + (uint32_t)(8 * wave) * 256;
-        auto gtile = [&](int t) { return tx + (size_t)min(t, ntiles - 1) * 32 * 256; };      // (the blocks are padded: any tile of the set is readable)
-        hm_dma(gtile(0), voff[0], lds0); hm_dma(gtile(0), voff[1], lds0 + 1024);
-        hm_dma(gtile(1), voff[0], lds1); hm_dma(gtile(1), voff[1], lds1 + 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        v4i a[8];
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) a[s8] = *reinterpret_cast<const v4i*>(&tr[0][aoff[s8]]);
-        // every wave has tile 0's fragments in registers before any wave's copy of tile 2 lands on them (a wave that leaves the
-        // barrier above late -- the older waves of the CU's other workgroups hold the issue slots -- would read rows of tile 2)
-        __syncthreads();
-        v16i A0, B0, A1, B1;
-        hm_tile4<false>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(2), voff, aoff);
-        int t = 1;
-        for (; t + 1 < ntiles; t += 2) {
-            hm_tile4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff);
-            hm_tile4<true>(A0, B0, A1, B1, cb, a, bq, K, tr[1], lds0, gtile(t + 3), voff, aoff);
-        }
-        const bool odd_last = t < ntiles;
-        if (odd_last) hm_tile4<true>(A1, B1, A0, B0, cb, a, bq, K, tr[0], lds1, gtile(t + 2), voff, aoff);
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int ka = odd_last ? A1[g] : A0[g], kb = odd_last ? B1[g] : B0[g];
-            hm_update(K, 0, (ka & (HM_MAX_TRAINS - 1)) < nt ? ka : HM_NONE);
-            hm_update(K, 1, (kb & (HM_MAX_TRAINS - 1)) < nt ? kb : HM_NONE);
-        }
-    }
-#pragma unroll
-    for (int set = 0; set < 2; set++) {
-        const int o0 = __shfl_xor(K.k0[set], 32), o1 = __shfl_xor(K.k1[set], 32);
-        const int b0 = min(K.k0[set], o0), b1 = min(max(K.k0[set], o0), min(K.k1[set], o1));
-        const int q = q0 + wave * 64 + set * 32 + r;
-        if (h == 0 && q < nq) {
-            const bool v0 = b0 < HM_NONE, v1 = b1 < HM_NONE;
-            idx2[(off + q) * 2] = v0 ? (b0 & (HM_MAX_TRAINS - 1)) : -1; idx2[(off + q) * 2 + 1] = v1 ? (b1 & (HM_MAX_TRAINS - 1)) : -1;
-            dist2[(off + q) * 2] = (float)(v0 ? (b0 - HM_FBIAS) >> 13 : 1 << 30); dist2[(off + q) * 2 + 1] = (float)(v1 ? (b1 - HM_FBIAS) >> 13 : 1 << 30);
-        }
-    }
-}
-
-// The same pass on the fp4 path of the matrix cores (knn2_hamming_fp4_kernel): v_mfma_scale_f32_32x32x64_f8f6f4 multiplies 64
-// E2M1 values per lane pair and instruction in the time the int8 instruction takes for 32, so a 32 x 32 tile of distances is 4
-// instructions per query set instead of 8.  A descriptor bit becomes one nibble: +4 (0x6) where a train bit is set, -4 (0xE) where
+// The fp4 path of the matrix cores (knn2_hamming_fp4_kernel): v_mfma_scale_f32_32x32x64_f8f6f4 multiplies 64 E2M1 values per lane
+// pair and instruction in the time the int8 instruction takes for 32, so a 32 x 32 tile of distances is 4 instructions per query set.  A descriptor bit becomes one nibble: +4 (0x6) where a train bit is set, -4 (0xE) where
 // it is clear, the opposite signs for a query; both operands carry the block scale 2^4, so a product is -4096 where the bits agree
 // and +4096 where they differ, and a row of 256 sums to 8192 hamming - 2^20.  The seed of the accumulator is the float 2^20 +
 // trainIdx: every partial sum is an integer below 2^24, exact in f32, and the result is the float 8192 hamming + trainIdx -- ordered
@@ -1204,21 +862,17 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     // flag of the L2 path (non-integer descriptors), copied into the pinned arena: an early return never leaves a copy aimed at this frame
     volatile int& l2_bad = *reinterpret_cast<volatile int*>(Hh + h_bad);
     l2_bad = 0;
-    static const bool hm_scalar = getenv("MIS_KNN_SCALAR") != nullptr;     // diagnostics: the vector-pipe kernel
-    if (!use_l2 && (maxq > HM_MAX_TRAINS || hm_scalar)) {
+    if (!use_l2 && maxq > HM_MAX_TRAINS) {
+        // train sets beyond the key's 13 index bits: the vector-pipe kernel (also what mis_knn2 runs)
         hipLaunchKernelGGL(knn2_hamming_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs, d_idx, d_dist);
-    } else if (!use_l2) {
-        // every frame's descriptors once as int8 (train form and query form), then all directed pairs in one MFMA launch
+    } else if (!use_l2 && !hm_jobs.empty()) {
+        // every frame's descriptors once as fp4 nibbles (train form and query form), then all directed pairs in one MFMA launch
         std::vector<HmFrame> hf(n);
         Carver lc;
-        const size_t o_fr = lc.take(sizeof(HmFrame) * n), o_jobs = lc.take(sizeof(HmJob) * std::max<size_t>(hm_jobs.size(), 1));
-        static const bool hm_v1 = getenv("MIS_KNN_MFMA_V1") != nullptr;     // diagnostics: round 2's form of the pass
-        static const bool hm_fp4_env = getenv("MIS_KNN_FP4") ? atoi(getenv("MIS_KNN_FP4")) != 0 : true;      // MIS_KNN_FP4=0: the int8 forms of the pass
-        const bool hm_fp4 = hm_fp4_env && !hm_v1 && !hm_jobs.empty();
-        const size_t row_bytes = hm_fp4 ? 128 : 256;
+        const size_t o_fr = lc.take(sizeof(HmFrame) * n), o_jobs = lc.take(sizeof(HmJob) * hm_jobs.size());
         for (int i = 0; i < n; i++) {
             const size_t rows = (size_t)(std::max(feats[i].n, 1) + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
-            hf[i].train_off = lc.take(rows * row_bytes); hf[i].query_off = lc.take(rows * row_bytes);
+            hf[i].train_off = lc.take(rows * 128); hf[i].query_off = lc.take(rows * 128);
         }
         MIS_HIP(ctx, ws->l2.reserve(lc.off));
         uint8_t* L = (uint8_t*)ws->l2.p;
@@ -1226,17 +880,13 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         memcpy(h_fr, hf.data(), sizeof(HmFrame) * n);
         MIS_HIP(ctx, hipMemcpyAsync(L + o_fr, h_fr, sizeof(HmFrame) * n, hipMemcpyHostToDevice, st));
         const int maxpad = (maxq + HM_ROWPAD - 1) / HM_ROWPAD * HM_ROWPAD;
-        hipLaunchKernelGGL(hm_fp4 ? hamming_expand4_kernel : hamming_expand_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
-        if (hm_v1 || hm_jobs.empty()) {
-            hipLaunchKernelGGL(knn2_hamming_mfma_kernel, dim3((maxq + 255) / 256, 2 * np), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
-                               (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist);
-        } else {
-            memcpy(Hh + h_jobs, hm_jobs.data(), sizeof(HmJob) * hm_jobs.size());
-            MIS_HIP(ctx, hipMemcpyAsync(L + o_jobs, Hh + h_jobs, sizeof(HmJob) * hm_jobs.size(), hipMemcpyHostToDevice, st));
-            static const bool hm_dma_on = getenv("MIS_KNN_DMA") ? atoi(getenv("MIS_KNN_DMA")) != 0 : true;      // MIS_KNN_DMA=0: the form that stages the train tiles through registers (0.645 ms; 0.58 with LDS-DMA)
-            hipLaunchKernelGGL(hm_fp4 ? knn2_hamming_fp4_kernel : hm_dma_on ? knn2_hamming_mfma4_kernel : knn2_hamming_mfma2_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
-                               (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist, (const HmJob*)(L + o_jobs));
-        }
+        hipLaunchKernelGGL(hamming_expand4_kernel, dim3(maxpad * 8 / 256, n), dim3(256), 0, st, (const FeatDev*)d_feats, (const HmFrame*)(L + o_fr), (int8_t*)L);
+        memcpy(Hh + h_jobs, hm_jobs.data(), sizeof(HmJob) * hm_jobs.size());
+        MIS_HIP(ctx, hipMemcpyAsync(L + o_jobs, Hh + h_jobs, sizeof(HmJob) * hm_jobs.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(knn2_hamming_fp4_kernel, dim3((unsigned)hm_jobs.size()), dim3(256), 0, st, (const FeatDev*)d_feats, (const PairDesc*)d_pairs,
+                           (const HmFrame*)(L + o_fr), (const int8_t*)L, d_idx, d_dist, (const HmJob*)(L + o_jobs));
+    } else if (!use_l2) {
+        // no query anywhere (every frame without features): nothing to search, the lists stay empty
     } else {
         // fp16 copies + squared norms of every image once, then one MFMA distance pass per directed pair
         std::vector<size_t> hoff(n), noff(n);

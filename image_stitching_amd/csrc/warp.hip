@@ -794,7 +794,7 @@ typedef __attribute__((address_space(3))) uint8_t* lds_p;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
-enum { V3F_WIDE_SRC = 1, V3F_FAST_OK = 2, V3F_WIDE_OUT = 4, V3F_WIDE_MASK = 8 };
+enum { V3F_WIDE_SRC = 1, V3F_FAST_OK = 2, V3F_WIDE_OUT = 4, V3F_WIDE_MASK = 8, V3F_STAMP = 16 /* diagnostics build: this frame records its tiles' stamps */ };
 struct V3Frame {        // everything a frame's strips share (filled on the host: v3_frame_of)
     float m[9];
     float xhi2, yhi2;   // mask test: a coordinate rounds inside the frame iff -0.5 <= v < hi2
@@ -1224,7 +1224,9 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
                         if (wide_out) {
                             // scalar base + 32-bit lane offset + immediate: no 64-bit address pair per lane (three of them cost the
                             // kernel its fifth wave per SIMD)
-                            asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %0, %2, %4 offset:128\n\tglobal_store_dwordx4 %0, %3, %4 offset:256"
+                            // (s_nop 1: a store of more than 64 bits needs two wait states before its data VGPRs are overwritten, and the
+                            // hazard recogniser does not see inside the statement -- tests/test_build_checks.py looks for it)
+                            asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %0, %2, %4 offset:128\n\tglobal_store_dwordx4 %0, %3, %4 offset:256\n\ts_nop 1"
                                          ::"v"(poff), "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(dg) : "memory");
                         } else {
 #pragma unroll
@@ -1277,7 +1279,7 @@ __device__ __forceinline__ void warp_strip_body(const V3Frame& f, int tx0, int t
             }
             drow += (size_t)V3_TH * f.dstride; mrow += (size_t)V3_TH * f.mstride;
 #ifdef WV_STAMPS
-            if (lane == 0 && (gridDim.y == 1 || blockIdx.y == gridDim.y / 2)) {      // one frame of a batched grid: the steady state
+            if (lane == 0 && (f.flags & V3F_STAMP)) {      // one frame of a batched grid (the middle one): the steady state
                 const int tile = (ty_first + k) * ((f.dw + V3_TW - 1) / V3_TW) + tx0 / V3_TW;
                 if (tile < 16384) { unsigned long long* o = g_warp_stamps + 8 * tile; for (int q = 0; q < 6; q++) o[q] = st[q]; o[6] = wall0; o[7] = wall_clock64(); }
             }
@@ -1356,8 +1358,41 @@ static V3Frame v3_frame_of(const WarpArgs& a, const float* tab) {
 }
 struct V3Batch {
     V3Frame f[WB_MAX];
-    int nwg[WB_MAX];
+    int wg_base[WB_MAX + 1];    // frame k owns workgroups wg_base[k] .. wg_base[k + 1] - 1 of the (one-dimensional) grid; multiples of 8
+    int nt[WB_MAX];             // tiles per strip of frame k
 };
+
+// Tiles per strip for every frame of one launch (frames in grid order).  `base` is what v3_strip_tiles asks for; the frames at the
+// end of the grid get shorter strips so that the launch's tail is made of short waves: a frame whose tiles all lie within the last
+// `WV3_TAIL2` tile-rounds of the launch (one round = one tile per wave slot of the device) takes 2-tile strips, within the last
+// WV3_TAIL4 rounds 4-tile strips.  (Short strips pay the pipeline's fill more often: 3 maps per 2 gathers instead of 9 per 8.)
+#ifndef WV3_TAIL2
+#define WV3_TAIL2 4
+#endif
+#ifndef WV3_TAIL4
+#define WV3_TAIL4 8
+#endif
+static void v3_plan_strips(const MisContext* ctx, const WarpArgs* args, int ng, int base, int* nt_out) {
+    const long long slots = (long long)std::max(ctx->num_cu, 1) * 4 * WV3_WAVES_MIN;
+    long long after = 0;        // tiles of the frames behind frame k in the grid
+    static const char* plan_env = getenv("MIS_WARP_NT_PLAN");      // experiments: "8,8,...,4,2" (per frame of a launch, the last entry repeats)
+    for (int k = ng - 1; k >= 0; k--) {
+        const long long tiles = (long long)((args[k].dw + V3_TW - 1) / V3_TW) * ((args[k].dh + V3_TH - 1) / V3_TH);
+        int nt = base;
+        if (after + tiles <= slots * WV3_TAIL2) nt = std::min(nt, 2);
+        else if (after + tiles <= slots * WV3_TAIL4) nt = std::min(nt, 4);
+        nt_out[k] = nt;
+        after += tiles;
+    }
+    if (plan_env) {
+        int v = base, k = 0;
+        const char* p = plan_env;
+        while (k < ng) {
+            if (*p) { v = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
+            nt_out[k++] = std::max(1, std::min(v, WV3_NT_MAX));
+        }
+    }
+}
 
 #ifndef WV3_SEQ_WAVES_MIN
 #define WV3_SEQ_WAVES_MIN 6
@@ -1390,14 +1425,21 @@ __global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
     warp_strip_body<false, WV3_SEQ_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
 }
-__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_batch_kernel(V3Batch b, int nt) {
+// The compose loop's grid: the strips of all frames of a batch, frame after frame, in ONE one-dimensional grid.  The dispatcher
+// hands out workgroups in index order as slots free up, so the strips of the LAST frames are the launch's tail: the host plans
+// them shorter (v3_plan_strips) -- with 8-tile strips everywhere a 16-frame launch is 7.25 generations of ~37 us waves and a
+// quarter of the slots run an eighth wave while the others idle.
+__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_batch_kernel(V3Batch b) {
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
-    const int fi = blockIdx.y;
-    if ((int)blockIdx.x >= b.nwg[fi]) return;      // the grid covers the largest frame of the batch
+    const int bid = (int)blockIdx.x;
+    int fi = 0;
+#pragma unroll
+    for (int k = 1; k < WB_MAX; k++) fi += bid >= b.wg_base[k] ? 1 : 0;       // (uniform: scalar compares on the kernel arguments)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const V3Frame& f = b.f[fi];
+    const int nt = b.nt[fi];
     int tx0, ty_first;
-    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
+    if (!v3_strip_of(bid - b.wg_base[fi], wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
     warp_strip_body<true, V3_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
 }
 
@@ -1657,6 +1699,7 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
     std::vector<WarpBatch> batches;
     std::vector<dim3> grids;
 #if WV_V3
+    std::vector<V3Batch> v3batches;
     int nt3 = 1 << 30;      // tiles per strip: one value for the grid (the smallest any frame asks for)
     for (int i = 0; i < n; i++) nt3 = std::min(nt3, v3_strip_tiles(ctx, args[i], n));
 #endif
@@ -1668,13 +1711,31 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
             const int i = g0 + (k < ng ? k : 0);
             b.a[k] = args[i]; b.tab[k] = (const float*)((uint8_t*)ctx->stage + tab_off[i]);
             b.nwg[k] = grid_of(args[i], &b.ntiles[k]);
-#if WV_V3
-            b.nwg[k] = v3_grid_of(args[i], nt3);
-#endif
             if (k < ng) { max_wg = std::max(max_wg, b.nwg[k]); max_trig = std::max(max_trig, (trig_cols(args[i].dw) + args[i].dh + 255) / 256); }
         }
         hipLaunchKernelGGL(warp_trig_batch_kernel, dim3(max_trig, ng), dim3(256), 0, ctx->stream, b);
+#if WV_V3
+        // one-dimensional grid: frame after frame, per-frame strip lengths (short strips for the frames at the launch's end)
+        V3Batch vb;
+        int nts[WB_MAX];
+        v3_plan_strips(ctx, &args[g0], ng, nt3, nts);
+        int wg = 0;
+        for (int k = 0; k < WB_MAX; k++) {
+            vb.f[k] = v3_frame_of(b.a[k], b.tab[k]);
+#ifdef WV_STAMPS
+            if (k == ng / 2) vb.f[k].flags |= V3F_STAMP;
+#endif
+            vb.nt[k] = k < ng ? nts[k] : 1;
+            vb.wg_base[k] = wg;
+            if (k < ng) wg += v3_grid_of(args[g0 + k], nts[k]);
+        }
+        vb.wg_base[WB_MAX] = wg;
+        v3batches.push_back(vb);
+        max_wg = wg; 
+        batches.push_back(b); grids.push_back(dim3(max_wg));
+#else
         batches.push_back(b); grids.push_back(dim3(max_wg, ng));
+#endif
     }
     if (avg_us) {
         MIS_HIP(ctx, hipEventCreate(&e0));
@@ -1684,11 +1745,7 @@ static int warp_fused_batch_impl(MisContext* ctx, const MisImage* srcs, int n, f
     for (int rep = 0; rep < repeats; rep++)
         for (size_t g = 0; g < batches.size(); g++)
 #if WV_V3
-            {
-                V3Batch vb;
-                for (int k = 0; k < WB_MAX; k++) { vb.f[k] = v3_frame_of(batches[g].a[k], batches[g].tab[k]); vb.nwg[k] = batches[g].nwg[k]; }
-                hipLaunchKernelGGL(warp_strip_batch_kernel, grids[g], dim3(64 * V3_WAVES), 0, ctx->stream, vb, nt3);
-            }
+            hipLaunchKernelGGL(warp_strip_batch_kernel, grids[g], dim3(64 * V3_WAVES), 0, ctx->stream, v3batches[g]);
 #else
             hipLaunchKernelGGL(warp_fused_batch_kernel, grids[g], dim3(64 * TILE_WAVES), 0, ctx->stream, batches[g]);
 #endif

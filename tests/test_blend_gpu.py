@@ -218,3 +218,64 @@ def test_feed_batch_edge_cases(ctx, oracle_mod):
     gout, gmask = gb.blend()
     ctx.synchronize()
     assert np.array_equal(gout.cpu().numpy(), oref) and np.array_equal(gmask.cpu().numpy(), omask)
+
+
+def test_feather_wide_ragged_masks_bit_exact(ctx, oracle_mod):
+    """K15's scans outside the easy case: rows wider than one 4096-pixel chunk, rows without any zero, zeros only in a later chunk,
+    columns whose nearest zero lies several 32-row segments away, an all-zero and an all-255 frame."""
+    rng = np.random.default_rng(31)
+    w, h = 9100, 150
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.int16)
+    mask = np.full((h, w), 255, np.uint8)
+    mask[0:3, 5000:5003] = 0                  # the only zeros of many rows' columns: far above
+    mask[40, 8800] = 0                        # a row whose only zero sits in the third chunk
+    mask[90:95, 10:4000] = 0
+    mask[120, :] = 0
+    mask[rng.integers(0, h, 40), rng.integers(0, w, 40)] = 0
+    frames = [(img, mask, (0, 0)),
+              (img[:, :300].copy(), np.zeros((h, 300), np.uint8), (50, 3)),
+              (img[:, 300:700].copy(), np.full((h, 400), 255, np.uint8), (200, -2))]
+    _run_both(ctx, oracle_mod, oracle_mod.BLEND_FEATHER, frames, sharp=1.0 / 37.0, check_levels=False)
+    _run_both(ctx, oracle_mod, oracle_mod.BLEND_FEATHER, frames, sharp=0.0004)      # weights below 1 across thousands of pixels
+
+
+def test_feather_config3_4k_pair_bit_exact(ctx, oracle_mod):
+    """FeatherBlender at frame size: two adjacent 3840 x 2160 frames of config 3 through the fused warp and the
+    feather blender with the sharpness image_stitching.cpp:1186-1190 gives for the 16-frame panorama: accumulated image and
+    weight sums (f32 as bits) after the feeds, then the blended panorama and mask."""
+    import torch
+    import synth
+    import image_stitching_amd as isa
+    cams_all = synth.workload("config3")
+    w, h = 3840, 2160
+    scale = isa.Stitcher.warped_image_scale(cams_all)
+    rois_all = isa.stitching.warp_rois(ctx, scale, (w, h), cams_all)
+    x0 = min(r[0] for r in rois_all); y0 = min(r[1] for r in rois_all)
+    x1 = max(r[0] + r[2] for r in rois_all); y1 = max(r[1] + r[3] for r in rois_all)
+    btype, _, sharp = oracle_mod.blend_config(oracle_mod.BLEND_FEATHER, 5.0, x1 - x0, y1 - y0)
+    assert btype == oracle_mod.BLEND_FEATHER and 0 < sharp < 0.01
+    pair = [7, 8]
+    cams = [cams_all[i] for i in pair]
+    dev = [synth.render_frame_gpu(c) for c in cams]
+    torch.cuda.synchronize()
+    warper = isa.SphericalWarper(ctx, scale)
+    batch = warper.warp_fused_batch(dev, cams, [rois_all[i] for i in pair])
+    gb, ob = isa.FeatherBlender(ctx, sharp), oracle_mod.Blender(oracle_mod.BLEND_FEATHER, 0, sharp)
+    corners = [b[0] for b in batch]
+    sizes = [(b[2].shape[1], b[2].shape[0]) for b in batch]
+    gb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    for cam, fd, (tl, img_s, msk) in zip(cams, dev, batch):
+        K, R = cam["K"].astype(np.float32), cam["R"].astype(np.float32)
+        oi, otl = oracle_mod.warp_spherical(fd.cpu().numpy(), scale, K, R)
+        om, _ = oracle_mod.warp_spherical(np.full((h, w), 255, np.uint8), scale, K, R, 0, 0)
+        assert otl == tl and np.array_equal(img_s.cpu().numpy(), oi.astype(np.int16)) and np.array_equal(msk.cpu().numpy(), om)
+        gb.feed(img_s, msk, tl)
+        ob.feed(oi.astype(np.int16), om, tl)
+    gl, gw = gb.level(0)
+    ol, ow = ob.level(0)
+    assert np.array_equal(gw.view(np.uint32), ow.view(np.uint32)), "feather weight sums"
+    assert np.array_equal(gl, ol), "feather accumulated image"
+    gp, gm = gb.blend()
+    op, om_ = ob.blend()
+    assert np.array_equal(gm.cpu().numpy(), om_) and np.array_equal(gp.cpu().numpy(), op)
