@@ -35,8 +35,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="config2 | config3 | config4 (default: config3, config4 when --gpus > 1)")
     ap.add_argument("--features", default=None, help="orb | sift (default: orb; sift for config5, BASELINE.json configs[4])")
-    ap.add_argument("--pipeline", default="hot_path", choices=["hot_path", "reference_default"],
-                    help="hot_path (the north star: no exposure / seam step) | reference_default (gain_blocks compensator + dp_color seams, rows N1b; not the metric)")
+    ap.add_argument("--pipeline", default="hot_path", choices=["hot_path", "hot_path_plus_seams", "reference"],
+                    help="hot_path (the north star: no exposure / seam step, compose_megapix = -1) | hot_path_plus_seams (the same with the gain_blocks "
+                         "compensator + dp_color seams, rows N1b) | reference (what the reference's main() runs with its globals untouched: reprojection "
+                         "bundle adjustment + wave correction, gain blocks, dp_color, seam_megapix 0.1, compose_megapix 0.4; not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpp-host", action="store_true", help="skip the C++-host leg (host/stitch_bench on the same workload)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage timing table to stderr")
@@ -133,8 +135,10 @@ def main():
     W, H = cams[0]["width"], cams[0]["height"]
     ctx = isa.Context(local_rank)
     features = args.features or ("sift" if workload == "config5" else "orb")
-    # the north-star path: no exposure / seam step (SURVEY rows N1b are "next"); --pipeline reference_default times the job with them
-    cfg = isa.StitchConfig.hot_path(features_type=features) if args.pipeline == "hot_path" else isa.StitchConfig(features_type=features)
+    # the north-star path: no exposure / seam step (SURVEY rows N1b are "next"); --pipeline hot_path_plus_seams | reference time the job with them
+    cfg = {"hot_path": lambda: isa.StitchConfig.hot_path(features_type=features),
+           "hot_path_plus_seams": lambda: isa.StitchConfig(features_type=features, compose_megapix=-1),
+           "reference": lambda: isa.StitchConfig.reference(features_type=features)}[args.pipeline]()
     job = misdist.StitchJob(ctx, (W, H), cams, rank=rank, world_size=world, group=pg, config=cfg)
     # synthetic frames of this rank's shard, rendered straight into HBM
     frames = {i: synth.render_frame_gpu(cams[i], device="cuda:%d" % local_rank) for i in job.my_frames}
@@ -218,16 +222,23 @@ def main():
             "ms_per_step_median": round(sorted(trace)[len(trace) // 2], 3), "ms_per_step_min": round(min(trace), 3),      # this rank's steps (value is the mean)
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s: %d x %dx%d frames, %s + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=-1"
-                                   % (workload, n, W, H, "SIFT (128-D f32, L2 on fp16 MFMA)" if features == "sift" else "ORB 4000"),
+            "config": {"workload": "%s: %d x %dx%d frames, %s + all-pairs 2-NN/RANSAC + spherical warp + multiband blend, compose_megapix=%s"
+                                   % (workload, n, W, H, "SIFT (128-D f32, L2 on fp16 MFMA)" if features == "sift" else "ORB 4000", cfg.compose_megapix),
                        "frames": n, "frame_size": [W, H], "pairs": n * (n - 1) // 2, "pano_size": list(out["pano_size"]),
                        "num_bands": out["num_bands"], "parallelism": "frames sharded %d/GPU" % (n // world),
                        "pipeline": args.pipeline,
                        "warp_roi": "computed inside every timed step (mis_warp_roi_batch: one kernel for all frames, nothing cached)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not args.no_cpp_host:
-            res["cpp_host"] = cpp_host_leg(cams, args)       # the same job driven from C++ (host/stitch_bench), after this process's GPU work
+        if args.pipeline == "hot_path" and features == "orb" and not args.no_cpp_host:
+            # the same job driven from C++ (host/stitch_bench), after this process's timed region: mis::StitchJob on one GPU; for N > 1
+            # mis::ShardedJob on N child ranks with RCCL called directly (the ranks of this script idle at the barrier below meanwhile)
+            res["cpp_host"] = cpp_host_leg(cams, args, world, rehearsal)
+        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not os.environ.get("MIS_BENCH_NO_OVERLAP"):
+            try:
+                res["two_jobs_in_flight"] = two_jobs_leg(isa, misdist, ctx, job, cams, (W, H), cfg, frames, max(4, args.steps // 2))
+            except Exception as e:       # informational: never costs the line
+                res["two_jobs_in_flight"] = {"error": str(e)[:200]}
         if single:
             res["same_workload_on_1_gpu"] = single
             res["speedup_vs_1_gpu_same_workload"] = round(value / single["value"], 3)
@@ -238,6 +249,56 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def two_jobs_leg(isa, misdist, ctx, job_a, cams, size, cfg, frames, steps):
+    """Informational, NOT `value`: two independent panorama jobs of the same workload in flight on the one GPU (two host threads,
+    each job with its own contexts and streams).  A single job leaves the device mostly idle while its RANSAC chains run (latency
+    chains of a few workgroups): a second job's feature stage and composition fill that time.  Throughput of a stitching service,
+    where `value` is one job's turn-around."""
+    import threading
+    s2 = torch.cuda.Stream(device=ctx.device)
+    with torch.cuda.stream(s2):
+        ctx_b = isa.Context(ctx.device.index)           # a context on a stream of its own
+    job_b = misdist.StitchJob(ctx_b, size, cams, config=cfg)
+    streams = [torch.cuda.current_stream(ctx.device), s2]
+    jobs = [job_a, job_b]
+    err = []
+    gate = threading.Barrier(3)
+
+    def worker(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                for _ in range(3):
+                    jobs[k].run(frames)         # warm: allocations of the second job
+                torch.cuda.synchronize()
+                gate.wait()
+                for _ in range(steps):
+                    jobs[k].run(frames)
+                torch.cuda.synchronize()
+        except BaseException as e:
+            err.append(e)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    try:
+        gate.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    n = len(cams)
+    return {"value": round(2 * steps * n / dt, 3), "unit": "frames/s", "jobs_in_flight": 2, "steps_per_job": steps, "ms_per_job_pair": round(dt / steps * 1e3, 3),
+            "what": "two independent jobs of the same workload overlapped on one GPU (one host thread, context pair and stream set per job): "
+                    "service throughput; informational -- `value` above is ONE job at a time"}
 
 
 def _events_ms(stream, fn, reps=1):
@@ -449,9 +510,11 @@ def measure_roofline(ctx, job, frames, cams, launches):
                                      "normalise, collapse, crop) -- more bytes than the fused kernels move; secondary, not the graded figure"},
             "parts": parts}
 
-def cpp_host_leg(cams, args):
+def cpp_host_leg(cams, args, world=1, rehearsal=False):
     """The same job (frames in HBM, ORB -> matcher with the composition speculated from its hook -> collapse) driven by the C++ host
-    over the C ABI: host/stitch_bench as a child process (this process's timed region is over; the child owns the GPU meanwhile)."""
+    over the C ABI: host/stitch_bench as a child process (this process's timed region is over; the child owns the GPU meanwhile).
+    world > 1: `--ranks N` -- the C++ sharded job (host/sharded_job.cpp) on N child ranks of stitch_bench, exchanges through RCCL
+    (`--comm host --one-gpu` in a one-GPU rehearsal: RCCL refuses two ranks on one device)."""
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "host", "stitch_bench")
@@ -465,13 +528,16 @@ def cpp_host_leg(cams, args):
                 vals = [c["f"], c["K"][0, 2], c["K"][1, 2], c.get("gain", 1.0)] + [float(v) for v in np.asarray(c["R"], np.float64).reshape(9)]
                 fh.write(" ".join(repr(float(v)) for v in vals) + "\n")
         try:
-            r = subprocess.run([exe, path, "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=600)
+            cmd = [exe, path, "--steps", str(args.steps), "--warmup", str(args.warmup)]
+            if world > 1:
+                cmd += ["--ranks", str(world)] + (["--comm", "host", "--one-gpu"] if rehearsal else ["--comm", "rccl"])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         except subprocess.TimeoutExpired:
             return {"error": "host/stitch_bench timed out"}
     if r.returncode != 0:
         return {"error": (r.stdout + r.stderr)[-300:]}
     try:
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     except (ValueError, IndexError):
         return {"error": "no result line from host/stitch_bench"}
 

@@ -284,12 +284,16 @@ class HipEngine:
         self.blender.feed(img_s, mask, tl)
 
     # ---- compose ----
-    def warp_roi(self, scale, cam):
-        return st.warp_roi(scale, self.frame_size, cam["K"], cam["R"])
+    def warp_roi(self, scale, cam, size=None):
+        return st.warp_roi(scale, size or self.frame_size, cam["K"], cam["R"])
 
-    def warp_rois(self, scale, cams):
+    def warp_rois(self, scale, cams, size=None):
         """warpRoi of every camera (image_stitching.cpp:1119-1140): one kernel on the compose stream, nothing cached."""
-        return st.warp_rois(self.cctx, scale, self.frame_size, cams)
+        return st.warp_rois(self.cctx, scale, size or self.frame_size, cams)
+
+    def resize_frame(self, frame, f):
+        """cv::resize(full_img, img, Size(), f, f, INTER_LINEAR_EXACT) (image_stitching.cpp:1143-1146) on the compose stream."""
+        return st.resize(self.cctx, frame, fx=f, fy=f)
 
     def begin_compose(self, scale, corners, sizes):
         x, y, pw, ph = st.result_roi(corners, sizes)
@@ -430,6 +434,7 @@ class StitchJob:
         st.check_seam_config(self.cfg)
         self.engine = engine or HipEngine(ctx, frame_size, self.cfg)
         self.cams = cameras
+        self.cams0 = cameras          # the caller's cameras; self.cams holds the refined ones after a run with bundle adjustment
         self.n = len(cameras)
         self.rank, self.world = rank, world_size
         self.comm = Comm(rank, world_size, group, always_collective)
@@ -472,21 +477,29 @@ class StitchJob:
         eng = self.engine
         # the reference takes the median focal of the KEPT cameras (image_stitching.cpp:746-748, :884-895)
         self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])
+        # compose scale (:1105-1140): warper scale, intrinsics and frame size of the compositing loop
+        g = st.compose_geometry(self.cfg, self.frame_size, self.scale)
+        self._geom = g
+        ccams = {i: st.scaled_camera(self.cams[i], g.aspect) for i in indices} if g.aspect != 1.0 else {i: self.cams[i] for i in indices}
+        if g.size != tuple(self.frame_size) and not hasattr(eng, "resize_frame"):
+            raise NotImplementedError("this engine does not resize frames (compose_megapix > 0 needs resize_frame)")
         if hasattr(eng, "warp_rois"):
-            rois = dict(zip(indices, eng.warp_rois(self.scale, [self.cams[i] for i in indices])))
+            rois = dict(zip(indices, eng.warp_rois(g.warp_scale, [ccams[i] for i in indices], g.size)))
         else:
-            rois = {i: eng.warp_roi(self.scale, self.cams[i]) for i in indices}
+            rois = {i: eng.warp_roi(g.warp_scale, ccams[i], g.size) for i in indices}
         corners = [(rois[i][0], rois[i][1]) for i in indices]
         sizes = [(rois[i][2], rois[i][3]) for i in indices]
-        btype, bands = eng.begin_compose(self.scale, corners, sizes)
-        self._compose_indices, self._compose_rois = indices, rois
+        btype, bands = eng.begin_compose(g.warp_scale, corners, sizes)
+        self._compose_indices, self._compose_rois, self._compose_cams = indices, rois, ccams
         return btype, bands
 
     def stage_compose(self, frames, indices, prepared=None):
         eng = self.engine
         btype, bands = prepared if prepared is not None else self.stage_compose_prepare(indices)
-        rois = self._compose_rois
+        rois, ccams, g = self._compose_rois, self._compose_cams, self._geom
         mine = [i for i in self.my_frames if i in rois]
+        # the loop's frames at compose scale (:1143-1146: INTER_LINEAR_EXACT when |compose_scale - 1| > 0.1)
+        cframes = {i: eng.resize_frame(frames[i], g.compose_scale) for i in mine} if g.size != tuple(self.frame_size) else frames
         if self.seam_needed:
             marks = getattr(self, "marks", None)
             if marks is not None:
@@ -495,16 +508,16 @@ class StitchJob:
             if marks is not None:
                 marks.append(("compose: seams solved", time.perf_counter()))
             if hasattr(eng, "warp_feed_seam_many"):
-                eng.warp_feed_seam_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine], [indices.index(i) for i in mine])
+                eng.warp_feed_seam_many([cframes[i] for i in mine], [ccams[i] for i in mine], [rois[i] for i in mine], [indices.index(i) for i in mine])
             else:
                 for i in mine:
-                    eng.warp_feed_seam(frames[i], self.cams[i], rois[i], indices.index(i))
+                    eng.warp_feed_seam(cframes[i], ccams[i], rois[i], indices.index(i))
             return btype, bands
         if hasattr(eng, "warp_feed_many"):
-            eng.warp_feed_many([frames[i] for i in mine], [self.cams[i] for i in mine], [rois[i] for i in mine])
+            eng.warp_feed_many([cframes[i] for i in mine], [ccams[i] for i in mine], [rois[i] for i in mine])
         else:
             for i in mine:
-                eng.warp_feed(frames[i], self.cams[i], rois[i])
+                eng.warp_feed(cframes[i], ccams[i], rois[i])
         return btype, bands
 
     def stage_seam(self, frames, indices):
@@ -760,8 +773,8 @@ class StitchJob:
                     # the adjuster needs every connected pair's inlier matches, and the pairs were dealt over the ranks: every
                     # rank contributes the entries it owns, all ranks assemble the same table and run the same (host) solver
                     pm = self.engine.matches_from_entries(self.comm.all_gather_objects(self.engine.match_entries(pm, self.cfg.conf_thresh)), self.n)
-                refined = self.engine.refine_cameras(feats, pm, indices, self.cams)
-                self.cams = list(self.cams)
+                refined = self.engine.refine_cameras(feats, pm, indices, self.cams0)     # every run starts from the cameras the job was given
+                self.cams = list(self.cams0)
                 for i, c in zip(indices, refined):
                     self.cams[i] = c
                 self.scale = st.Stitcher.warped_image_scale([self.cams[i] for i in indices])

@@ -954,6 +954,43 @@ def seam_solve(ctx, cfg, corners, images_warped, masks_warped):
 
 
 @dataclass
+class ComposeGeometry:
+    compose_scale: float      # min(1, sqrt(compose_megapix * 1e6 / area)); 1 when compose_megapix <= 0
+    aspect: float             # compose_work_aspect = compose_scale / work_scale (work_scale = 1: features at full resolution)
+    warp_scale: float         # warped_image_scale * (float)compose_work_aspect
+    size: tuple               # frame size inside the compositing loop
+
+
+def compose_geometry(cfg, frame_size, warped_image_scale):
+    """The scales of the compositing loop (image_stitching.cpp:1105-1146): compose_scale from compose_megapix, the warper's scale
+    and the intrinsics multiplied by compose_work_aspect, and -- only when |compose_scale - 1| > 0.1, as the reference tests it --
+    frames and their sizes resized (cvRound)."""
+    w, h = frame_size
+    cs = 1.0
+    if cfg.compose_megapix > 0:
+        cs = min(1.0, float(np.sqrt(cfg.compose_megapix * 1e6 / (w * h))))
+    aspect = cs / 1.0
+    warp_scale = float(np.float32(warped_image_scale) * np.float32(aspect))
+    size = (int(round(w * cs)), int(round(h * cs))) if abs(cs - 1) > 1e-1 else (int(w), int(h))      # cvRound: half to even, as Python's round
+    return ComposeGeometry(cs, aspect, warp_scale, size)
+
+
+def scaled_camera(cam, aspect):
+    """cameras[i].focal *= a; ppx *= a; ppy *= a (image_stitching.cpp:1122-1125), in double like CameraParams; K() = [f 0 ppx; 0 f*aspect ppy]"""
+    K = np.array(cam["K"], np.float64)
+    f = K[0, 0] * aspect
+    K2 = K.copy()
+    K2[0, 0] = f
+    K2[1, 1] = f * (K[1, 1] / K[0, 0])
+    K2[0, 2] = K[0, 2] * aspect
+    K2[1, 2] = K[1, 2] * aspect
+    d = dict(cam)
+    d["K"] = K2
+    d["f"] = f
+    return d
+
+
+@dataclass
 class StitchConfig:
     """The reference's globals-as-config (image_stitching.cpp:49-85), same defaults; compose_megapix
     <= 0 keeps frames at full resolution through warp + blend (the throughput configuration)."""
@@ -979,11 +1016,19 @@ class StitchConfig:
     seam_find_type: str = "dp_color"       # "no" | "voronoi" | "dp_color"
 
     @classmethod
+    def reference(cls, **kw):
+        """What the reference's main() runs with its globals untouched (image_stitching.cpp:49-85): reprojection bundle adjustment +
+        horizontal wave correction, block gain compensation, dp_color seams, seam_megapix 0.1, compose_megapix 0.4."""
+        kw.setdefault("ba_cost_func", "reproj")
+        return cls(**kw)
+
+    @classmethod
     def hot_path(cls, **kw):
         """The configuration of the north-star hot path (features -> match -> warp -> blend): no exposure compensation and no
         seam finder (the steps between warp and blend); everything else as given."""
         kw.setdefault("expos_comp_type", "no")
         kw.setdefault("seam_find_type", "no")
+        kw.setdefault("compose_megapix", -1)      # true-resolution warp + blend: the throughput configuration (SURVEY 8(d), F7)
         return cls(**kw)
 
 
@@ -1016,12 +1061,19 @@ class Stitcher:
         return float(np.float32(focals[n // 2 - 1] + focals[n // 2]) * np.float32(0.5))
 
     def compose(self, frames, cameras, indices=None, blender=None):
-        """Compositing loop (image_stitching.cpp:1086-1225) with compose_scale = 1."""
+        """Compositing loop (image_stitching.cpp:1086-1225), frames and intrinsics at compose scale (compose_megapix)."""
         indices = list(range(len(frames)) if indices is None else indices)
         # the reference replaces `cameras` by the kept subset (image_stitching.cpp:746-748) before the median focal (:884-895)
         scale = self.warped_image_scale([cameras[i] for i in indices])
+        g = compose_geometry(self.cfg, self.frame_size, scale)
+        seam = self.seam_step(frames, cameras, indices, scale)      # at seam scale, with the un-scaled intrinsics (:973-1065)
+        if g.aspect != 1.0:
+            cameras = {i: scaled_camera(cameras[i], g.aspect) for i in indices}
+        if g.size != tuple(self.frame_size):
+            frames = {i: resize(self.ctx, frames[i], fx=g.compose_scale, fy=g.compose_scale) for i in indices}
+        scale = g.warp_scale
         warper = SphericalWarper(self.ctx, scale)
-        w, h = self.frame_size
+        w, h = g.size
         rois = warp_rois(self.ctx, scale, (w, h), [cameras[i] for i in indices])
         corners = [(r[0], r[1]) for r in rois]
         sizes = [(r[2], r[3]) for r in rois]
@@ -1035,7 +1087,6 @@ class Stitcher:
             else:
                 blender = Blender(self.ctx)
         blender.prepare(corners, sizes)
-        seam = self.seam_step(frames, cameras, indices, scale)
         for k, i in enumerate(indices):
             tl, img_s, mask = warper.warp_fused(frames[i], cameras[i]["K"], cameras[i]["R"], rois[k])
             if seam is not None:

@@ -80,9 +80,12 @@ class OracleEngine:
     def confidence_tensor(self, pm, n):
         return torch.tensor([m.confidence for m in pm], dtype=torch.float64).view(n, n)
 
-    def warp_roi(self, scale, cam):
-        w, h = self.frame_size
+    def warp_roi(self, scale, cam, size=None):
+        w, h = size or self.frame_size
         return oracle.warp_roi(scale, w, h, cam["K"].astype(np.float32), cam["R"].astype(np.float32))
+
+    def resize_frame(self, frame, f):
+        return oracle.resize_exact(np.asarray(frame), fx=f, fy=f)
 
     def begin_compose(self, scale, corners, sizes):
         x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)

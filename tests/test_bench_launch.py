@@ -52,3 +52,7 @@ def test_two_rank_rehearsal_from_a_plain_invocation_on_one_gpu():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["frames"] == 16 and res["value"] > 0
     assert res["roofline"]["parts"]["warp"]["frac"] > 0
+    # the C++ host's sharded job on two child ranks of host/stitch_bench (exchanges staged through shared memory in a one-GPU rehearsal)
+    cpp = res["cpp_host"]
+    assert "error" not in cpp, cpp
+    assert "ShardedJob, 2 ranks" in cpp["host"] and cpp["frames"] == 16 and cpp["kept"] == 16 and cpp["pano_size"] == res["config"]["pano_size"]

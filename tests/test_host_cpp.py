@@ -436,3 +436,117 @@ def test_cpp_job_equals_python_job(tmp_path, ctx, stray):
     assert got["bands"] == ref["num_bands"]
     assert np.array_equal(got["mask"], ref["mask"].cpu().numpy())
     assert np.array_equal(got["pano"], ref["pano"].cpu().numpy())
+
+
+def _py_rank(rank, world, port, out_path, yaws, w, h):
+    """One rank of the Python sharded job on the one GPU (gloo rendezvous, device tensors staged through the host)."""
+    import sys
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth
+        import image_stitching_amd as isa
+        from image_stitching_amd.distributed import StitchJob
+        cams = _sweep_cams(yaws, w, h)
+        job = StitchJob(isa.Context(0), (w, h), cams, rank=rank, world_size=world, group=dist.group.WORLD)
+        frames = {i: synth.render_frame_gpu(cams[i]) for i in job.my_frames}
+        out = job.run(frames)
+        if rank == 0:
+            np.savez(out_path, pano=out["pano"].cpu().numpy(), mask=out["mask"].cpu().numpy(), conf=out["confidence"].cpu().numpy().reshape(-1),
+                     indices=np.array(out["indices"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _sweep_cams(yaws, w, h):
+    import synth
+    return [synth.make_camera(w, h, 60.0, y, 0.4 * ((i % 3) - 1), 0.3 * ((i % 2) - 0.5), 0.95 + 0.02 * i) for i, y in enumerate(yaws)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,stray", [(2, False), (3, False), (3, True)])
+def test_cpp_sharded_job_equals_python_sharded_job_and_oracle(tmp_path, ctx, oracle_mod, world, stray):
+    """host/stitch_bench --ranks N (mis::ShardedJob: frame blocks, feature all-gather, round-robin pairs, confidence sum, strip
+    exchange of pyramid rectangles, per-strip collapse, strip all-gather -- all in C++ over the C ABI, exchanges through
+    mis::Communicator's host-staged implementation, N child processes on the one GPU) against
+      the Python sharded job at the same N     byte for byte (same plan, same order of the f32 additions),
+      the oracle's single-process run           indices, confidences and mask exact, every pixel within 1 LSB."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    import synth
+    from oracle import job as ojob
+    _build()
+    w, h = 640, 360
+    yaws = [-30.0, -18.0, -6.0, 6.0, 18.0, 150.0 if stray else 30.0]
+    cams = _sweep_cams(yaws, w, h)
+    cams_path, prefix = str(tmp_path / "cams.txt"), str(tmp_path / "out")
+    write_cams_file(cams_path, cams)
+    r = subprocess.run([os.path.join(HOST, "stitch_bench"), cams_path, "--steps", "1", "--warmup", "1", "--ranks", str(world), "--comm", "host", "--one-gpu", "--dump", prefix],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["one_gpu_rehearsal"] is True and "ShardedJob, %d ranks" % world in line["host"]
+    got = _read_dump(prefix)
+    # the Python sharded job at the same world size
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    npz = str(tmp_path / "py.npz")
+    mp.start_processes(_py_rank, args=(world, port, npz, yaws, w, h), nprocs=world, join=True, start_method="spawn")
+    py = np.load(npz)
+    kept = [0, 1, 2, 3, 4] if stray else [0, 1, 2, 3, 4, 5]
+    assert got["indices"] == list(py["indices"]) == kept
+    assert line["kept"] == len(kept) and line["speculation_kept"] == (not stray)
+    assert np.array_equal(got["conf"], py["conf"])
+    assert np.array_equal(got["mask"], py["mask"]) and np.array_equal(got["pano"], py["pano"])
+    # the oracle's run of the whole sequence
+    frames = [synth.render_frame_gpu(c).cpu().numpy() for c in cams]
+    ref = ojob.stitch_job(frames, cams)
+    assert ref["indices"] == kept
+    assert np.array_equal(got["conf"].reshape(len(cams), len(cams)), ref["confidence"])
+    assert got["nfeat"] == [len(f["kps"]) for f in ref["features"]]
+    assert np.array_equal(got["mask"], ref["mask"])
+    d = np.abs(got["pano"].astype(np.int32) - ref["pano"].astype(np.int32))
+    assert d.max() <= 1, d.max()
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_flow_on_a_one_rank_rccl_communicator(tmp_path, ctx):
+    """The RCCL calls of mis::ShardedJob themselves (ncclCommInitRank, ncclAllGather, grouped ncclSend / ncclRecv on the job's
+    streams) on the box's one GPU: a one-rank communicator; the result is the unsharded job's, byte for byte."""
+    import json
+    import synth
+    from image_stitching_amd.distributed import StitchJob
+    _build()
+    w, h = 640, 360
+    yaws = [-26.0, -13.0, 0.0, 13.0, 26.0, 39.0]
+    cams = _sweep_cams(yaws, w, h)
+    cams_path, prefix = str(tmp_path / "cams.txt"), str(tmp_path / "out")
+    write_cams_file(cams_path, cams)
+    r = subprocess.run([os.path.join(HOST, "stitch_bench"), cams_path, "--steps", "2", "--warmup", "1", "--ranks", "1", "--comm", "rccl", "--dump", prefix],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "RCCL" in line["host"] and line["n_gpus"] == 1
+    got = _read_dump(prefix)
+    ref = StitchJob(ctx, (w, h), cams).run({i: synth.render_frame_gpu(c) for i, c in enumerate(cams)})
+    assert got["indices"] == ref["indices"] == [0, 1, 2, 3, 4, 5]
+    assert np.array_equal(got["conf"], np.asarray(ref["confidence"]).reshape(-1))
+    assert np.array_equal(got["mask"], ref["mask"].cpu().numpy()) and np.array_equal(got["pano"], ref["pano"].cpu().numpy())
+
+
+def test_stitch_bench_launcher_ends_the_other_ranks_when_one_fails(tmp_path):
+    """No GPU needed: with a camera file that does not parse every rank exits non-zero before touching a device; the parent
+    (which never touches the GPU itself) reports it and removes the session's shared-memory files."""
+    _build()
+    bad = tmp_path / "cams.txt"
+    bad.write_text("not a camera file\n")
+    r = subprocess.run([os.path.join(HOST, "stitch_bench"), str(bad), "--ranks", "2", "--comm", "host", "--one-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "a rank exited with code" in r.stderr
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("mis_bench_")]

@@ -8,7 +8,7 @@ import image_stitching_amd as isa
 from image_stitching_amd import distributed as misdist
 cams = synth.workload("config3")
 ctx = isa.Context(0)
-cfg = isa.StitchConfig() if os.environ.get("MIS_PIPELINE") == "reference_default" else isa.StitchConfig.hot_path()
+cfg = isa.StitchConfig() if os.environ.get("MIS_PIPELINE") in ("reference_default", "hot_path_plus_seams") else isa.StitchConfig.hot_path()
 job = misdist.StitchJob(ctx, (3840, 2160), cams, config=cfg)
 frames = {i: synth.render_frame_gpu(cams[i]) for i in job.my_frames}
 torch.cuda.synchronize()
