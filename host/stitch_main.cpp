@@ -17,7 +17,7 @@
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::cout << "usage: " << argv[0] << " <image directory> [--features orb|sift] [--ba no|reproj] [--ba_refine_mask xxxxx] [--wave_correct horiz|vert|no]\n"
-                     "       [--expos_comp no|gain_blocks] [--seam no|voronoi|dp_color] [--blend no|feather|multiband] [--conf_thresh f] [--match_conf f]\n"
+                     "       [--expos_comp no|gain_blocks] [--seam no|voronoi|dp_color] [--blend no|feather|multiband] [--conf_thresh f] [--match_conf f] [--compose_megapix f] [--seam_megapix f]\n"
                      "(the reference sets these as globals, image_stitching.cpp:49-85)\n";
         return -1;
     }
@@ -31,6 +31,8 @@ int main(int argc, char** argv) {
         else if (k == "--expos_comp") cfg.expos_comp_type = v;
         else if (k == "--seam") cfg.seam_find_type = v;
         else if (k == "--blend") cfg.blend_type = v == "no" ? MIS_BLEND_NO : (v == "feather" ? MIS_BLEND_FEATHER : MIS_BLEND_MULTI_BAND);
+        else if (k == "--compose_megapix") cfg.compose_megapix = std::strtod(v.c_str(), nullptr);
+        else if (k == "--seam_megapix") cfg.seam_megapix = std::strtod(v.c_str(), nullptr);
         else if (k == "--conf_thresh") cfg.conf_thresh = std::strtof(v.c_str(), nullptr);
         else if (k == "--match_conf") cfg.match_conf = std::strtof(v.c_str(), nullptr);
         else { std::cout << "unknown option " << k << "\n"; return -1; }

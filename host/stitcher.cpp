@@ -165,19 +165,29 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
     float warped_image_scale = focals.size() % 2 == 1 ? static_cast<float>(focals[focals.size() / 2])
                                                       : static_cast<float>(focals[focals.size() / 2 - 1] + focals[focals.size() / 2]) * 0.5f;
 
-    // ---- compositing (:1086-1228), compose_scale = 1 ----
+    // ---- compositing (:1086-1228) at compose scale (:1105-1146): the warper's scale and the intrinsics times compose_work_aspect,
+    //      frames (and their sizes, cvRound) resized only when |compose_scale - 1| > 0.1, as the reference tests it ----
     std::cout << "Compositing..." << std::endl;
     t = now();
+    double compose_scale = 1.0;
+    if (cfg_.compose_megapix > 0) compose_scale = std::min(1.0, std::sqrt(cfg_.compose_megapix * 1e6 / ((double)W * H)));
+    const double compose_work_aspect = compose_scale / 1.0;     // work_scale = 1: features at full resolution
+    const bool compose_resized = std::abs(compose_scale - 1) > 1e-1;
+    const int cW = compose_resized ? (int)std::nearbyint(W * compose_scale) : W, cH = compose_resized ? (int)std::nearbyint(H * compose_scale) : H;
+    const float compose_warp_scale = warped_image_scale * static_cast<float>(compose_work_aspect);
     std::vector<MisPoint> corners(kept);
     std::vector<MisSize> sizes(kept);
-    std::vector<std::array<float, 9>> Ks(kept), Rs(kept);
+    std::vector<std::array<float, 9>> Ks(kept), Rs(kept), cKs(kept);     // Ks: work-scale intrinsics (the seam step), cKs: the compositing loop's
     for (int k = 0; k < kept; k++) {
         const CameraParams& c = cameras[out.indices[k]];
-        Mat3<float> K = c.K().cast<float>(), R = c.R.cast<float>();
+        CameraParams cc = c;
+        cc.focal *= compose_work_aspect; cc.ppx *= compose_work_aspect; cc.ppy *= compose_work_aspect;
+        Mat3<float> K = c.K().cast<float>(), R = c.R.cast<float>(), cK = cc.K().cast<float>();
         std::copy(K.m.begin(), K.m.end(), Ks[k].begin());
         std::copy(R.m.begin(), R.m.end(), Rs[k].begin());
+        std::copy(cK.m.begin(), cK.m.end(), cKs[k].begin());
         MisRect roi;
-        mis_warp_roi(warped_image_scale, W, H, Ks[k].data(), Rs[k].data(), &roi);
+        mis_warp_roi(compose_warp_scale, cW, cH, cKs[k].data(), Rs[k].data(), &roi);
         corners[k] = {roi.x, roi.y};
         sizes[k] = {roi.width, roi.height};
     }
@@ -227,9 +237,12 @@ StitchResult Stitcher::stitch(const std::vector<HostImage>& frames, const std::v
     }
     for (int k = 0; k < kept; k++) {
         std::cout << "Compositing image #" << out.indices[k] + 1 << std::endl;
-        MisImage src = view(frames[out.indices[k]]), img_warped_s{}, mask_warped{};
+        MisImage full = view(frames[out.indices[k]]), src{}, img_warped_s{}, mask_warped{};
+        if (compose_resized) check(mis_resize_linear_exact(ctx_, &full, 0, 0, compose_scale, compose_scale, &src), "mis_resize_linear_exact (compose scale)");
+        else src = full;
         MisPoint tl;
-        check(mis_warp_spherical_fused(ctx_, &src, warped_image_scale, Ks[k].data(), Rs[k].data(), &img_warped_s, &mask_warped, &tl), "mis_warp_spherical_fused");
+        check(mis_warp_spherical_fused(ctx_, &src, compose_warp_scale, cKs[k].data(), Rs[k].data(), &img_warped_s, &mask_warped, &tl), "mis_warp_spherical_fused");
+        if (compose_resized) mis_image_free(ctx_, &src);
         if (compensator) check(mis_compensator_apply(compensator, k, &img_warped_s), "mis_compensator_apply");   // :1162
         if (seam_step) {
             check(mis_seam_mask_apply(ctx_, &masks_warped[k], &mask_warped), "mis_seam_mask_apply");                // :1169-1171

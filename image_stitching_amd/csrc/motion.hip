@@ -166,7 +166,11 @@ void svd3(const T* R, T* u, T* w, T* vt) {
 void rodrigues_to_mat(const double* r, double* R) {
     const double theta = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < DBL_EPSILON) { double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; memcpy(R, I, sizeof(I)); return; }
-    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, it = 1 / theta;
+    // cos and sin of one angle through ONE sincos call, as the oracle does: gcc merges separate calls into sincos, clang does not,
+    // and glibc's sincos differs from its cos / sin in the last place for some arguments (found on a 6-camera scene: one float ulp in R)
+    double c, s;
+    ::sincos(theta, &s, &c);
+    const double c1 = 1. - c, it = 1 / theta;
     const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
     const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
@@ -215,6 +219,12 @@ struct LevMarq {
         for (int i = 0; i < nparams; i++) A(i, i) *= 1. + lambda;
         std::vector<double> d;
         solve_svd(A, JtErr, d);
+        if (getenv("MIS_BA_TRACE")) {      // diagnostics: bit checksums of the step's system and its solution (the oracle prints the same)
+            unsigned long long ha = 0, hb = 0, hd = 0, t;
+            for (size_t q = 0; q < A.v.size(); q++) { memcpy(&t, &A.v[q], 8); ha += t * (q + 1); }
+            for (int q = 0; q < nparams; q++) { memcpy(&t, &JtErr[q], 8); hb += t * (unsigned long long)(q + 1); memcpy(&t, &d[q], 8); hd += t * (unsigned long long)(q + 1); }
+            fprintf(stderr, "[ba] step lambdaLg10 %d A %016llx JtErr %016llx delta %016llx\n", lambdaLg10, ha, hb, hd);
+        }
         for (int i = 0; i < nparams; i++) param[i] = prevParam[i] - d[i];
     }
     // normL2Sqr<double, double>: groups of four, as the unrolled loop of core's stat code adds them

@@ -14,6 +14,7 @@
  * leave as CV_32F and wave correction runs in CV_32F.  Transcendentals are libm's (cos, sin, acos, exp, log, hypot).
  * Never linked into the product.
  */
+#define _GNU_SOURCE      /* sincos */
 #include "mo_motion.h"
 #include <float.h>
 #include <math.h>
@@ -185,7 +186,11 @@ static double l2sqr_diff(const double* a, const double* b, int n) {
 static void rodrigues_vec_to_mat(const double* r, double* R) {
     const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < DBL_EPSILON) { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; memcpy(R, I, sizeof(I)); return; }
-    const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1 / theta;
+    /* cos and sin of one angle: ONE sincos call on both sides (gcc merges the two calls into sincos at -O2, clang keeps cos and sin,
+     * and glibc's sincos is not bit-identical to its cos / sin for every argument: a refined camera moved by one float ulp) */
+    double c, s;
+    sincos(theta, &s, &c);
+    const double c1 = 1. - c, it = 1 / theta;
     const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
     const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
@@ -403,6 +408,12 @@ int mo_bundle_adjust_reproj(int n, const MoFeatures* features, const MoMatchesIn
             memcpy(A, JtJ, sizeof(double) * (size_t)np * np);
             for (int a = 0; a < np; a++) A[(size_t)a * np + a] *= 1. + lambda;
             solve_svd(A, JtErr, delta, np);
+            if (getenv("MO_BA_TRACE")) {      /* diagnostics: bit checksums of the step's system and its solution */
+                unsigned long long ha = 0, hb = 0, hd = 0, t;
+                for (size_t q = 0; q < (size_t)np * np; q++) { memcpy(&t, &A[q], 8); ha += t * (q + 1); }
+                for (int q = 0; q < np; q++) { memcpy(&t, &JtErr[q], 8); hb += t * (unsigned long long)(q + 1); memcpy(&t, &delta[q], 8); hd += t * (unsigned long long)(q + 1); }
+                fprintf(stderr, "[mo-ba] step lambdaLg10 %d A %016llx JtErr %016llx delta %016llx\n", lambdaLg10, ha, hb, hd);
+            }
             for (int a = 0; a < np; a++) param[a] = prev[a] - delta[a];
         }
         memcpy(ba.cam, param, sizeof(double) * (size_t)np);

@@ -120,6 +120,15 @@ def test_stitch_main_seam_step_and_sift_match_python_pipeline(tmp_path, ctx, ora
     assert r.returncode == 0, r.stdout + r.stderr
     ref_default, _ = isa.Stitcher(ctx, size, isa.StitchConfig(compose_megapix=-1)).compose(dev, cams)      # gain_blocks + dp_color
     assert np.array_equal(np.clip(ref_default.cpu().numpy(), 0, 255).astype(np.uint8), _read_ppm(os.path.join(str(tmp_path), "result.ppm")))
+    # the compositing loop at compose scale (image_stitching.cpp:1105-1146: frames resized, intrinsics and warper scale times
+    # compose_work_aspect) with the reference's seam step, C++ driver = Python mirror
+    r = subprocess.run([exe, str(tmp_path), "--expos_comp", "gain_blocks", "--seam", "dp_color", "--compose_megapix", "0.05", "--seam_megapix", "0.02"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    small, _ = isa.Stitcher(ctx, size, isa.StitchConfig(compose_megapix=0.05, seam_megapix=0.02)).compose(dev, cams)
+    got_small = _read_ppm(os.path.join(str(tmp_path), "result.ppm"))
+    assert got_small.shape[1] < 0.75 * got.shape[1]
+    assert np.array_equal(np.clip(small.cpu().numpy(), 0, 255).astype(np.uint8), got_small)
     # options the library does not implement are refused, not ignored
     r = subprocess.run([exe, str(tmp_path), "--seam", "gc_color"], capture_output=True, text=True)
     assert r.returncode == 1 and "not implemented" in r.stdout
