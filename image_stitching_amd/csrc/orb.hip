@@ -1227,18 +1227,24 @@ int orb_alloc_workspace(MisOrb* o, int frames) {
     MisContext* ctx = o->ctx;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o_ = off; off += mis_align_up(bytes, 256); return o_; };
-    size_t o_pad = carve(o->pad_bytes), o_blur = carve(o->pad_bytes), o_score = carve(o->map_bytes), o_nms = carve(o->map_bytes);
+    // per frame: the padded gray pyramid and the small arrays; the blurred pyramid only when the descriptors need it (patterns that
+    // reach beyond describe_direct_kernel's patch).  The NMS map and, otherwise, the blurred pyramid exist ONCE behind the frames'
+    // blocks: only the debug views of the last single detect read them (16 complete workspaces were 2.2 GB at 4K)
+    const bool frame_blur = !o->direct_describe;
+    size_t o_pad = carve(o->pad_bytes), o_blur = frame_blur ? carve(o->pad_bytes) : 0;
     size_t o_hist = carve(sizeof(int) * (256 * HIST_COPIES * ORB_MAX_LEVELS + 4 * ORB_MAX_LEVELS)), o_flags = carve(256);
     size_t o_sxy = carve(sizeof(uint32_t) * FT_SLOTS * (size_t)o->surv_total), o_ssc = carve(FT_SLOTS * (size_t)o->surv_total), o_tc = carve(sizeof(int) * (size_t)o->surv_total);
     size_t o_cxy = carve(sizeof(uint32_t) * o->cand_total), o_cr = carve(sizeof(float) * o->cand_total);
     size_t o_fxy = carve(sizeof(uint32_t) * o->fin_total), o_fr = carve(sizeof(float) * o->fin_total);
     size_t o_tab = carve(sizeof(int) * (o->tab_total + 4)), o_umax = carve(sizeof(int) * 64), o_pat = carve(1024);
+    const size_t tail = mis_align_up(o->map_bytes, 256) + (frame_blur ? 0 : mis_align_up(o->pad_bytes, 256));
     void* mem = nullptr;
-    if (hipMalloc(&mem, off * (size_t)frames) != hipSuccess) return mis_set_error(ctx, MIS_E_NOMEM, "hipMalloc of %zu bytes failed", off * (size_t)frames);
+    if (hipMalloc(&mem, off * (size_t)frames + tail) != hipSuccess) return mis_set_error(ctx, MIS_E_NOMEM, "hipMalloc of %zu bytes failed", off * (size_t)frames + tail);
     o->mem = mem; o->ws_stride = off; o->ws_frames = frames;
     uint8_t* m = (uint8_t*)o->mem;
+    uint8_t* shared = m + off * (size_t)frames;
     Work& W = o->w;
-    W.pad = m + o_pad; W.blur = m + o_blur; W.score = m + o_score; W.nms = m + o_nms;
+    W.pad = m + o_pad; W.nms = shared; W.blur = frame_blur ? m + o_blur : shared + mis_align_up(o->map_bytes, 256); W.score = nullptr;
     W.hist = (int*)(m + o_hist); W.thr = W.hist + 256 * HIST_COPIES * ORB_MAX_LEVELS; W.cnt1 = W.thr + ORB_MAX_LEVELS; W.cnt2 = W.cnt1 + ORB_MAX_LEVELS;
     W.surv_xy = (uint32_t*)(m + o_sxy); W.surv_sc = m + o_ssc; W.tile_cnt = (int*)(m + o_tc);
     W.flags = (int*)(m + o_flags);
@@ -1269,8 +1275,15 @@ int orb_ensure_frames(MisOrb* o, int frames) {
     const Work oldw = o->w;
     const size_t olds = o->ws_stride;
     const int oldf = o->ws_frames;
-    int rc = orb_alloc_workspace(o, frames);
-    if (rc != MIS_OK) { o->mem = old; o->w = oldw; o->ws_stride = olds; o->ws_frames = oldf; return rc; }
+    // a batch wants `frames` workspaces; when the device cannot give that many, fewer do (the batch loops over groups of ws_frames)
+    int rc = MIS_E_NOMEM;
+    for (int f = frames; f > oldf; f = std::max(oldf, f / 2)) {
+        if ((rc = orb_alloc_workspace(o, f)) == MIS_OK) break;
+    }
+    if (rc != MIS_OK) {       // keep what there was: the batch runs in groups of the old size
+        o->mem = old; o->w = oldw; o->ws_stride = olds; o->ws_frames = oldf;
+        return oldf >= 1 ? MIS_OK : rc;
+    }
     if (old) MIS_HIP(ctx, hipFree(old));
     return orb_init_workspace(o);
 }
@@ -1294,9 +1307,6 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
     o->ctx = ctx; o->p = *p; o->max_w = max_w; o->max_h = max_h;
     plan_levels(o, max_w, max_h);
     o->out_cap = o->fin_total;
-    int rc0 = orb_alloc_workspace(o, 1);
-    if (rc0 != MIS_OK) { delete o; return rc0; }
-    Work& W = o->w;
     // umax (orb.cpp) and the random BRIEF pattern: patchSize != 31 -> RNG(0x34985739), 512 points
     int umax[64] = {0};
     {
@@ -1325,7 +1335,8 @@ extern "C" int mis_orb_create(MisContext* ctx, const MisOrbParams* p, int max_w,
         // FAST keypoints keep 3 pixels from the edge, the level carries a border ring of ORB_BORDER: the patch stays inside the padded level
         o->direct_describe = reach <= DD_R && 3 + ORB_BORDER >= DD_P && getenv("MIS_ORB_FULL_BLUR") == nullptr;
     }
-    (void)W;
+    int rc0 = orb_alloc_workspace(o, 1);      // (after direct_describe is known: it decides whether a frame's block carries a blurred pyramid)
+    if (rc0 != MIS_OK) { delete o; return rc0; }
     memcpy(o->umax_host, umax, sizeof(umax));
     memcpy(o->pattern_host, pat, sizeof(pat));
     o->cur_w = max_w; o->cur_h = max_h;

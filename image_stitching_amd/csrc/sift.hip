@@ -178,6 +178,103 @@ __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float* __rest
         }
 }
 
+// Row and column pass of one GaussianBlur in ONE kernel (round 4): the two kernels above move 24 bytes per pixel and layer (source
+// read, row results written and read back, the previous layer read again for the DoG, blurred layer and DoG written); fused, a
+// layer is one read of the source (which IS the previous layer: the DoG's subtrahend comes with it) and the two writes.  A
+// workgroup owns a strip of FB_TW columns and walks `seg` output rows downwards, FB_CH input rows at a time: the rows are
+// staged in LDS, row-filtered (a thread: 8 consecutive outputs of one row from 8 + N - 1 LDS reads, indices padded as in the
+// row kernel) into a ring of the last N + FB_CH - 1 filtered rows, and the column pass (thread = column, 8 output rows from
+// N + 7 ring reads) emits the newest 8 complete rows.  Every sum is `acc = 0; acc += tap[k] * v` over ascending k, as in the
+// separate passes (and the CPU path): the results are the same bits.  Vertically a strip costs N - 1 extra input rows per
+// segment; the next chunk's global loads are in flight while the current one is filtered.
+constexpr int FB_TW = 256, FB_CH = 8;
+template <int N>
+__global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int w, int h, int seg, Taps t) {
+    constexpr int R = N / 2, RB = N + FB_CH - 1, SPAN = FB_TW + N - 1;
+    constexpr int RPITCH = FB_TW + FB_TW / 8, SPITCH = SPAN + SPAN / 8 + 1;
+    constexpr int NE = (FB_CH * SPAN + 255) / 256;
+    __shared__ float ring[RB * RPITCH];
+    __shared__ float stage[FB_CH * SPITCH];
+    const int tid = threadIdx.x, x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * seg;
+    const int rows_out = min(seg, h - y0);
+    const int nchunks = (rows_out + N - 1 + FB_CH - 1) / FB_CH;
+    const bool xin = x0 - R >= 0 && x0 + FB_TW - 1 + R < w;      // no horizontal reflection in this strip
+    float pre[NE];
+    auto load_chunk = [&](int c) {
+        const int yb = y0 - R + FB_CH * c;
+        const bool yin = yb >= 0 && yb + FB_CH - 1 < h;
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = tid + 256 * i;
+            const int j = e / SPAN, k = e - j * SPAN;
+            float v = 0.f;
+            if (e < FB_CH * SPAN) {
+                const int yi = yin ? yb + j : mis_reflect101(yb + j, h), xi = xin ? x0 - R + k : mis_reflect101(x0 - R + k, w);
+                v = src[(size_t)yi * w + xi];
+            }
+            pre[i] = v;
+        }
+    };
+    load_chunk(0);
+    const int rj = tid >> 5, rx = tid & 31;       // row pass: row of the chunk, block of 8 columns
+    for (int c = 0; c < nchunks; c++) {
+        __syncthreads();       // the previous chunk's passes are done with the staged rows and the ring's oldest rows
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = tid + 256 * i;
+            const int j = e / SPAN, k = e - j * SPAN;
+            if (e < FB_CH * SPAN) stage[j * SPITCH + k + (k >> 3)] = pre[i];
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        {   // row pass: filtered row q = FB_CH * c + rj (relative to y0 - R) into its ring slot
+            float acc[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) acc[jj] = 0.f;
+            const float* my = stage + rj * SPITCH + 9 * rx;
+#pragma unroll
+            for (int k = 0; k < N + 7; k++) {
+                const float v = my[k + (k >> 3)];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (k - jj >= 0 && k - jj < N) acc[jj] += t.k[k - jj] * v;
+            }
+            float* o = ring + ((FB_CH * c + rj) % RB) * RPITCH + 9 * rx;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) o[jj] = acc[jj];
+        }
+        __syncthreads();
+        // column pass: output rows m0 .. m0 + 7 (relative to y0), from the filtered rows m0 .. m0 + N + 6
+        const int m0 = FB_CH * c + FB_CH - N;
+        if (m0 + 7 >= 0 && m0 < rows_out) {
+            float acc[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) acc[jj] = 0.f;
+            int slot = ((m0 % RB) + RB) % RB;
+            const int col = tid + (tid >> 3);
+#pragma unroll
+            for (int k = 0; k < N + 7; k++) {
+                const float v = m0 + k >= 0 ? ring[slot * RPITCH + col] : 0.f;      // rows above the segment's first input row only meet outputs that are not emitted
+                slot = slot + 1 == RB ? 0 : slot + 1;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (k - jj >= 0 && k - jj < N) acc[jj] += t.k[k - jj] * v;
+            }
+            const int x = x0 + tid;
+            if (x < w) {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const int m = m0 + jj;
+                    if (m < 0 || m >= rows_out) continue;
+                    const size_t o = (size_t)(y0 + m) * w + x;
+                    dst[o] = acc[jj];
+                    if (dog) dog[o] = acc[jj] - src[o];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sift_sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) d[i] = b[i] - a[i];
@@ -710,8 +807,16 @@ static void blur(MisSift* s, const float* src, float* dst, int w, int h, double 
     const Taps t = gaussian_taps(sigma);
     hipStream_t st = s->ctx->stream;
     const dim3 grows(((w + BLK - 1) / BLK + 255) / 256, h), gcols((w + 255) / 256, (h + BLK - 1) / BLK), block(256);
+    // the tap counts of SIFT::create()'s sigmas run fused (one read, two writes per layer); `prev` is always the source there.
+    // Segments: long enough that the N - 1 extra input rows stay a small share, short enough that a layer is >= ~1500 workgroups
+    const int nsx = (w + FB_TW - 1) / FB_TW;
+    int seg = (h * nsx + 1499) / 1500;
+    seg = std::min(256, std::max(64, (seg + 7) & ~7));
+    const dim3 gfused(nsx, (h + seg - 1) / seg);
+    const bool fused_ok = (prev == nullptr || prev == src) && (dog != nullptr) == (prev != nullptr);
 #define MIS_BLUR_CASE(NN)                                                                                                                        \
     case NN:                                                                                                                                     \
+        if (fused_ok) { hipLaunchKernelGGL(sift_blur_fused_kernel<NN>, gfused, block, 0, st, src, dst, dog, w, h, seg, t); break; }              \
         hipLaunchKernelGGL(sift_blur_rows_kernel<NN>, grows, block, 0, st, src, s->tmp, w, h, t);                                                \
         hipLaunchKernelGGL(sift_blur_cols_kernel<NN>, gcols, block, 0, st, (const float*)s->tmp, dst, w, h, t, prev, dog);                       \
         break;

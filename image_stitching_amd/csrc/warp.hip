@@ -698,6 +698,7 @@ struct WarpBatch {
     const float* tab[WB_MAX];
     int ntiles[WB_MAX], nwg[WB_MAX];
 };
+#if !WV_V3      // round 2's batched tile kernel: only in the A / B build without the strip kernels
 __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu(WV_WAVES_MIN, 8))) void warp_fused_batch_kernel(WarpBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[TILE_WAVES][STAGE_BYTES];
     const int f = blockIdx.y;
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) __attribute__((amdgpu_waves_per_eu
     const WarpArgs a = b.a[f];
     warp_fused_body(a, b.tab[f], b.ntiles[f], (int)blockIdx.x, b.nwg[f], stage_all);
 }
+#endif
 __global__ __launch_bounds__(256) void warp_trig_batch_kernel(WarpBatch b) {
     const int f = blockIdx.y;
     const WarpArgs& a = b.a[f];
@@ -1394,37 +1396,6 @@ static void v3_plan_strips(const MisContext* ctx, const WarpArgs* args, int ng, 
     }
 }
 
-#ifndef WV3_SEQ_WAVES_MIN
-#define WV3_SEQ_WAVES_MIN 6
-#endif
-#ifndef WV3_SEQ_NT
-#define WV3_SEQ_NT 1           // tiles per wave of the one-frame launch
-#endif
-#ifndef WV3_SINGLE
-#define WV3_SINGLE 0           // one-frame launches: 0 = round 2's tile kernel (fastest there: 24.6 us vs 27.5 / 28.1, gpurun_out/r3_v3_var9.txt), 1 = strips without overlap, 2 = pipelined strips
-#endif
-#ifndef WV3_SINGLE_NT_MAX
-#define WV3_SINGLE_NT_MAX 1
-#endif
-#ifndef WV3_SEQ_RING
-#define WV3_SEQ_RING 6144      // one box per wave: boxes beyond it take the per-pixel loop
-#endif
-static_assert(WV3_SEQ_RING >= V3_OUT_BYTES, "a tile's output group must fit its region");
-__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_WAVES_MIN, 8))) void warp_strip_kernel(V3Frame f, int nt) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][V3_RING];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx0, ty_first;
-    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
-    warp_strip_body<true, V3_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
-}
-// one frame per launch (mis_warp_spherical_fused): short strips, one tile at a time per wave
-__global__ __launch_bounds__(64 * V3_WAVES) __attribute__((amdgpu_waves_per_eu(WV3_SEQ_WAVES_MIN, 8))) void warp_strip_seq_kernel(V3Frame f, int nt) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[V3_WAVES][WV3_SEQ_RING];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx0, ty_first;
-    if (!v3_strip_of((int)blockIdx.x, wave, f.dw, f.dh, nt, &tx0, &ty_first)) return;
-    warp_strip_body<false, WV3_SEQ_RING>(f, tx0, ty_first, nt, (lds_p)ring_all[wave]);
-}
 // The compose loop's grid: the strips of all frames of a batch, frame after frame, in ONE one-dimensional grid.  The dispatcher
 // hands out workgroups in index order as slots free up, so the strips of the LAST frames are the launch's tail: the host plans
 // them shorter (v3_plan_strips) -- with 8-tile strips everywhere a 16-frame launch is 7.25 generations of ~37 us waves and a
@@ -1589,22 +1560,10 @@ static int warp_fused_impl(MisContext* ctx, const MisImage* src, float scale, co
         MIS_HIP(ctx, hipEventCreate(&e1));
         MIS_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
-#if WV_V3 && WV3_SINGLE == 1        // one tile at a time per wave
-    (void)nwg; (void)ntiles;
-    const int nt = WV3_SEQ_NT;
-    const int nwg3 = v3_grid_of(a, nt);
-    for (int rep = 0; rep < repeats; rep++)
-        hipLaunchKernelGGL(warp_strip_seq_kernel, dim3(nwg3), dim3(64 * V3_WAVES), 0, ctx->stream, v3_frame_of(a, tab), nt);
-#elif WV_V3 && WV3_SINGLE == 2      // the pipelined strips, as short as the frame's tile count asks
-    (void)nwg; (void)ntiles;
-    const int nt = std::min(v3_strip_tiles(ctx, a, 1), WV3_SINGLE_NT_MAX);
-    const int nwg3 = v3_grid_of(a, nt);
-    for (int rep = 0; rep < repeats; rep++)
-        hipLaunchKernelGGL(warp_strip_kernel, dim3(nwg3), dim3(64 * V3_WAVES), 0, ctx->stream, v3_frame_of(a, tab), nt);
-#else
+    // one frame per launch: round 2's tile kernel (measured faster there than the strip forms: 23.2 us against 29.3 for one-tile
+    // strips and more for longer ones -- a frame alone is 3.5 tiles per wave slot, gpurun_out/r4_plan_ab3.txt)
     for (int rep = 0; rep < repeats; rep++)
         hipLaunchKernelGGL(warp_fused_kernel, dim3(nwg), dim3(64 * TILE_WAVES), 0, ctx->stream, a, (const float*)tab, ntiles);
-#endif
     if (avg_us) {
         float ms = 0.f;
         MIS_HIP(ctx, hipEventRecord(e1, ctx->stream));
