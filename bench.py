@@ -216,6 +216,9 @@ def main():
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
         if not args.no_cpu_baseline and features == "orb" and world == 1 and args.pipeline == "hot_path":     # the CPU baseline is an N = 1 item
             cpu = cpu_baseline(cams, workload, frames)
+        # (under rocprofv3 the preloaded profiler would trace child processes into the same output directory: the legs that start
+        # children or a second job are skipped there, as with --no-cpp-host)
+        profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         res = {
             "metric": "4K frames stitched/sec", "value": round(value, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -230,11 +233,11 @@ def main():
                        "warp_roi": "computed inside every timed step (mis_warp_roi_batch: one kernel for all frames, nothing cached)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if args.pipeline == "hot_path" and features == "orb" and not args.no_cpp_host:
+        if args.pipeline == "hot_path" and features == "orb" and not args.no_cpp_host and not profiled:
             # the same job driven from C++ (host/stitch_bench), after this process's timed region: mis::StitchJob on one GPU; for N > 1
             # mis::ShardedJob on N child ranks with RCCL called directly (the ranks of this script idle at the barrier below meanwhile)
             res["cpp_host"] = cpp_host_leg(cams, args, world, rehearsal)
-        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not os.environ.get("MIS_BENCH_NO_OVERLAP"):
+        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not os.environ.get("MIS_BENCH_NO_OVERLAP") and not profiled:
             try:
                 res["two_jobs_in_flight"] = two_jobs_leg(isa, misdist, ctx, job, cams, (W, H), cfg, frames, max(4, args.steps // 2))
             except Exception as e:       # informational: never costs the line

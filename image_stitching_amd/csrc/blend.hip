@@ -113,17 +113,36 @@ constexpr int PD_W = 32, PD_H = 16, PD_SW = 2 * PD_W + 3, PD_SH = 2 * PD_H + 3;
 // footprint lies inside the frame (no reflection at all: the bulk of a 4K frame) stage their rows with aligned dword
 // loads (a row is 402 contiguous bytes of 16SC3) instead of three 2-byte loads per pixel, and their weights with dword
 // loads of the mask.
-constexpr int PDV_ROW_DW = (PD_SW * 6 + 2 + 3) / 4 + 1;   // dwords that cover a row of 67 pixels from an address rounded down to 4
+constexpr int PDV_ROW_DW = 104;                           // dwords of an LDS row: 67 pixels (201 shorts) from an address rounded down to 16 bytes (<= 7 shorts in) = 26 pieces of 16 bytes
+static_assert(PDV_ROW_DW * 2 >= 7 + 3 * PD_SW && PDV_ROW_DW % 4 == 0, "an LDS row holds the footprint from any 16-byte phase");
+constexpr int PDV_MROW_B = 96;                            // bytes of a staged mask row: 67 from an address rounded down to 16 (<= 15 in) = 6 pieces
 constexpr int PDV_MROW_DW = (PD_SW + 3 + 3) / 4 + 1;      // same for the 67 mask bytes
 // FROM_VIEW = false: the same pair of reductions for a level >= 1 (sources: the frame's Gaussian level `src` and weight level
 // `wsrc`, sw x sh, tightly packed), one launch instead of two per level.
+// one global -> LDS copy instruction (LDS address = M0 + lane * 16, global address = base + voff): inline assembly, as in warp.hip
+// (s_nop 0: the wait state between the scalar write of M0 and the instruction that reads it)
+__device__ __forceinline__ void pd_dma16(const void* base, unsigned voff, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_off) : "memory", "m0");
+}
+
 template <bool FROM_VIEW>
 __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int16_t* __restrict__ src, const float* __restrict__ wsrc, int psw, int psh,
                                                    int16_t* __restrict__ dst, float* __restrict__ wdst, int dw, int dh, int bx, int by) {
-    __shared__ __attribute__((aligned(4))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
-    __shared__ float wt[PD_SH * PD_SW];
+    // LDS.  From a frame view (level 0 -> 1) the weights of the footprint are staged as the mask's BYTES (`mraw`, 96-byte rows) and
+    // become floats (`wt`) only behind the image's vertical pass, in the memory of the spent `tile`: 24.6 KB per workgroup, six
+    // workgroups per compute unit (with a float array of its own: 30.9 KB, five).  Levels >= 1 carry float weights from the start.
+    constexpr int WT_BYTES = (int)sizeof(float) * PD_SH * PD_SW;
+    static_assert(WT_BYTES <= (int)sizeof(int16_t) * PD_SH * PDV_ROW_DW * 2, "the weights fit the spent image tile");
+    __shared__ __attribute__((aligned(16))) int16_t tile[PD_SH * PDV_ROW_DW * 2];   // row pitch PDV_ROW_DW dwords; pixels start `toff` shorts in
+    __shared__ __attribute__((aligned(16))) uint8_t wmem[FROM_VIEW ? PD_SH * PDV_MROW_B : WT_BYTES];
     __shared__ int vbuf[PD_H * PDV_ROW_DW];   // vertical sums: 16 rows of packed u16 pairs (fast path) or 8 rows of one int per short
+    __shared__ int sflag;     // DMA staging: bit 0 a mask byte of the footprint is not 255, bit 1 one is not 0, bit 2 a short is outside 0..255
+    uint8_t* const mraw = wmem;                                                               // FROM_VIEW: mask bytes, row pitch PDV_MROW_B
+    float* const wt = FROM_VIEW ? reinterpret_cast<float*>(tile) : reinterpret_cast<float*>(wmem);   // FROM_VIEW: valid behind convert_weights() only
+    int moff = 0;             // FROM_VIEW: column of the footprint's first pixel inside a staged mask row
+    bool rowchk = false;      // FROM_VIEW: rows outside the image were staged from some valid row and carry no weight (DMA staging)
     unsigned wide_bits = 0;   // bits of the staged shorts outside 0..255 (0 for a converted 8-bit image: the packed 16-bit path is exact)
+    int wconst = 0;           // 1: every weight of the footprint is 1 (mask 255 everywhere), 2: every weight is 0 -- the outputs are constants
     const int x0 = bx * PD_W, y0 = by * PD_H, t = threadIdx.x;
     const int sw = FROM_VIEW ? v.tw : psw, sh = FROM_VIEW ? v.th : psh;
     const int tx0 = 2 * x0 - 2, ty0 = 2 * y0 - 2;                    // tile coordinates of the footprint's corner
@@ -131,13 +150,93 @@ __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int
     const bool interior = FROM_VIEW && tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW <= sw && ty0 + PD_SH <= sh && ix0 >= 0 && iy0 >= 0 && ix0 + PD_SW + 12 <= v.w && iy0 + PD_SH <= v.h &&   /* + 12: the dword loads may run past the last needed byte */
                           (v.istride & 1) == 0 && ((uintptr_t)v.img & 3) == 0 && (v.mstride & 3) == 0 && ((uintptr_t)v.mask & 3) == 0;
     int toff;   // shorts between the start of an LDS row and its first pixel
-    if (interior) {
+    // Tiles of a frame whose rows start on 16 bytes (the job's warped frames: 256-byte pitches) go global -> LDS by LDS-DMA: 26 + 6
+    // pieces of 16 bytes per row of image and mask, no staging registers and no index arithmetic per element (the register paths
+    // below spent a third of the kernel's vector instructions there).  Eligible: a footprint inside the padded tile whose 67
+    // COLUMNS lie inside the image, or entirely in the left / right margin within one reflection -- there the view is the
+    // mirrored image (BORDER_REFLECT): the un-mirrored block [cs, cs + 67) is staged and the tile's outputs are the block's in
+    // reverse order (the 5-tap kernel is symmetric and the block's windows start at even columns: output x of the tile = output
+    // 31 - x of the block), all weights are 0.  ROWS may be anything: a row's address is the reflected row's.
+    bool dma = false, mir = false;
+    int cs = ix0;       // image column of the staged block's first pixel
+    if (FROM_VIEW && tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW <= sw && ty0 + PD_SH <= sh) {
+        bool cols = true;
+        if (ix0 >= 0 && ix0 + PD_SW <= v.w) cs = ix0;
+        else if (ix0 + PD_SW <= 0 && -ix0 <= v.w) { cs = -ix0 - PD_SW; mir = true; }
+        else if (ix0 >= v.w && 2 * v.w - PD_SW - ix0 >= 0) { cs = 2 * v.w - PD_SW - ix0; mir = true; }
+        else cols = false;
+        const size_t ia = ((size_t)3 * cs * 2) & ~(size_t)15, ma = (size_t)cs & ~(size_t)15;
+        dma = cols && (((uintptr_t)v.img | (v.istride * 2)) & 15) == 0 && ia + PDV_ROW_DW * 4 <= v.istride * 2 && (size_t)v.h * v.istride * 2 < (1ull << 32) &&
+              (mir || ((((uintptr_t)v.mask | v.mstride) & 15) == 0 && ma + PDV_MROW_B <= v.mstride && (size_t)v.h * v.mstride < (1ull << 32)));
+        if (!dma) mir = false;
+    }
+    if (dma) {
+        const size_t ib = (size_t)3 * cs * 2, ia = ib & ~(size_t)15;
+        toff = (int)((ib - ia) >> 1);
+        moff = cs & 15;
+        rowchk = true;
+        const uint8_t* ibase = reinterpret_cast<const uint8_t*>(v.img) + ia;
+        const uint8_t* mbase = v.mask + ((size_t)cs & ~(size_t)15);
+        const uint32_t tile_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)tile;
+        const uint32_t mraw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)mraw;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        constexpr int IPR = PDV_ROW_DW / 4, IP = PD_SH * IPR, MPR = PDV_MROW_B / 16, MP = PD_SH * MPR;      // pieces per row / in all
+#pragma unroll
+        for (int k = 0; k < (IP + 255) / 256; k++) {
+            const int p0 = (k * 4 + wave) * 64, p = p0 + lane;       // (wave-uniform p0: the instruction's LDS base)
+            if (p0 < IP) {
+                const int r = min(p / IPR, PD_SH - 1), c = p - r * IPR;
+                const int iy = reflect_near(iy0 + r, v.h);
+                if (p < IP) pd_dma16(ibase, (unsigned)iy * (unsigned)(v.istride * 2) + (unsigned)c * 16u, tile_lds + (uint32_t)p0 * 16u);
+            }
+        }
+        if (!mir) {
+            const int p0 = wave * 64, p = p0 + lane;
+            if (p0 < MP) {
+                const int r = min(p / MPR, PD_SH - 1), c = p - r * MPR;
+                const int iy = min(max(iy0 + r, 0), v.h - 1);         // (rows outside the image carry no weight: any valid row will do)
+                if (p < MP) pd_dma16(mbase, (unsigned)iy * (unsigned)v.mstride + (unsigned)c * 16u, mraw_lds + (uint32_t)p0 * 16u);
+            }
+        }
+        if (t == 0) sflag = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // the footprint's mask bytes: all 255 (the inside of a warped frame: every weight 1) or all 0?  Dwords of the staged rows, bytes
+        // outside columns moff .. moff + 66 ignored.  And the bits of the footprint's shorts outside 0..255 (the register paths collect
+        // them while staging).  One LDS word gathers the three answers (most workgroups never touch it: an 8-bit frame's inside).
+        unsigned all1 = mir ? 0u : 0xffffffffu, any = 0u, wide = 0u;      // (mirrored columns: outside the image, every weight 0)
+        if (!mir) {
+            for (int i = t; i < PD_SH * (PDV_MROW_B / 4); i += 256) {
+                const int r = i / (PDV_MROW_B / 4), c = i - r * (PDV_MROW_B / 4);
+                const bool row_in = (unsigned)(iy0 + r) < (unsigned)v.h;         // a row outside the image: weight 0 whatever was staged
+                const unsigned d = row_in ? reinterpret_cast<const unsigned*>(mraw)[i] : 0u;
+                unsigned in = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) in |= ((unsigned)(4 * c + q - moff) < (unsigned)PD_SW) ? (0xffu << (8 * q)) : 0u;
+                all1 &= d | ~in;
+                any |= d & in;
+            }
+        }
+        const int td0 = toff >> 1;
+        constexpr int FDW = (3 * PD_SW + 1) / 2 + 1;      // dwords that hold a row's 201 shorts from either half-dword phase
+        for (int i = t; i < PD_SH * FDW; i += 256) {
+            const int r = i / FDW, c = i - r * FDW;
+            wide |= reinterpret_cast<const unsigned*>(tile)[r * PDV_ROW_DW + td0 + c];
+        }
+        // (one LDS atomic per wave at most: 256 lanes on one word serialise)
+        const int bits = (__any(all1 != 0xffffffffu) ? 1 : 0) | (__any(any != 0u) ? 2 : 0) | (__any((wide & 0xFF00FF00u) != 0u) ? 4 : 0);
+        if (bits && lane == 0) atomicOr(&sflag, bits);
+        __syncthreads();
+        const int fl = sflag;
+        wconst = !(fl & 1) ? 1 : (!(fl & 2) ? 2 : 0);
+        wide_bits = (fl & 4) ? 0xFF00u : 0u;
+    } else if (interior) {
         const size_t e0 = 3 * (size_t)ix0;                           // first short of a row, relative to the row start
         toff = (int)(e0 & 1);
         const int16_t* base = v.img + (size_t)iy0 * v.istride + (e0 - toff);
         // all loads of a thread are issued before the first LDS store (a load -> store loop serialises the round trips)
         constexpr int NI = (PD_SH * PDV_ROW_DW + 255) / 256, NM = (PD_SH * PDV_MROW_DW + 255) / 256;
-        const int moff = ix0 & 3;
+        moff = ix0 & 3;
         const uint8_t* mbase = v.mask + (size_t)iy0 * v.mstride + (ix0 - moff);
         unsigned ri[NI], rm[NM];
 #pragma unroll
@@ -158,13 +257,7 @@ __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int
 #pragma unroll
         for (int k = 0; k < NM; k++) {
             const int i = t + 256 * k, r = i / PDV_MROW_DW, c = i - r * PDV_MROW_DW;
-            if (i < PD_SH * PDV_MROW_DW) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int x = 4 * c + q - moff;
-                    if (x >= 0 && x < PD_SW) wt[r * PD_SW + x] = (float)((rm[k] >> (8 * q)) & 255u) * (float)(1. / 255.);
-                }
-            }
+            if (i < PD_SH * PDV_MROW_DW) reinterpret_cast<unsigned*>(mraw)[r * (PDV_MROW_B / 4) + c] = rm[k];
         }
     } else if (!FROM_VIEW && tx0 >= 0 && ty0 >= 0 && tx0 + PD_SW + 2 <= sw && ty0 + PD_SH <= sh && (sw & 1) == 0 && ((uintptr_t)src & 3) == 0) {
         // a level >= 1, footprint inside it: rows are 3 sw shorts apart (sw even: every row starts on the same dword phase)
@@ -230,18 +323,20 @@ __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int
                 int16_t* o = tile + (size_t)r * (PDV_ROW_DW * 2) + 3 * c;
                 o[0] = gp[k][0]; o[1] = gp[k][1]; o[2] = gp[k][2];
                 wide_bits |= (unsigned)(unsigned short)gp[k][0] | (unsigned)(unsigned short)gp[k][1] | (unsigned)(unsigned short)gp[k][2];
-                wt[i] = FROM_VIEW ? (gw[k] < 0.f ? 0.f : gw[k] * (float)(1. / 255.)) : gw[k];
+                if (FROM_VIEW) mraw[r * PDV_MROW_B + c] = gw[k] < 0.f ? (uint8_t)0 : (uint8_t)gw[k];     // (moff = 0; outside the image: weight 0)
+                else wt[i] = gw[k];
             }
         }
     }
     // every short of the footprint in 0..255 (block-uniform): vertical sums <= 4080 and the full 5 x 5 sums <= 65280 fit 16 bits,
     // so the image goes through packed 16-bit arithmetic on the raw dwords; any other data takes 32-bit sums
-    const bool small = __syncthreads_or((int)(wide_bits & 0xFF00FF00u)) == 0;
+    const bool small = dma ? wide_bits == 0 : __syncthreads_or((int)(wide_bits & 0xFF00FF00u)) == 0;      // (dma: block-uniform already)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const unsigned* tw32 = reinterpret_cast<const unsigned*>(tile);
     // a thread owns two adjacent outputs (x even) of one row: 7 source pixels = 21 shorts of the row of vertical sums
     const int j = t >> 4, x = 2 * (t & 15);
-    const int gx = x0 + x, gy = y0 + j;
+    int gx = x0 + x;
+    const int gy = y0 + j;
     int o[2][3];
     if (small) {
         // pass 1 (image, vertical first -- integer sums, the pass order is free): V[j][.] = 6 r[2j+2] + 4 (r[2j+1] + r[2j+3]) + r[2j] + r[2j+4]
@@ -255,9 +350,9 @@ __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int
         }
         __syncthreads();
         // pass 2 (horizontal) on the packed sums
-        const unsigned* q = reinterpret_cast<const unsigned*>(vbuf) + (size_t)j * PDV_ROW_DW + 3 * x;   // shorts 6 x .. (+ toff)
+        const unsigned* q = reinterpret_cast<const unsigned*>(vbuf) + (size_t)j * PDV_ROW_DW + 3 * x + (toff >> 1);   // shorts toff + 6 x ..
         unsigned D[11];
-        if (toff) {
+        if (toff & 1) {
             unsigned e[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) e[k] = q[k];
@@ -304,17 +399,40 @@ __device__ __forceinline__ void pyr_down_view_tile(const FrameView& v, const int
             }
         }
     }
+    if (FROM_VIEW && !wconst) {
+        // the staged mask bytes -> weights (mask / 255), into the memory of the image tile: every thread is behind a barrier that
+        // follows its last read of `tile` (the vertical passes above)
+        for (int i = t; i < PD_SH * PD_SW; i += 256) {
+            const int r = i / PD_SW, c = i - r * PD_SW;
+            const bool row_in = !rowchk || (unsigned)(iy0 + r) < (unsigned)v.h;
+            wt[i] = row_in ? (float)mraw[r * PDV_MROW_B + moff + c] * (float)(1. / 255.) : 0.f;
+        }
+        __syncthreads();
+    }
     // weights: horizontal sums of the five source rows of the output row, then the vertical sum (f32: the reference's order)
     float ow[2];
+    if (wconst) {
+        // a footprint of equal weights (all 1: the inside of a warped frame; all 0: outside its mask): the same sums on the one value
+        const float wv = wconst == 1 ? (float)255u * (float)(1. / 255.) : 0.f;
+        const float hr = ((wv * 6.f + (wv + wv) * 4.f) + wv) + wv;
+        ow[0] = ow[1] = (((hr * 6.f + (hr + hr) * 4.f) + hr) + hr) * (1.f / 256.f);
+    } else {
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-        float hr[5];
+        for (int p = 0; p < 2; p++) {
+            float hr[5];
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const float* sw_ = wt + (2 * j + r) * PD_SW + 2 * (x + p);
-            hr[r] = ((sw_[2] * 6.f + (sw_[1] + sw_[3]) * 4.f) + sw_[0]) + sw_[4];
+            for (int r = 0; r < 5; r++) {
+                const float* sw_ = wt + (2 * j + r) * PD_SW + 2 * (x + p);
+                hr[r] = ((sw_[2] * 6.f + (sw_[1] + sw_[3]) * 4.f) + sw_[0]) + sw_[4];
+            }
+            ow[p] = (((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4]) * (1.f / 256.f);
         }
-        ow[p] = (((hr[2] * 6.f + (hr[1] + hr[3]) * 4.f) + hr[0]) + hr[4]) * (1.f / 256.f);
+    }
+    if (mir) {      // the block's outputs in reverse order: this thread's pair (x, x + 1) lands at (31 - x, 30 - x)
+        gx = x0 + (PD_W - 2 - x);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const int tv = o[0][c]; o[0][c] = o[1][c]; o[1][c] = tv; }
+        const float tw = ow[0]; ow[0] = ow[1]; ow[1] = tw;
     }
     if (gx >= dw || gy >= dh) return;
     const size_t e = (size_t)gy * dw + gx;
@@ -510,15 +628,45 @@ struct FeedGather {
     FrameView v[FB_MAX];
     int x_tl[FB_MAX], y_tl[FB_MAX], view_ok[FB_MAX];
 };
-// One frame's contribution to a thread's 2 x 2 block (levels < nb): returns whether the block was touched.  VIEW: level 0 (the frame
-// view); FAST: the frame's / coarse level's rows allow 8-byte pixel loads.  All loads of a phase are unconditional, so that they
-// are in flight together: the four weights, then (if any is non-zero) the 3 x 3 coarse pixels and the four pixels of the block.
+// A frame's contribution to a thread's 2 x 2 block (levels < nb) in two phases (round 4).  The loop over the frames that meet a
+// workgroup's region used to be a chain of dependent round trips per lane -- a frame's four weights, wait, (if any is non-zero) its
+// thirteen pixels, wait, next frame: ~9 memory latencies per block at six waves per SIMD, which is what the kernel's time was.
+//   gather_probe   phase A, for up to four candidate frames at once, no branches: the four weights of the block at clamped (always
+//                  valid) coordinates -> "this lane gets a non-zero weight from frame k".  The loads of the four frames are in
+//                  flight together; a wave then knows which frames contribute to ANY of its lanes.
+//   gather_frame   phase B, only for those frames, in feed order: weights and pixels are loaded together (no early-out between
+//                  them), lanes outside the frame's tile or with zero weights add `(short)(lap * 0) = 0` and `+ 0.f`: exact no-ops.
+// VIEW: level 0 (the frame view); FAST: the frame's / coarse level's rows allow 8-byte pixel loads.
+template <bool VIEW>
+__device__ __forceinline__ bool gather_probe(const FeedGather& a, const FeedLayout& lay, int k, int l, int px0, int py0, bool on) {
+    const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
+    const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
+    const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
+    const bool in = on && tx >= 0 && tx < tw && ty >= 0 && ty < th;
+    bool nz;
+    if (VIEW) {
+        const FrameView& v = a.v[k];
+        const int ix0 = tx - v.left, iy0 = ty - v.top;
+        const int cx0 = min(max(ix0, 0), v.w - 1), cx1 = min(max(ix0 + 1, 0), v.w - 1), cy0 = min(max(iy0, 0), v.h - 1), cy1 = min(max(iy0 + 1, 0), v.h - 1);
+        const unsigned m0 = v.mask[(unsigned)cy0 * (unsigned)v.mstride + (unsigned)cx0], m1 = v.mask[(unsigned)cy0 * (unsigned)v.mstride + (unsigned)cx1];
+        const unsigned m2 = v.mask[(unsigned)cy1 * (unsigned)v.mstride + (unsigned)cx0], m3 = v.mask[(unsigned)cy1 * (unsigned)v.mstride + (unsigned)cx1];
+        const bool x0in = (unsigned)ix0 < (unsigned)v.w, x1in = (unsigned)(ix0 + 1) < (unsigned)v.w, y0in = (unsigned)iy0 < (unsigned)v.h, y1in = (unsigned)(iy0 + 1) < (unsigned)v.h;
+        nz = (x0in & y0in & (m0 != 0)) | (x1in & y0in & (m1 != 0)) | (x0in & y1in & (m2 != 0)) | (x1in & y1in & (m3 != 0));
+    } else {
+        const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
+        const int cx = min(max(tx, 0), tw - 2), cy = min(max(ty, 0), th - 2);
+        const float2 r0 = *reinterpret_cast<const float2*>(Wl + (unsigned)(cy * tw + cx)), r1 = *reinterpret_cast<const float2*>(Wl + (unsigned)((cy + 1) * tw + cx));
+        nz = (r0.x != 0.f) | (r0.y != 0.f) | (r1.x != 0.f) | (r1.y != 0.f);
+    }
+    return in & nz;
+}
 template <bool VIEW, bool FAST>
 __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayout& lay, int k, int l, int px0, int py0, bool live, int (*acc)[6], float (*accw)[2]) {
     const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
     const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
-    const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
-    if (!live || tx < 0 || tx >= tw || ty < 0 || ty >= th) return false;
+    const int tx0_ = px0 - xt, ty0_ = py0 - yt;         // the block's corner in the frame's tile (tile sizes are even here)
+    const bool in = live && tx0_ >= 0 && tx0_ < tw && ty0_ >= 0 && ty0_ < th;
+    const int tx = min(max(tx0_, 0), tw - 2), ty = min(max(ty0_, 0), th - 2);      // lanes outside the tile: some valid block, weight 0
     const FrameView& v = a.v[k];
     float w[4];
     // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
@@ -534,17 +682,16 @@ __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayo
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ix = ix0 + (q & 1), iy = iy0 + (q >> 1);
-            w[q] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)m[q] * (float)(1. / 255.) : 0.f;
+            w[q] = (in && (unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)m[q] * (float)(1. / 255.) : 0.f;
         }
     } else {
         const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const float2 ww = *reinterpret_cast<const float2*>(Wl + (unsigned)((ty + r) * tw + tx));   // tw and tx even
-            w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
+            w[2 * r] = in ? ww.x : 0.f; w[2 * r + 1] = in ? ww.y : 0.f;
         }
     }
-    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) return false;   // exact no-op contributions
     const int cw = (tw + 1) >> 1, ch = (th + 1) >> 1;
     int up[4][3], px[4][3];
     pyr_up_block<FAST>((const int16_t*)(a.base[k] + lay.goff[l + 1]), cw, ch, tx >> 1, ty >> 1, up);
@@ -558,18 +705,18 @@ __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayo
 #pragma unroll
         for (int q = 0; q < 4; q++) load_px3_t<true>(Gl + (unsigned)((ty + (q >> 1)) * tw) * 3u, tx + (q & 1), px[q]);   // tw even: rows start on a dword
     }
+    // no branch on the weights: `x + (short)(lap * 0) = x` and `w + 0.f = w` bit for bit, and the loads above need no verdict to start
 #pragma unroll
     for (int r = 0; r < 2; r++) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const float wq = w[2 * r + q];
-            if (wq == 0.f) continue;        // `+ (short)(v * 0)` and `+ 0.f`: no-ops
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[r][3 * q + c] += (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * wq);
             accw[r][q] += wq;
         }
     }
-    return true;
+    return (w[0] != 0.f) | (w[1] != 0.f) | (w[2] != 0.f) | (w[3] != 0.f);
 }
 constexpr int FG_BX = 32, FG_BY = 8;                  // blocks per workgroup (64 x 16 pixels of the level)
 __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayout lay) {
@@ -617,17 +764,39 @@ __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayo
             accw[r][0] = ws.x; accw[r][1] = ws.y;
         }
         while (todo) {
-            const int k = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
-            todo &= todo - 1ull;
-            const bool cok = (level_dim(a.v[k].tw, l + 1) & 1) == 0;     // even coarse width: its rows start on a dword
-            // one instantiation per combination of (level 0 reads the frame view, 8-byte pixel loads allowed): a run-time flag inside
-            // the pixel loads turns every one of them into a branch of its own and the 13 loads of a block into 13 round trips
+            // the next (up to) four candidate frames, ascending = feed order (uniform)
+            int kk[4], ng = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (todo) { kk[i] = (int)__builtin_ctzll(todo); todo &= todo - 1ull; ng = i + 1; }
+                else kk[i] = kk[i > 0 ? i - 1 : 0];
+            }
+            // phase A: which of them give ANY lane of this wave a non-zero weight (their weight loads in flight together)
+            bool p[4];
             if (l == 0) {
-                if (a.view_ok[k] && cok) have |= gather_frame<true, true>(a, lay, k, l, px0, py0, live, acc, accw);
-                else have |= gather_frame<true, false>(a, lay, k, l, px0, py0, live, acc, accw);
+#pragma unroll
+                for (int i = 0; i < 4; i++) p[i] = gather_probe<true>(a, lay, kk[i], l, px0, py0, live && i < ng);
             } else {
-                if (cok) have |= gather_frame<false, true>(a, lay, k, l, px0, py0, live, acc, accw);
-                else have |= gather_frame<false, false>(a, lay, k, l, px0, py0, live, acc, accw);
+#pragma unroll
+                for (int i = 0; i < 4; i++) p[i] = gather_probe<false>(a, lay, kk[i], l, px0, py0, live && i < ng);
+            }
+            const unsigned act = (__any(p[0]) ? 1u : 0u) | (__any(p[1]) ? 2u : 0u) | (__any(p[2]) ? 4u : 0u) | (__any(p[3]) ? 8u : 0u);
+            const unsigned kpk = (unsigned)kk[0] | ((unsigned)kk[1] << 4) | ((unsigned)kk[2] << 8) | ((unsigned)kk[3] << 12);     // FB_MAX = 16: four bits each
+            // phase B: the contributing frames, in order
+#pragma unroll 1
+            for (int i = 0; i < ng; i++) {
+                if (!((act >> i) & 1u)) continue;
+                const int k = __builtin_amdgcn_readfirstlane((int)((kpk >> (4 * i)) & 15u));
+                const bool cok = (level_dim(a.v[k].tw, l + 1) & 1) == 0;     // even coarse width: its rows start on a dword
+                // one instantiation per combination of (level 0 reads the frame view, 8-byte pixel loads allowed): a run-time flag inside
+                // the pixel loads turns every one of them into a branch of its own and the 13 loads of a block into 13 round trips
+                if (l == 0) {
+                    if (a.view_ok[k] && cok) have |= gather_frame<true, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                    else have |= gather_frame<true, false>(a, lay, k, l, px0, py0, live, acc, accw);
+                } else {
+                    if (cok) have |= gather_frame<false, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                    else have |= gather_frame<false, false>(a, lay, k, l, px0, py0, live, acc, accw);
+                }
             }
         }
         if (!have) return;

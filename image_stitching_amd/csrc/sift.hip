@@ -192,27 +192,33 @@ template <int N>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int w, int h, int seg, Taps t) {
     constexpr int R = N / 2, RB = N + FB_CH - 1, SPAN = FB_TW + N - 1;
     constexpr int RPITCH = FB_TW + FB_TW / 8, SPITCH = SPAN + SPAN / 8 + 1;
-    constexpr int NE = (FB_CH * SPAN + 255) / 256;
     __shared__ float ring[RB * RPITCH];
     __shared__ float stage[FB_CH * SPITCH];
     const int tid = threadIdx.x, x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * seg;
     const int rows_out = min(seg, h - y0);
     const int nchunks = (rows_out + N - 1 + FB_CH - 1) / FB_CH;
     const bool xin = x0 - R >= 0 && x0 + FB_TW - 1 + R < w;      // no horizontal reflection in this strip
-    float pre[NE];
+    float tk[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) tk[k] = t.k[k];
+    // a chunk's FB_CH input rows: thread `tid` takes columns tid and (the first N - 1 threads) FB_TW + tid of every row
+    const int xa = xin ? x0 - R + tid : mis_reflect101(x0 - R + tid, w);
+    const int xb = tid < N - 1 ? (xin ? x0 - R + FB_TW + tid : mis_reflect101(x0 - R + FB_TW + tid, w)) : xa;
+    const int x = x0 + tid, xc = min(x, w - 1);
+    float pa[FB_CH], pb[FB_CH], ctr[FB_CH];      // the next chunk's inputs and the DoG's subtrahends of its outputs, in flight during the passes
     auto load_chunk = [&](int c) {
         const int yb = y0 - R + FB_CH * c;
         const bool yin = yb >= 0 && yb + FB_CH - 1 < h;
 #pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const int e = tid + 256 * i;
-            const int j = e / SPAN, k = e - j * SPAN;
-            float v = 0.f;
-            if (e < FB_CH * SPAN) {
-                const int yi = yin ? yb + j : mis_reflect101(yb + j, h), xi = xin ? x0 - R + k : mis_reflect101(x0 - R + k, w);
-                v = src[(size_t)yi * w + xi];
-            }
-            pre[i] = v;
+        for (int j = 0; j < FB_CH; j++) {
+            const size_t ro = (size_t)(yin ? yb + j : mis_reflect101(yb + j, h)) * w;
+            pa[j] = src[ro + xa];
+            pb[j] = tid < N - 1 ? src[ro + xb] : 0.f;
+        }
+        if (dog) {
+            const int m0 = FB_CH * c + 1 - N;
+#pragma unroll
+            for (int j = 0; j < FB_CH; j++) { const int m = min(max(m0 + j, 0), rows_out - 1); ctr[j] = src[(size_t)(y0 + m) * w + xc]; }
         }
     };
     load_chunk(0);
@@ -220,11 +226,13 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
     for (int c = 0; c < nchunks; c++) {
         __syncthreads();       // the previous chunk's passes are done with the staged rows and the ring's oldest rows
 #pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const int e = tid + 256 * i;
-            const int j = e / SPAN, k = e - j * SPAN;
-            if (e < FB_CH * SPAN) stage[j * SPITCH + k + (k >> 3)] = pre[i];
+        for (int j = 0; j < FB_CH; j++) {
+            stage[j * SPITCH + tid + (tid >> 3)] = pa[j];
+            if (tid < N - 1) stage[j * SPITCH + (FB_TW + tid) + ((FB_TW + tid) >> 3)] = pb[j];
         }
+        float cc[FB_CH];
+#pragma unroll
+        for (int j = 0; j < FB_CH; j++) cc[j] = ctr[j];
         __syncthreads();
         if (c + 1 < nchunks) load_chunk(c + 1);
         {   // row pass: filtered row q = FB_CH * c + rj (relative to y0 - R) into its ring slot
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
                 const float v = my[k + (k >> 3)];
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
-                    if (k - jj >= 0 && k - jj < N) acc[jj] += t.k[k - jj] * v;
+                    if (k - jj >= 0 && k - jj < N) acc[jj] += tk[k - jj] * v;
             }
             float* o = ring + ((FB_CH * c + rj) % RB) * RPITCH + 9 * rx;
 #pragma unroll
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
         }
         __syncthreads();
         // column pass: output rows m0 .. m0 + 7 (relative to y0), from the filtered rows m0 .. m0 + N + 6
-        const int m0 = FB_CH * c + FB_CH - N;
+        const int m0 = FB_CH * c + 1 - N;       // the newest complete output row is FB_CH * c + FB_CH - N: the eight rows that end there
         if (m0 + 7 >= 0 && m0 < rows_out) {
             float acc[8];
 #pragma unroll
@@ -258,9 +266,8 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
                 slot = slot + 1 == RB ? 0 : slot + 1;
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
-                    if (k - jj >= 0 && k - jj < N) acc[jj] += t.k[k - jj] * v;
+                    if (k - jj >= 0 && k - jj < N) acc[jj] += tk[k - jj] * v;
             }
-            const int x = x0 + tid;
             if (x < w) {
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
                     if (m < 0 || m >= rows_out) continue;
                     const size_t o = (size_t)(y0 + m) * w + x;
                     dst[o] = acc[jj];
-                    if (dog) dog[o] = acc[jj] - src[o];
+                    if (dog) dog[o] = acc[jj] - cc[jj];
                 }
             }
         }

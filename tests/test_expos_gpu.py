@@ -195,7 +195,7 @@ def test_stitcher_compose_with_seam_step_matches_oracle(ctx, oracle_mod, expos, 
     cams = [synth.make_camera(W, H, 60.0, y, p, r) for y, p, r in [(0.0, 0.0, 0.0), (14.0, 0.8, -0.5), (27.0, -0.6, 0.4)]]
     gains = [0.75, 1.0, 1.25]
     frames = [np.clip(synth.render_frame(c).astype(np.float32) * g, 0, 255).astype(np.uint8) for c, g in zip(cams, gains)]
-    cfg = isa.StitchConfig(expos_comp_type=expos, seam_find_type=seam, seam_megapix=0.1)
+    cfg = isa.StitchConfig(expos_comp_type=expos, seam_find_type=seam, seam_megapix=0.1, compose_megapix=-1)      # (compose scale: tests/test_reference_job_gpu.py)
     st = isa.Stitcher(ctx, (W, H), cfg)
     pano, mask = st.compose([torch.from_numpy(f).cuda() for f in frames], cams)
     want, wmask = _oracle_compose(oracle_mod, frames, cams, cfg, (W, H))

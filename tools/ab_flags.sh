@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 fa=$1; fb=$2; shift 2
 for rep in 1 2; do
   for f in "$fa" "$fb"; do
-    bash $R/tools/run_variant.sh "$f" python3 $R/bench.py --no-cpu-baseline --no-cpp-host "$@" 2>/dev/null | python3 -c "import sys, json; j = json.loads(sys.stdin.readlines()[-1]); print('flags [%s]: %.3f ms / step' % ('$f', j['ms_per_step']))"
+    bash $R/tools/run_variant.sh "$f" python3 $R/bench.py --no-cpu-baseline --no-cpp-host "$@" 2>$R/gpurun_out/ab_flags.err | python3 -c "import sys, json; j = json.loads(sys.stdin.readlines()[-1]); print('flags [%s]: %.3f ms / step' % ('$f', j['ms_per_step']))"
   done
 done
