@@ -628,45 +628,20 @@ struct FeedGather {
     FrameView v[FB_MAX];
     int x_tl[FB_MAX], y_tl[FB_MAX], view_ok[FB_MAX];
 };
-// A frame's contribution to a thread's 2 x 2 block (levels < nb) in two phases (round 4).  The loop over the frames that meet a
-// workgroup's region used to be a chain of dependent round trips per lane -- a frame's four weights, wait, (if any is non-zero) its
-// thirteen pixels, wait, next frame: ~9 memory latencies per block at six waves per SIMD, which is what the kernel's time was.
-//   gather_probe   phase A, for up to four candidate frames at once, no branches: the four weights of the block at clamped (always
-//                  valid) coordinates -> "this lane gets a non-zero weight from frame k".  The loads of the four frames are in
-//                  flight together; a wave then knows which frames contribute to ANY of its lanes.
-//   gather_frame   phase B, only for those frames, in feed order: weights and pixels are loaded together (no early-out between
-//                  them), lanes outside the frame's tile or with zero weights add `(short)(lap * 0) = 0` and `+ 0.f`: exact no-ops.
-// VIEW: level 0 (the frame view); FAST: the frame's / coarse level's rows allow 8-byte pixel loads.
-template <bool VIEW>
-__device__ __forceinline__ bool gather_probe(const FeedGather& a, const FeedLayout& lay, int k, int l, int px0, int py0, bool on) {
-    const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
-    const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
-    const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
-    const bool in = on && tx >= 0 && tx < tw && ty >= 0 && ty < th;
-    bool nz;
-    if (VIEW) {
-        const FrameView& v = a.v[k];
-        const int ix0 = tx - v.left, iy0 = ty - v.top;
-        const int cx0 = min(max(ix0, 0), v.w - 1), cx1 = min(max(ix0 + 1, 0), v.w - 1), cy0 = min(max(iy0, 0), v.h - 1), cy1 = min(max(iy0 + 1, 0), v.h - 1);
-        const unsigned m0 = v.mask[(unsigned)cy0 * (unsigned)v.mstride + (unsigned)cx0], m1 = v.mask[(unsigned)cy0 * (unsigned)v.mstride + (unsigned)cx1];
-        const unsigned m2 = v.mask[(unsigned)cy1 * (unsigned)v.mstride + (unsigned)cx0], m3 = v.mask[(unsigned)cy1 * (unsigned)v.mstride + (unsigned)cx1];
-        const bool x0in = (unsigned)ix0 < (unsigned)v.w, x1in = (unsigned)(ix0 + 1) < (unsigned)v.w, y0in = (unsigned)iy0 < (unsigned)v.h, y1in = (unsigned)(iy0 + 1) < (unsigned)v.h;
-        nz = (x0in & y0in & (m0 != 0)) | (x1in & y0in & (m1 != 0)) | (x0in & y1in & (m2 != 0)) | (x1in & y1in & (m3 != 0));
-    } else {
-        const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
-        const int cx = min(max(tx, 0), tw - 2), cy = min(max(ty, 0), th - 2);
-        const float2 r0 = *reinterpret_cast<const float2*>(Wl + (unsigned)(cy * tw + cx)), r1 = *reinterpret_cast<const float2*>(Wl + (unsigned)((cy + 1) * tw + cx));
-        nz = (r0.x != 0.f) | (r0.y != 0.f) | (r1.x != 0.f) | (r1.y != 0.f);
-    }
-    return in & nz;
-}
+// (Round 4 tried this loop in two phases -- the weights of four candidate frames probed at once, then the contributing frames with
+// branch-free contributions, so that a lane's ~9 dependent memory round trips become ~5: 589 -> 667 us per 16 frames.  The kernel is
+// bound by vector issue (66 % busy, gpurun_out/r4_pmc*), not by that latency chain: the probes and the un-skipped zero-weight lanes cost
+// more than the overlap gains; a wave-uniform fast path for blocks whose weights are all exactly 1 (no float conversions: 48 fewer
+// instructions per visit) measured 595 us against 589.  Kept as it was.)
+// One frame's contribution to a thread's 2 x 2 block (levels < nb): returns whether the block was touched.  VIEW: level 0 (the frame
+// view); FAST: the frame's / coarse level's rows allow 8-byte pixel loads.  All loads of a phase are unconditional, so that they
+// are in flight together: the four weights, then (if any is non-zero) the 3 x 3 coarse pixels and the four pixels of the block.
 template <bool VIEW, bool FAST>
 __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayout& lay, int k, int l, int px0, int py0, bool live, int (*acc)[6], float (*accw)[2]) {
     const int xt = a.x_tl[k] >> l, yt = a.y_tl[k] >> l;
     const int tw = level_dim(a.v[k].tw, l), th = level_dim(a.v[k].th, l);
-    const int tx0_ = px0 - xt, ty0_ = py0 - yt;         // the block's corner in the frame's tile (tile sizes are even here)
-    const bool in = live && tx0_ >= 0 && tx0_ < tw && ty0_ >= 0 && ty0_ < th;
-    const int tx = min(max(tx0_, 0), tw - 2), ty = min(max(ty0_, 0), th - 2);      // lanes outside the tile: some valid block, weight 0
+    const int tx = px0 - xt, ty = py0 - yt;             // the block's corner in the frame's tile (tile sizes are even here)
+    if (!live || tx < 0 || tx >= tw || ty < 0 || ty >= th) return false;
     const FrameView& v = a.v[k];
     float w[4];
     // view: image coordinates of the block's corner pixel (the block is even-aligned in the tile, not in the image)
@@ -682,16 +657,17 @@ __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayo
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ix = ix0 + (q & 1), iy = iy0 + (q >> 1);
-            w[q] = (in && (unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)m[q] * (float)(1. / 255.) : 0.f;
+            w[q] = ((unsigned)ix < (unsigned)v.w && (unsigned)iy < (unsigned)v.h) ? (float)m[q] * (float)(1. / 255.) : 0.f;
         }
     } else {
         const float* Wl = (const float*)(a.base[k] + lay.woff[l]);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const float2 ww = *reinterpret_cast<const float2*>(Wl + (unsigned)((ty + r) * tw + tx));   // tw and tx even
-            w[2 * r] = in ? ww.x : 0.f; w[2 * r + 1] = in ? ww.y : 0.f;
+            w[2 * r] = ww.x; w[2 * r + 1] = ww.y;
         }
     }
+    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) return false;   // exact no-op contributions
     const int cw = (tw + 1) >> 1, ch = (th + 1) >> 1;
     int up[4][3], px[4][3];
     pyr_up_block<FAST>((const int16_t*)(a.base[k] + lay.goff[l + 1]), cw, ch, tx >> 1, ty >> 1, up);
@@ -705,18 +681,18 @@ __device__ __forceinline__ bool gather_frame(const FeedGather& a, const FeedLayo
 #pragma unroll
         for (int q = 0; q < 4; q++) load_px3_t<true>(Gl + (unsigned)((ty + (q >> 1)) * tw) * 3u, tx + (q & 1), px[q]);   // tw even: rows start on a dword
     }
-    // no branch on the weights: `x + (short)(lap * 0) = x` and `w + 0.f = w` bit for bit, and the loads above need no verdict to start
 #pragma unroll
     for (int r = 0; r < 2; r++) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const float wq = w[2 * r + q];
+            if (wq == 0.f) continue;        // `+ (short)(v * 0)` and `+ 0.f`: no-ops
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[r][3 * q + c] += (int)(int16_t)((float)sat_s16(px[2 * r + q][c] - up[2 * r + q][c]) * wq);
             accw[r][q] += wq;
         }
     }
-    return (w[0] != 0.f) | (w[1] != 0.f) | (w[2] != 0.f) | (w[3] != 0.f);
+    return true;
 }
 constexpr int FG_BX = 32, FG_BY = 8;                  // blocks per workgroup (64 x 16 pixels of the level)
 __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayout lay) {
@@ -764,39 +740,17 @@ __global__ __launch_bounds__(256) void feed_gather_kernel(FeedGather a, FeedLayo
             accw[r][0] = ws.x; accw[r][1] = ws.y;
         }
         while (todo) {
-            // the next (up to) four candidate frames, ascending = feed order (uniform)
-            int kk[4], ng = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (todo) { kk[i] = (int)__builtin_ctzll(todo); todo &= todo - 1ull; ng = i + 1; }
-                else kk[i] = kk[i > 0 ? i - 1 : 0];
-            }
-            // phase A: which of them give ANY lane of this wave a non-zero weight (their weight loads in flight together)
-            bool p[4];
+            const int k = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+            todo &= todo - 1ull;
+            const bool cok = (level_dim(a.v[k].tw, l + 1) & 1) == 0;     // even coarse width: its rows start on a dword
+            // one instantiation per combination of (level 0 reads the frame view, 8-byte pixel loads allowed): a run-time flag inside
+            // the pixel loads turns every one of them into a branch of its own and the 13 loads of a block into 13 round trips
             if (l == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) p[i] = gather_probe<true>(a, lay, kk[i], l, px0, py0, live && i < ng);
+                if (a.view_ok[k] && cok) have |= gather_frame<true, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                else have |= gather_frame<true, false>(a, lay, k, l, px0, py0, live, acc, accw);
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) p[i] = gather_probe<false>(a, lay, kk[i], l, px0, py0, live && i < ng);
-            }
-            const unsigned act = (__any(p[0]) ? 1u : 0u) | (__any(p[1]) ? 2u : 0u) | (__any(p[2]) ? 4u : 0u) | (__any(p[3]) ? 8u : 0u);
-            const unsigned kpk = (unsigned)kk[0] | ((unsigned)kk[1] << 4) | ((unsigned)kk[2] << 8) | ((unsigned)kk[3] << 12);     // FB_MAX = 16: four bits each
-            // phase B: the contributing frames, in order
-#pragma unroll 1
-            for (int i = 0; i < ng; i++) {
-                if (!((act >> i) & 1u)) continue;
-                const int k = __builtin_amdgcn_readfirstlane((int)((kpk >> (4 * i)) & 15u));
-                const bool cok = (level_dim(a.v[k].tw, l + 1) & 1) == 0;     // even coarse width: its rows start on a dword
-                // one instantiation per combination of (level 0 reads the frame view, 8-byte pixel loads allowed): a run-time flag inside
-                // the pixel loads turns every one of them into a branch of its own and the 13 loads of a block into 13 round trips
-                if (l == 0) {
-                    if (a.view_ok[k] && cok) have |= gather_frame<true, true>(a, lay, k, l, px0, py0, live, acc, accw);
-                    else have |= gather_frame<true, false>(a, lay, k, l, px0, py0, live, acc, accw);
-                } else {
-                    if (cok) have |= gather_frame<false, true>(a, lay, k, l, px0, py0, live, acc, accw);
-                    else have |= gather_frame<false, false>(a, lay, k, l, px0, py0, live, acc, accw);
-                }
+                if (cok) have |= gather_frame<false, true>(a, lay, k, l, px0, py0, live, acc, accw);
+                else have |= gather_frame<false, false>(a, lay, k, l, px0, py0, live, acc, accw);
             }
         }
         if (!have) return;
