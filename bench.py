@@ -237,10 +237,12 @@ def main():
             # the same job driven from C++ (host/stitch_bench), after this process's timed region: mis::StitchJob on one GPU; for N > 1
             # mis::ShardedJob on N child ranks with RCCL called directly (the ranks of this script idle at the barrier below meanwhile)
             res["cpp_host"] = cpp_host_leg(cams, args, world, rehearsal)
-        if world == 1 and args.pipeline == "hot_path" and features == "orb" and not os.environ.get("MIS_BENCH_NO_OVERLAP") and not profiled:
+        if world == 1 and os.environ.get("MIS_BENCH_TWO_JOBS") == "1" and not profiled:
+            # experiment, off by default (round 4: two overlapped jobs reached 3287 frames/s against 3250 for one at a time: the eight
+            # streams of two jobs share the runtime's four hardware queues)
             try:
                 res["two_jobs_in_flight"] = two_jobs_leg(isa, misdist, ctx, job, cams, (W, H), cfg, frames, max(4, args.steps // 2))
-            except Exception as e:       # informational: never costs the line
+            except Exception as e:
                 res["two_jobs_in_flight"] = {"error": str(e)[:200]}
         if single:
             res["same_workload_on_1_gpu"] = single

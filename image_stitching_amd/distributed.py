@@ -320,12 +320,21 @@ class HipEngine:
         """fn() runs inside this engine's NEXT matcher call, on the calling thread, once that call's device work is enqueued
         (mis_match_on_enqueued): the thread is idle from there until the device finishes.  fn=None clears a pending hook."""
         if fn is None:
-            self._enqueued_cb = None
+            self._enqueued_fn = None
             self.ctx.lib.mis_match_on_enqueued(self.ctx.h, None, None)
             return
-        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())
-        self._enqueued_cb = cb          # alive until it has run
-        self.ctx.check(self.ctx.lib.mis_match_on_enqueued(self.ctx.h, C.cast(cb, C.c_void_p), None))
+        # ONE ctypes callback object per instance, created on first use: a CFUNCTYPE instance is a reference cycle that only the
+        # cyclic garbage collector frees, and a fresh one per step kept that step's closure -- and through it the step's panorama --
+        # alive while bench.py times with the collector paused (config 5: +1 GB of allocator growth per step, round 4)
+        self._enqueued_fn = fn
+        if getattr(self, "_enqueued_cb", None) is None:
+            self._enqueued_cb = C.CFUNCTYPE(None, C.c_void_p)(self._run_enqueued)
+        self.ctx.check(self.ctx.lib.mis_match_on_enqueued(self.ctx.h, C.cast(self._enqueued_cb, C.c_void_p), None))
+
+    def _run_enqueued(self, _user):
+        fn, self._enqueued_fn = getattr(self, "_enqueued_fn", None), None
+        if fn is not None:
+            fn()
 
     def compose_after_knn(self, target_seq):
         """Queue the compose stream behind the 2-NN pass of matcher call `target_seq` (made by another thread): that
@@ -763,6 +772,7 @@ class StitchJob:
                 btype, bands = box["r"] if indices == everyone else self._compose_on_side_stream(frames, indices)
                 with torch.cuda.stream(self.engine.compose_stream):
                     pano, mask = self.stage_exchange_finalize()
+            box.clear()          # (the hook's closure may outlive this call: it must not hold a panorama)
         else:
             pm, conf = self.stage_match(feats)
             indices = self.stage_prune(conf)

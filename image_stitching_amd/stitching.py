@@ -577,12 +577,21 @@ class OrbFeatureFinder:
         """fn() runs inside this finder's NEXT detect_batch call, on the calling thread, once the batch's device work is enqueued
         (mis_orb_on_enqueued).  fn=None clears a pending hook."""
         if fn is None:
-            self._enqueued_cb = None
+            self._enqueued_fn = None
             self.ctx.lib.mis_orb_on_enqueued(self.h, None, None)
             return
-        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _user: fn())
-        self._enqueued_cb = cb          # alive until it has run
-        self.ctx.check(self.ctx.lib.mis_orb_on_enqueued(self.h, C.cast(cb, C.c_void_p), None))
+        # ONE ctypes callback object per instance, created on first use: a CFUNCTYPE instance is a reference cycle that only the
+        # cyclic garbage collector frees, and a fresh one per step kept that step's closure -- and through it the step's panorama --
+        # alive while bench.py times with the collector paused (config 5: +1 GB of allocator growth per step, round 4)
+        self._enqueued_fn = fn
+        if getattr(self, "_enqueued_cb", None) is None:
+            self._enqueued_cb = C.CFUNCTYPE(None, C.c_void_p)(self._run_enqueued)
+        self.ctx.check(self.ctx.lib.mis_orb_on_enqueued(self.h, C.cast(self._enqueued_cb, C.c_void_p), None))
+
+    def _run_enqueued(self, _user):
+        fn, self._enqueued_fn = getattr(self, "_enqueued_fn", None), None
+        if fn is not None:
+            fn()
 
     def detect_batch(self, imgs):
         n = len(imgs)
