@@ -14,6 +14,15 @@
 #define MIS_HD __host__ __device__ __forceinline__
 #define MIS_PI_F 3.14159265358979323846f
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on gfx9 that fence
+// is `s_waitcnt vmcnt(0) lgkmcnt(0)`: every global load the wave has in flight -- a software prefetch of the next tile -- is waited
+// for at the barrier, and every global store has to drain.  Kernels whose barriers only hand LDS data between waves (the global
+// buffers are read-only or written once, by their owner) use this one and keep their loads in flight across it; the compiler still
+// waits for a loaded register where it is first used.
+__device__ __forceinline__ void mis_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // cvRound: round half to even
 MIS_HD int mis_round_f(float v) {
 #ifdef __HIP_DEVICE_COMPILE__

@@ -800,6 +800,8 @@ __device__ unsigned long long g_jac_prof[8];    // shader cycles: pivot search, 
 #define JP_T(v)
 #define JP_ADD(i, a, b)
 #endif
+__device__ unsigned long long g_tail_log[6 * 1024];
+__device__ unsigned g_tail_log_n;
 __device__ unsigned long long g_tail_prof[12];  // [8..11], part 4 launches: first entry (wall clock) + 1, last exit, longest workgroup, workgroups with work
 //   // jacobi ticks, rotations, normal_eq ticks, LM iterations, dlt ticks, tail ticks, tails, max tail ticks
 #define PROF_T0(v) unsigned long long v = wall_clock64()
@@ -812,7 +814,15 @@ __device__ unsigned long long g_tail_prof[12];  // [8..11], part 4 launches: fir
 #define JP_T(v)
 #define JP_ADD(i, a, b)
 #endif
-constexpr int TAIL_PCAP = 2048;
+#ifndef MIS_PS_PTS
+#define MIS_PS_PTS 32
+#endif
+constexpr int PS_PTS = MIS_PS_PTS;           // points per stage of ordered_sums (a multiple of 8, at most 64)
+constexpr int PS_TERMS = 42;                 // non-zero terms of a point: 6 accumulators with two (LM) + 30 with one, or 36 with one (L^T L)
+constexpr int PS_PITCH = 43;                 // doubles between consecutive points of a stage: 86 dwords, so that 32 lanes (one point each) write 32 different bank pairs;
+                                             // a point's 43rd double is 0.0: the second term of the accumulators that have one
+constexpr int PS_STAGE = PS_PTS * PS_PITCH;  // doubles of one stage
+constexpr size_t TAIL_DYN_LDS = sizeof(double) * 2 * PS_STAGE;     // dynamic LDS of the launches that run a DLT / LM refinement
 struct TailShared {
     double A[81], V[81], W[9];
     double best[9], nrm[8];
@@ -820,25 +830,25 @@ struct TailShared {
     float Hf[9];
     int indR[9], indC[9];
     int np, go;
-    double chunk[TB * 10];  // per-point terms of the current 256-point chunk of a sequential sum
-    float4* pts;            // the tail's point set {d.x, d.y, s.x, s.y}, staged once in the launch's dynamic LDS: every pass of the DLT and of the LM refinement reads it
-    int pcap;               // points that fit (0 in the launches that only replay or mask: 23 KB workgroups find a compute unit beside the composition's kernels, 55 KB ones wait)
+    int bad;                // = the number of the ordered_sums call whose chunk holds a non-finite record: those sums take the plain loop
+    double chunk[TB * 10];  // per-point records of the current 256-point chunk of a sequential sum
+    int staged;             // the launch carries ordered_sums' term stages (PS_PTS points, double-buffered) in its dynamic LDS (none in the
+                            // launches that only replay or mask: 23 KB workgroups find a compute unit beside the composition's kernels, larger ones wait)
+#ifdef MIS_TAIL_PROF
+    int prof_rot, prof_lm;  // this tail's rotations / LM iterations (g_tail_log)
+#endif
 };
 // The DLT (two passes for the normalisation, one for L^T L) and every normal-equations pass of the LM refinement (1 + up to 20)
-// walk the same inlier set 256 points at a time; from global memory each chunk starts with an exposed memory latency (1 - 3 us
-// beside the composition's kernels: a third of a 21 us pass over 586 points).  Points past S.pcap are read from memory.
-__device__ __forceinline__ void tail_stage_points(TailShared& S, const float* s1, const float* d1, int np) {
-    for (int i = threadIdx.x; i < min(np, S.pcap); i += TB) {
-        const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
-        S.pts[i] = make_float4(dd.x, dd.y, ss.x, ss.y);
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ float4 tail_point(const TailShared& S, const float* s1, const float* d1, int i) {
-    if (i < S.pcap) return S.pts[i];
+// walk the same inlier set 256 points at a time, thread t taking point base + t.  From global memory each chunk would start with an
+// exposed memory latency (1 - 3 us beside the composition's kernels); round 3 staged the whole set in 32 KB of LDS instead, which
+// made the workgroup wait for room beside the composition's grids (a step moves by ~0.1 ms per 16 KB of the tails' LDS, round 4).
+// Now a thread keeps its point of chunk 0 in registers for the whole tail and loads its point of chunk c + 1 while chunk c is being
+// summed; the barriers inside a pass wait for LDS traffic only (lds_barrier), so the load stays in flight across them.
+__device__ __forceinline__ float4 tail_load_point(const float* s1, const float* d1, int i) {
     const float2 dd = reinterpret_cast<const float2*>(d1)[i], ss = reinterpret_cast<const float2*>(s1)[i];
     return make_float4(dd.x, dd.y, ss.x, ss.y);
 }
+__device__ __forceinline__ void lds_barrier() { mis_lds_barrier(); }      // every wave's LDS writes are done and visible; global loads stay in flight (dev_math.h)
 
 // Jacobi with the n independent plane rotations of a step spread over n lanes and the four
 // index-table scans over four lanes; the arithmetic of every element is that of the serial loop.
@@ -1009,6 +1019,9 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
             JP_ADD(1, j1, j2); JP_ADD(2, j2, j3); JP_ADD(3, j3, j4);
         }
         PROF_INC(1, iters);
+#ifdef MIS_TAIL_PROF
+        if (t == 0) S.prof_rot += iters;
+#endif
         JP_T(j_sort);
         if (t < n) W[t] = Wt;
         wave_sync();
@@ -1033,6 +1046,191 @@ __device__ __forceinline__ void jacobi_eigen_coop(TailShared& S) {
     PROF_ADD(0, pj);
 }
 
+
+// ---- round 4: the ordered sums of the tails as a pipeline ----
+// Every pass of the DLT / LM refinement over the inlier set is a set of 45 sums that must add their terms in point order (the CPU
+// loop's order: the results are compared bit for bit).  Round 3 gave the 45 sums to 45 lanes of one wave, which per point read four
+// operands from LDS, multiplied and added: 6 f64 operations per point at ~9.5 issue cycles each for a wave alone on its SIMD
+// (tools/micro/lat_bench.hip) = ~60 cycles per point, 38 us per pass at 1500 points, nine to twelve passes per tail -- 45 % of the
+// longest tails.  Only the additions have to be serial.  Now waves 1 .. 3 turn PS_PTS points at a time into the accumulators' terms
+// -- a lane takes ONE point: its record (10 doubles) in five 16-byte reads, then a third of the terms, whose operand indices are
+// compile-time constants of the wave's number (a first form with the indices in registers read every operand from LDS again: 16
+// conflicting 8-byte reads per lane, no faster than round 3) --, double-buffered in S.prod, and lane a < 45 of wave 0 reads its
+// term(s) of a point and adds: the additions -- two per point for six of the LM sums (acc += u0 v0; acc += u1 v1), one for the
+// others and for L^T L (acc += (u0 v0 + u1 v1)) -- are all that is left on its chain (11 cycles per dependent add: 22 per point).
+//  * Terms with a structural zero are not formed: a record's zero entry (LM: index 9, L^T L: index 3) makes 48 of the 90 products
+//    +-0, and adding +-0 leaves an accumulator that is not -0 as it is (ours start at +0 and x + y is -0 only for x = y = -0).  That
+//    holds for finite records; a chunk with a non-finite one (0 x inf = NaN in the CPU loop) takes round 3's plain loop instead
+//    (S.bad).  A point's 42 terms are 344 bytes of LDS instead of 720.
+struct PsEntry { int a0, b0, a1, b1; };
+constexpr int ps_nib(unsigned long long tab, int i) { return (int)((tab >> (4 * i)) & 15ull); }
+// operand indices of LM accumulator a: 36 entries of J^T J (upper triangle, row-major), 8 of J^T r, |r|^2; a per-point record is
+// {a b ww c0 c1 c2 c3 e0 e1 0}: row 2q of J is (a b ww 0 0 0 c0 c1), row 2q + 1 is (0 0 0 a b ww c2 c3)
+constexpr PsEntry lm_entry(int a) {
+    const unsigned long long j0 = 0x43999210ull, j1 = 0x65210999ull;
+    if (a == 44) return PsEntry{7, 7, 8, 8};
+    if (a >= 36) return PsEntry{ps_nib(j0, a - 36), 7, ps_nib(j1, a - 36), 8};
+    int ai = 0, aj = a;
+    while (aj >= 8 - ai) { aj -= 8 - ai; ai++; }
+    aj += ai;
+    return PsEntry{ps_nib(j0, ai), ps_nib(j0, aj), ps_nib(j1, ai), ps_nib(j1, aj)};
+}
+// ... of L^T L entry a (upper triangle of 9 x 9, row-major); a per-point record is {X Y 1 0 -xX -xY -x -yX -yY -y}
+constexpr PsEntry dlt_entry(int a) {
+    const unsigned long long lx = 0x654333210ull, ly = 0x987210333ull;
+    int j = 0, k = a;
+    while (k >= 9 - j) { k -= 9 - j; j++; }
+    k += j;
+    return PsEntry{ps_nib(lx, j), ps_nib(lx, k), ps_nib(ly, j), ps_nib(ly, k)};
+}
+// ADDS: 2 = LM (two separately added terms), 1 = L^T L (the two products are added to each other first)
+template <int ADDS> constexpr PsEntry ps_entry(int a) { return ADDS == 2 ? lm_entry(a) : dlt_entry(a); }
+template <int ADDS> constexpr bool ps_z1(int a) { const PsEntry e = ps_entry<ADDS>(a); const int z = ADDS == 2 ? 9 : 3; return e.a0 == z || e.b0 == z; }
+template <int ADDS> constexpr bool ps_z2(int a) { const PsEntry e = ps_entry<ADDS>(a); const int z = ADDS == 2 ? 9 : 3; return e.a1 == z || e.b1 == z; }
+// terms accumulator a adds per point: 0 (both products structurally zero), 1, or 2 (LM only)
+template <int ADDS> constexpr int ps_kind(int a) { return (ps_z1<ADDS>(a) && ps_z2<ADDS>(a)) ? 0 : (ADDS == 2 && !ps_z1<ADDS>(a) && !ps_z2<ADDS>(a)) ? 2 : 1; }
+// where they sit in a point's block of PS_TERMS doubles: the two-term accumulators first (term pairs), then the one-term ones
+template <int ADDS> constexpr int ps_off(int a) {
+    int pairs = 0;
+    for (int i = 0; i < 45; i++) pairs += ps_kind<ADDS>(i) == 2;
+    int p = 0, o = 0;
+    for (int i = 0; i < a; i++) { p += ps_kind<ADDS>(i) == 2; o += ps_kind<ADDS>(i) == 1; }
+    return ps_kind<ADDS>(a) == 2 ? 2 * p : ps_kind<ADDS>(a) == 1 ? 2 * pairs + o : -1;
+}
+static_assert(ps_off<2>(44) == 10 && ps_kind<2>(44) == 2 && ps_kind<2>(3) == 0 && ps_off<2>(43) == 8 && ps_off<2>(41) == PS_TERMS - 1, "LM term layout");
+static_assert(ps_kind<1>(44) == 1 && ps_off<1>(44) == 35 && ps_kind<1>(3) == 0, "L^T L term layout");
+// the terms of accumulators A .. 44 whose offsets fall in wave W's third of the block (W = 0 .. 2; W = 3: accumulator 44 alone)
+template <int ADDS, int W, int A> struct PsEmit {
+    static __device__ __forceinline__ void put(const double (&r)[10], double* out) {
+        constexpr PsEntry e = ps_entry<ADDS>(A);
+        constexpr int kind = ps_kind<ADDS>(A), off = ps_off<ADDS>(A);
+        constexpr bool mine = kind != 0 && (W == 3 ? A == 44 : off / (PS_TERMS / 3) == W);
+        if constexpr (mine) {
+            if constexpr (ADDS == 1) {
+                if constexpr (ps_z2<1>(A)) out[off] = r[e.a0] * r[e.b0];
+                else if constexpr (ps_z1<1>(A)) out[off] = r[e.a1] * r[e.b1];
+                else out[off] = r[e.a0] * r[e.b0] + r[e.a1] * r[e.b1];
+            } else if constexpr (kind == 2) {
+                out[off] = r[e.a0] * r[e.b0];
+                out[off + 1] = r[e.a1] * r[e.b1];
+            } else {
+                out[off] = ps_z2<2>(A) ? r[e.a0] * r[e.b0] : r[e.a1] * r[e.b1];
+            }
+        }
+        PsEmit<ADDS, W, A + 1>::put(r, out);
+    }
+};
+template <int ADDS, int W> struct PsEmit<ADDS, W, 45> { static __device__ __forceinline__ void put(const double (&)[10], double*) {} };
+
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#define PS_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define PS_ADD(i, who, a, b) do { if (threadIdx.x == (who)) atomicAdd(&g_jac_prof[i], (b) - (a)); } while (0)
+#else
+#define PS_T(v)
+#define PS_ADD(i, who, a, b)
+#endif
+// The sums of one chunk: cnt <= TB records in S.chunk, written by all threads, not yet fenced.  `all`: every accumulator; otherwise only
+// the 45th (|r|^2 of an LM trial step).  kind / off: this lane's accumulator (lane t < 45 of wave 0; ps_kind / ps_off of t), ent:
+// its packed operand indices for the plain loop.  Barriers wait for LDS only: the caller's load of the next chunk's point is in flight.
+extern __shared__ double tail_dyn[];      // the term stages (TAIL_DYN_LDS bytes in the launches that have them)
+template <int ADDS>
+__device__ __forceinline__ void ordered_sums(TailShared& S, int cnt, bool all, int kind, int off, int ent, int& gen, double& acc) {
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), L = t & 63;
+    lds_barrier();
+    // a thread with a non-finite record stamped the flag with this call's number (never reset: the numbers do not repeat); a launch
+    // without term stages (a four-correspondence problem met by a replay-only launch) takes the plain loop as well
+    const bool bad = S.bad == gen || !S.staged;
+    gen++;
+    if (bad) {
+        // round 3's loop: 45 lanes, operands from the records, every product formed
+        if (all ? t < 45 : t == 44) {
+            const int a0 = ent & 15, b0 = (ent >> 4) & 15, a1 = (ent >> 8) & 15, b1 = (ent >> 12) & 15;
+            for (int q = 0; q < cnt; q++) {
+                const double* r = S.chunk + 10 * q;
+                if (ADDS == 2) { acc += r[a0] * r[b0]; acc += r[a1] * r[b1]; }
+                else acc += r[a0] * r[b0] + r[a1] * r[b1];
+            }
+        }
+        lds_barrier();
+        return;
+    }
+    const int nsub = (cnt + PS_PTS - 1) / PS_PTS;
+    const bool accumulate = (all ? t < 45 : t == 44) && kind != 0;
+    const int off2 = kind == 2 ? off + 1 : PS_TERMS;
+    auto produce = [&](int sb) {
+        const int p = sb * PS_PTS + L;
+        if (wave == 0 || L >= PS_PTS || p >= cnt) return;
+        double r[10];
+        const double2* rp = reinterpret_cast<const double2*>(S.chunk + 10 * p);
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const double2 v = rp[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+        double* out = tail_dyn + (sb & 1) * PS_STAGE + L * PS_PITCH;
+        if (!all) { if (wave == 1) PsEmit<ADDS, 3, 0>::put(r, out); }
+        else if (wave == 1) PsEmit<ADDS, 0, 0>::put(r, out);
+        else if (wave == 2) PsEmit<ADDS, 1, 0>::put(r, out);
+        else PsEmit<ADDS, 2, 0>::put(r, out);
+    };
+    PS_T(ps0);
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+    unsigned long long ps_acc = 0, ps_prod = 0, ps_bar = 0;
+#endif
+    produce(0);
+    lds_barrier();
+    for (int sb = 0; sb < nsub; sb++) {
+        PS_T(ps1);
+        if (sb + 1 < nsub) produce(sb + 1);
+        PS_T(ps2);
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+        ps_prod += ps2 - ps1;
+#endif
+        if (accumulate) {
+            // a lane's second term: the slot behind its first (two-term accumulators) or the point's zero (x + 0 = x: no select on the chain)
+            const double* P = tail_dyn + (sb & 1) * PS_STAGE;
+            const int n_s = min(PS_PTS, cnt - sb * PS_PTS);
+            if (n_s == PS_PTS) {
+#pragma unroll
+                for (int u0 = 0; u0 < PS_PTS; u0 += 8) {      // eight points in flight
+                    double v0[8], v1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { v0[u] = P[(u0 + u) * PS_PITCH + off]; if (ADDS == 2) v1[u] = P[(u0 + u) * PS_PITCH + off2]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { acc += v0[u]; if (ADDS == 2) acc += v1[u]; }
+                }
+            } else {
+                for (int u = 0; u < n_s; u++) {
+                    acc += P[u * PS_PITCH + off];
+                    if (ADDS == 2) acc += P[u * PS_PITCH + off2];
+                }
+            }
+        }
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+        asm volatile("" :: "v"(acc));
+#endif
+        PS_T(ps3);
+        lds_barrier();
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+        ps_acc += ps3 - ps2;
+        ps_bar += __builtin_readcyclecounter() - ps3;
+#endif
+    }
+    PS_T(ps4);
+#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+    PS_ADD(0, 44, 0ull, ps_acc);
+    PS_ADD(1, 64, 0ull, ps_prod);
+    PS_ADD(2, 44, ps0, ps4);
+    PS_ADD(3, 44, 0ull, (unsigned long long)nsub);
+    PS_ADD(4, 44, 0ull, ps_bar);
+    PS_ADD(5, 64, 0ull, ps_bar);
+#endif
+}
+// a record's entries are all finite (their sum of magnitudes is: an overflowing sum only sends the chunk to the plain loop)
+__device__ __forceinline__ bool ps_record_bad(const double* r) {
+    double m = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) m += fabs(r[i]);
+    return !(m <= DBL_MAX);
+}
+
 // LM callback of the homography refinement (fundam.cpp HomographyRefineCallback)
 __device__ __forceinline__ void lm_point(const double* h, double Mx, double My, double* ww, double* xi, double* yi) {
     double w = (h[6] * Mx + h[7] * My) + 1.;
@@ -1044,29 +1242,41 @@ __device__ __forceinline__ void lm_point(const double* h, double Mx, double My, 
 
 // HomographyEstimatorCallback::runKernel on np points (s1 -> d1) by the whole workgroup; S.best is
 // overwritten unless the configuration is degenerate.  Sums keep the sequential order.
-__device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np, double* rec) {
+__device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np, float4 pt0, double* rec) {
     const int t = threadIdx.x;
     {
-        // the four centroids and the four mean absolute deviations: sequential sums over the points by four accumulator threads, from
-        // the staged set in LDS (a serial loop over global memory pays a memory latency per handful of points: 100 us of a 270 us DLT
-        // at 500 points); points past the staged set go through a 256-point buffer.
-        float* stage = reinterpret_cast<float*>(S.chunk);      // 4 floats per point: d.x d.y s.x s.y
+        // the four centroids and the four mean absolute deviations: sequential sums over the points by four accumulator lanes.  All
+        // threads turn their point into the four double terms of the pass (the conversion, |x - c|) in LDS; the lanes only add.
+        double* stage = S.chunk;      // 4 doubles per point: d.x d.y s.x s.y
         for (int pass = 0; pass < 2; pass++) {
             double acc = 0;
-            const double c = pass ? S.nrm[t & 3] : 0.;
+            const double c0 = pass ? S.nrm[0] : 0., c1 = pass ? S.nrm[1] : 0., c2 = pass ? S.nrm[2] : 0., c3 = pass ? S.nrm[3] : 0.;
+            float4 cur = pt0;
             for (int base = 0; base < np; base += TB) {
                 const int i = base + t, cnt = min(TB, np - base);
-                const float* src = reinterpret_cast<const float*>(S.pts + base);      // the staged set itself while it lasts
-                if (base + TB > S.pcap) {
-                    if (i < np) reinterpret_cast<float4*>(stage)[t] = tail_point(S, s1, d1, i);
-                    __syncthreads();
-                    src = stage;
+                float4 nxt = cur;
+                if (i + TB < np) nxt = tail_load_point(s1, d1, i + TB);
+                if (i < np) {
+                    double* o = stage + 4 * t;
+                    if (pass == 0) { o[0] = cur.x; o[1] = cur.y; o[2] = cur.z; o[3] = cur.w; }
+                    else { o[0] = fabs(cur.x - c0); o[1] = fabs(cur.y - c1); o[2] = fabs(cur.z - c2); o[3] = fabs(cur.w - c3); }
                 }
+                lds_barrier();
                 if (t < 4) {
-                    if (pass == 0) for (int q = 0; q < cnt; q++) acc += src[4 * q + t];
-                    else for (int q = 0; q < cnt; q++) acc += fabs(src[4 * q + t] - c);
+                    const double* q = stage + t;
+                    int u = 0;
+#pragma unroll 1
+                    for (; u + 8 <= cnt; u += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) v[k] = q[4 * (u + k)];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) acc += v[k];
+                    }
+                    for (; u < cnt; u++) acc += q[4 * u];
                 }
-                if (base + TB > S.pcap) __syncthreads();
+                lds_barrier();
+                cur = nxt;
             }
             if (t < 4) { if (pass == 0) S.nrm[t] = acc / np; else S.nrm[4 + t] = acc; }      // cmx cmy cMx cMy, then smx smy sMx sMy
             __syncthreads();
@@ -1079,31 +1289,33 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
     if (t < 4) S.nrm[4 + t] = np / S.nrm[4 + t];
     __syncthreads();
     {
-        // L^T L: 256 points at a time -- every thread produces the terms of one point into LDS, then the 45
-        // accumulator threads add the chunk in point order (the sequential order of the CPU loop)
+        // L^T L: 256 points at a time -- every thread produces the record of one point into LDS, then the 45 sums take their terms
+        // in point order (the sequential order of the CPU loop) through ordered_sums
         const double cmx = S.nrm[0], cmy = S.nrm[1], cMx = S.nrm[2], cMy = S.nrm[3], smx = S.nrm[4], smy = S.nrm[5], sMx = S.nrm[6], sMy = S.nrm[7];
         int j = 0, k = t;  // t-th entry of the upper triangle, row-major (t < 45)
         while (t < 45 && k >= 9 - j) { k -= 9 - j; j++; }
         k += j;
-        const int lxi[9] = {0, 1, 2, 3, 3, 3, 4, 5, 6}, lyi[9] = {3, 3, 3, 0, 1, 2, 7, 8, 9};
-        const int xj = t < 45 ? lxi[j] : 0, xk = t < 45 ? lxi[k] : 0, yj = t < 45 ? lyi[j] : 0, yk = t < 45 ? lyi[k] : 0;
+        const int ta = t < 45 ? t : 0;
+        const PsEntry e = dlt_entry(ta);
+        const int kind = ps_kind<1>(ta), off = ps_off<1>(ta), ent = e.a0 | (e.b0 << 4) | (e.a1 << 8) | (e.b1 << 12);
+        int gen = 1;
         double acc = 0;
+        float4 cur = pt0;
         for (int base = 0; base < np; base += TB) {
             const int i = base + t, cnt = min(TB, np - base);
+            float4 nxt = cur;
+            if (i + TB < np) nxt = tail_load_point(s1, d1, i + TB);
             if (i < np) {
-                const float4 pt = tail_point(S, s1, d1, i);
-                double x = (pt.x - cmx) * smx, y = (pt.y - cmy) * smy;
-                double X = (pt.z - cMx) * sMx, Y = (pt.w - cMy) * sMy;
-                double* r = S.chunk + 10 * t;  // X Y 1 0 -xX -xY -x -yX -yY -y
-                r[0] = X; r[1] = Y; r[2] = 1; r[3] = 0; r[4] = -x * X; r[5] = -x * Y; r[6] = -x; r[7] = -y * X; r[8] = -y * Y; r[9] = -y;
+                double x = (cur.x - cmx) * smx, y = (cur.y - cmy) * smy;
+                double X = (cur.z - cMx) * sMx, Y = (cur.w - cMy) * sMy;
+                const double rv[10] = {X, Y, 1., 0., -x * X, -x * Y, -x, -y * X, -y * Y, -y};      // X Y 1 0 -xX -xY -x -yX -yY -y
+                double* r = S.chunk + 10 * t;
+#pragma unroll
+                for (int q = 0; q < 10; q++) r[q] = rv[q];
+                if (ps_record_bad(rv)) S.bad = gen;
             }
-            __syncthreads();
-            if (t < 45)
-                for (int q = 0; q < cnt; q++) {
-                    const double* r = S.chunk + 10 * q;
-                    acc += r[xj] * r[xk] + r[yj] * r[yk];
-                }
-            __syncthreads();
+            ordered_sums<1>(S, cnt, true, kind, off, ent, gen, acc);      // acc += r[xj] r[xk] + r[yj] r[yk], in point order
+            cur = nxt;
         }
         if (t < 45) S.A[j * 9 + k] = acc;
     }
@@ -1116,59 +1328,63 @@ __device__ void dlt_coop(TailShared& S, const float* s1, const float* d1, int np
 }
 
 // createLMSolver(HomographyRefineCallback, 10)->run(H8): OpenCV <= 4.5 LMSolverImpl::run
-__device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, int np, double* rec) {
+__device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, int np, float4 pt0, double* rec) {
     const int t = threadIdx.x;
     double* x = S.lm;            double* xd = x + 8;   double* A = xd + 8;  double* Ap = A + 64;
     double* v = Ap + 64;         double* d = v + 8;    double* D = d + 8;   double* sc = D + 8;  // S, Sd, rmax, accepted, lambda, lc, need_invert, nu
+    int ai = 0, aj = t;
+    while (t < 36 && aj >= 8 - ai) { aj -= 8 - ai; ai++; }
+    aj += ai;
+    // this lane's accumulator in ordered_sums (lane t < 45 of wave 0)
+    const int ta = t < 45 ? t : 0;
+    const PsEntry le = lm_entry(ta);
+    const int kind = ps_kind<2>(ta), off = ps_off<2>(ta), ent = le.a0 | (le.b0 << 4) | (le.a1 << 8) | (le.b1 << 12);
+    int gen = 1 << 20;
     auto normal_eq = [&](const double* h, bool with_J) {
-        // thread roles of the sequential sums, all in wave 0 and all of one form, acc += r[a0] r[b0]; acc += r[a1] r[b1] per point:
-        // 36 entries of J^T J (t < 36), 8 of J^T r (36 .. 43), |r|^2 (44, which also keeps |r|_inf).  Spread over three waves
-        // (round 2) the three loops competed for the LDS pipe: 82 cycles per point against this loop's ~40 (one wave's issue rate).
-        const int j0[8] = {0, 1, 2, 9, 9, 9, 3, 4}, j1[8] = {9, 9, 9, 0, 1, 2, 5, 6};
-        int ai = 0, aj = t;
-        while (t < 36 && aj >= 8 - ai) { aj -= 8 - ai; ai++; }
-        aj += ai;
-        int a0 = 9, b0 = 9, a1 = 9, b1 = 9;
-        if (t < 36) { a0 = j0[ai]; b0 = j0[aj]; a1 = j1[ai]; b1 = j1[aj]; }
-        else if (t < 44) { a0 = j0[t - 36]; b0 = 7; a1 = j1[t - 36]; b1 = 8; }
-        else if (t == 44) { a0 = 7; b0 = 7; a1 = 8; b1 = 8; }
+        // the sequential sums, all of one form, acc += r[a0] r[b0]; acc += r[a1] r[b1] per point: 36 entries of J^T J (lane t < 36 of
+        // wave 0), 8 of J^T r (36 .. 43), |r|^2 (44).  |r|_inf ("if (fabs(e) > mx) mx = fabs(e)" is a maximum: order-free) is kept by
+        // the threads that produce the points' records and reduced at the end.
         double acc = 0, mx = 0;
         PROF_T0(pn);
+        float4 cur = pt0;
         for (int base = 0; base < np; base += TB) {
             const int p = base + t, cnt = min(TB, np - base);
+            float4 nxt = cur;
+            if (p + TB < np) nxt = tail_load_point(s1, d1, p + TB);
             if (p < np) {
-                const float4 pt = tail_point(S, s1, d1, p);
-                double Mx = (double)pt.z, My = (double)pt.w, ww, xi, yi;
+                double Mx = (double)cur.z, My = (double)cur.w, ww, xi, yi;
                 lm_point(h, Mx, My, &ww, &xi, &yi);
-                double* r = S.chunk + 10 * t;  // a b ww c0 c1 c2 c3 e0 e1 0
-                r[7] = xi - (double)pt.x; r[8] = yi - (double)pt.y;
-                r[0] = Mx * ww; r[1] = My * ww; r[2] = ww;
-                r[3] = -Mx * ww * xi; r[4] = -My * ww * xi; r[5] = -Mx * ww * yi; r[6] = -My * ww * yi; r[9] = 0;
-            }
-            __syncthreads();
-            if (with_J ? t < 45 : t == 44) {
-                // "if (fabs(e) > mx) mx = fabs(e)" is a maximum: one v_max_f64 per value (lane 44's operands are the residuals; the
-                // other lanes' maxima are not used).  Eight points per trip, LDS reads up front.
-                auto one = [&](const double* r) {
-                    const double u0 = r[a0], v0 = r[b0], u1 = r[a1], v1 = r[b1];
-                    acc += u0 * v0;
-                    acc += u1 * v1;
-                    asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(u0));
-                    asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(u1));
-                };
-                int q = 0;
-#pragma unroll 1
-                for (; q + 8 <= cnt; q += 8) {
+                const double e0 = xi - (double)cur.x, e1 = yi - (double)cur.y;
+                const double rv[10] = {Mx * ww, My * ww, ww, -Mx * ww * xi, -My * ww * xi, -Mx * ww * yi, -My * ww * yi, e0, e1, 0.};      // a b ww c0 c1 c2 c3 e0 e1 0
+                double* r = S.chunk + 10 * t;
 #pragma unroll
-                    for (int u = 0; u < 8; u++) one(S.chunk + 10 * (q + u));
-                }
-                for (; q < cnt; q++) one(S.chunk + 10 * q);
+                for (int i = 0; i < 10; i++) r[i] = rv[i];
+                asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e0));
+                asm("v_max_f64 %0, %1, |%2|" : "=v"(mx) : "v"(mx), "v"(e1));
+                if (ps_record_bad(rv)) S.bad = gen;
             }
-            __syncthreads();
+            ordered_sums<2>(S, cnt, with_J, kind, off, ent, gen, acc);
+            cur = nxt;
         }
         if (with_J && t < 36) { A[ai * 8 + aj] = acc; A[aj * 8 + ai] = acc; }
         else if (with_J && t >= 36 && t < 44) v[t - 36] = acc;
-        else if (t == 44) { sc[with_J ? 0 : 1] = acc; if (with_J) sc[2] = mx; }
+        else if (t == 44) sc[with_J ? 0 : 1] = acc;
+        if (with_J) {
+            // |r|_inf over all points: per-thread maxima -> 16 partial maxima -> one
+            S.chunk[t] = mx;
+            __syncthreads();
+            if (t < 16) {
+                double m = 0;
+                for (int i = 0; i < TB / 16; i++) { const double o = S.chunk[t * (TB / 16) + i]; asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o)); }
+                S.chunk[TB + t] = m;
+            }
+            __syncthreads();
+            if (t == 0) {
+                double m = 0;
+                for (int i = 0; i < 16; i++) { const double o = S.chunk[TB + i]; asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o)); }
+                sc[2] = m;
+            }
+        }
         __syncthreads();
         PROF_ADD(2, pn);
 #ifdef MIS_TAIL_PROF
@@ -1264,6 +1480,9 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
         if (sc[3] != 0.) normal_eq(x, true);
         iter++;
         PROF_INC(3, 1);
+#ifdef MIS_TAIL_PROF
+        if (t == 0) S.prof_lm++;
+#endif
         double dmax = 0;
         for (int i = 0; i < 8; i++) { double a = fabs(d[i]); if (a > dmax) dmax = a; }
         bool proceed = iter < 10 && dmax >= (double)FLT_EPSILON && sc[2] >= (double)FLT_EPSILON;
@@ -1283,7 +1502,7 @@ __device__ void lm_refine_coop(TailShared& S, const float* s1, const float* d1, 
 #endif
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MIS_TAIL_WAVES, 8))) void scan_tail_kernel(const HomoCall* calls, RansacState* states, const double* Hc, const int* valid, const int* good,
                                                        float* scr_all, double* rec_all, HomoResult* results, int lo, int hi, int max_iters,
-                                                       double confidence, float thr, int* fin, int part, int want, int pcap) {
+                                                       double confidence, float thr, int* fin, int part, int want, int staged) {
 #if MIS_CHAIN_PRIO
     __builtin_amdgcn_s_setprio(MIS_CHAIN_PRIO);      // a latency-bound chain beside the composition's bandwidth-bound kernels: its few waves issue first
 #endif
@@ -1292,9 +1511,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MIS_TAIL_WAV
     if (part == 4 && want == 0 && threadIdx.x == 0) atomicMin(&g_tail_prof[8], wg_in);
 #endif
     __shared__ TailShared S;
-    extern __shared__ float4 tail_dyn[];
     __shared__ int s_done_now;
-    if (threadIdx.x == 0) { S.pts = tail_dyn; S.pcap = pcap; }
+    if (threadIdx.x == 0) { S.staged = staged; S.bad = 0; }
+    if (staged)
+        for (int i = threadIdx.x; i < 2 * PS_PTS; i += TB) tail_dyn[i * PS_PITCH + PS_TERMS] = 0.;      // (stage 1 follows stage 0 at PS_PTS * PS_PITCH)
     __syncthreads();
     __shared__ int wcnt[TB / 64];
     __shared__ int s_base;
@@ -1325,8 +1545,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MIS_TAIL_WAV
         // exactly four correspondences: runKernel directly, mask all ones, no refinement
         if (t == 0) for (int i = 0; i < 9; i++) S.best[i] = 0;
         __syncthreads();
-        tail_stage_points(S, c.src, c.dst, 4);
-        dlt_coop(S, c.src, c.dst, 4, rec);
+        dlt_coop(S, c.src, c.dst, 4, t < 4 ? tail_load_point(c.src, c.dst, t) : make_float4(0.f, 0.f, 0.f, 0.f), rec);
         const int ok = S.go;
         for (int i = t; c.mask && i < n; i += TB) c.mask[i] = ok ? 1 : 0;
         if (t == 0) { res->ok = ok; res->iters = 0; res->ninl = ok ? 4 : 0; if (ok) for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; st->done = 1; fin[b] = lo == 0 ? 0 : 1; }
@@ -1428,16 +1647,24 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MIS_TAIL_WAV
         return;
     }
     PROF_T0(pt);
+#ifdef MIS_TAIL_PROF
+    if (t == 0) { S.prof_rot = 0; S.prof_lm = 0; }
+#endif
     if (np > 0) {
-        tail_stage_points(S, s1, d1, np);
-        dlt_coop(S, s1, d1, np, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
+        // this thread's point of every pass's first chunk: loaded once (the compaction above wrote it: its stores are fenced by the loop's barriers)
+        const float4 pt0 = t < np ? tail_load_point(s1, d1, t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dlt_coop(S, s1, d1, np, pt0, rec);   // runKernel on all inliers (keeps the RANSAC model if degenerate)
         PROF_ADD(4, pt);
-        lm_refine_coop(S, s1, d1, np, rec);
+        lm_refine_coop(S, s1, d1, np, pt0, rec);
     }
     PROF_ADD(5, pt);
     PROF_INC(6, 1);
 #ifdef MIS_TAIL_PROF
     if (t == 0) atomicMax(&g_tail_prof[7], wall_clock64() - pt);
+    if (t == 0) {      // one line per tail: points, LM iterations, rotations, ticks, launch kind, entry tick
+        const unsigned k = atomicAdd(&g_tail_log_n, 1u);
+        if (k < 1024) { unsigned long long* e = g_tail_log + 6 * k; e[0] = np; e[1] = S.prof_lm; e[2] = S.prof_rot; e[3] = wall_clock64() - pt; e[4] = part * 10 + want; e[5] = pt; }
+    }
     if (part == 4 && want == 0 && t == 0) { const unsigned long long o = wall_clock64(); atomicMax(&g_tail_prof[9], o); atomicMax(&g_tail_prof[10], o - wg_in); atomicAdd(&g_tail_prof[11], 1ull); }
 #endif
     if (t == 0) { for (int i = 0; i < 9; i++) res->H[i] = S.best[i]; res->ninl = np; if (part == 4) st->tail_pending = 0; }
@@ -1500,6 +1727,15 @@ extern "C" int mis_debug_tail_prof(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[12] = {0}; z[8] = ~0ull; hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)); }
     return 0;
 }
+extern "C" int mis_debug_tail_log(unsigned long long* out, int cap, int reset) {      // -> entries copied (6 values each)
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tail_log_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > 1024) n = 1024;
+    if ((int)n > cap) n = cap;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_log), sizeof(unsigned long long) * 6 * n) != hipSuccess) return -1;
+    if (reset) { unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tail_log_n), &z, sizeof(z)) != hipSuccess) return -1; }
+    return (int)n;
+}
 extern "C" int mis_debug_draw_prof(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_draw_prof), sizeof(unsigned long long) * 12);
@@ -1559,9 +1795,11 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
     }
     RansacState* states = (RansacState*)b->state;
     const int p0 = std::min(PHASE0, max_iters);
-    // the launches that run a DLT / LM refinement (parts 0, 2, 4) stage the point set in dynamic LDS; replay-only and mask-only ones do not
-    auto tail_cap = [](int part) { return (part == 1 || part == 3) ? 0 : TAIL_PCAP; };
-    auto tail_lds = [&](int part) { return sizeof(float4) * (size_t)tail_cap(part); };
+    // the launches that run a DLT / LM refinement (parts 0, 2, 4) carry the term stages of ordered_sums in dynamic LDS; replay-only and mask-only ones do not
+    // (MIS_TAIL_PLAIN=1: none anywhere -- every ordered sum takes round 3's plain loop; the parity tests run both)
+    static const bool plain = getenv("MIS_TAIL_PLAIN") != nullptr && atoi(getenv("MIS_TAIL_PLAIN")) != 0;
+    auto tail_staged = [&](int part) { return (part == 1 || part == 3 || plain) ? 0 : 1; };
+    auto tail_lds = [&](int part) { return tail_staged(part) ? TAIL_DYN_LDS : (size_t)0; };
     if (phases == 0 || phases == 2 || phases == 3) {
         MIS_HIP(ctx, hipMemsetAsync(b->fin, 0xff, sizeof(int) * (size_t)b->count, st));
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 0, p0);
@@ -1570,15 +1808,15 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         if (sy.rec_hyp0) MIS_HIP(ctx, hipEventRecord(sy.rec_hyp0, st));
         hipLaunchKernelGGL(hyp_count_kernel, dim3((p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, 0, max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 3 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0, tail_cap(phases == 3 ? 1 : 0));
+                           max_iters, confidence, thr, b->fin, phases == 3 ? 1 : 0, 0, tail_staged(phases == 3 ? 1 : 0));
     }
     if (phases == 4)   // the tails a phases == 3 run left pending (fin == 0)
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(2), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, 2, 0, tail_cap(2));
+                           max_iters, confidence, thr, b->fin, 2, 0, tail_staged(2));
     if (phases >= 10) {   // 10 + 2 w: mask + compaction, 11 + 2 w: DLT + LM, of the problems a replay-only run left pending with fin == w
         const int want = (phases - 10) >> 1, part = 3 + ((phases - 10) & 1);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(part), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, 0, p0,
-                           max_iters, confidence, thr, b->fin, part, want, tail_cap(part));
+                           max_iters, confidence, thr, b->fin, part, want, tail_staged(part));
     }
     if ((phases == 1 || phases == 2 || phases == 6) && max_iters > p0) {
         hipLaunchKernelGGL(draw_kernel, dim3(b->count), dim3(DRAW_TB), 0, st, b->calls, states, b->sub_idx, b->draw_idx, rt.U, rt.state_T, max_iters, 1, max_iters);
@@ -1589,7 +1827,7 @@ int homo_batch_run(MisContext* ctx, HomoBatch* b, double thresh, int max_iters, 
         hipLaunchKernelGGL(hyp_count_kernel, dim3((max_iters - p0 + 3) / 4, b->count), dim3(256), 0, st, b->calls, states, (const double*)b->Hc, (const int*)b->valid, b->good, p0,
                            max_iters, thr);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(b->count), dim3(TB), tail_lds(phases == 6 ? 1 : 0), st, b->calls, states, b->Hc, b->valid, b->good, b->scr, b->rec, b->results, p0,
-                           max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0, tail_cap(phases == 6 ? 1 : 0));
+                           max_iters, max_iters, confidence, thr, b->fin, phases == 6 ? 1 : 0, 0, tail_staged(phases == 6 ? 1 : 0));
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

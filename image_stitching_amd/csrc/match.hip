@@ -732,7 +732,7 @@ struct MatchWorkspace : MisWorkspace {
     // "the 2-NN pass of matcher call number knn_seq has been enqueued, ev_knn marks its end" (mis_match_knn_fence)
     hipEvent_t ev_knn = nullptr;
     hipEvent_t ev_draw1 = nullptr, ev_side_hyp0 = nullptr, ev_b2_replay = nullptr;
-    hipEvent_t tev[8] = {nullptr};   // MIS_MATCH_TRACE: timing events (2-NN end, phase 0 end, draw 1 end, main chain end, side end, third end, tails of phase 0 end)
+    hipEvent_t tev[8] = {nullptr};   // MIS_MATCH_TRACE: timing events (2-NN end, phase 0 end, main chain's second RANSAC phase end, main chain end, side end, third end, tails of phase 0 end, side chain's first RANSAC phase end)
     hipEvent_t ev_gate = nullptr;    // what mis_match_knn_fence queues a stream behind: ev_knn, or the end of the first RANSAC phase (MIS_COMPOSE_GATE)
     std::atomic<long long> seq{0}, knn_seq{0};
     hipEvent_t ev_lists = nullptr;                       // the early download of the match lists has landed
@@ -1030,6 +1030,7 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
     }
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
     MIS_HIP(ctx, hipEventRecord(ws->ev_phase1, st));
+    mark(2, st);
     // the refinement of the phase-1 finishers' first H stays on this stream (1.7 ms of latency-bound work: behind the 2 ms
     // refinement of the phase-0 finishers on the third stream it ended the matcher 0.6 ms later); their inlier-only second
     // estimation goes to the third stream instead
@@ -1182,7 +1183,9 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             float e1 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0;
             hipEventElapsedTime(&e1, ws->tev[0], ws->tev[1]); hipEventElapsedTime(&e3, ws->tev[0], ws->tev[3]); hipEventElapsedTime(&e4, ws->tev[0], ws->tev[4]);
             hipEventElapsedTime(&e5, ws->tev[0], ws->tev[5]); hipEventElapsedTime(&e6, ws->tev[0], ws->tev[6]);
-            fprintf(stderr, "match chains, ms after the 2-NN pass was enqueued-behind (device events): first phase done %.2f | tails of its finishers done %.2f | main chain done %.2f | side chain done %.2f | third chain done %.2f\n", e1, e6, e3, e4, e5);
+            float e2 = 0;
+            if (ws->tev[2]) hipEventElapsedTime(&e2, ws->tev[0], ws->tev[2]);
+            fprintf(stderr, "match chains, ms after the 2-NN pass was enqueued-behind (device events): first phase done %.2f | tails of its finishers done %.2f | main chain: second RANSAC phase done %.2f, done %.2f | side chain done %.2f | third chain done %.2f\n", e1, e6, e2, e3, e4, e5);
         }
     }
     return MIS_OK;

@@ -299,6 +299,31 @@ def test_three_chain_matcher_flow_gives_identical_results(tmp_path):
     assert ran >= 10      # adjacent frames do have inliers: the second estimation was exercised
 
 
+def test_pipelined_ordered_sums_equal_the_plain_loop(tmp_path):
+    """The DLT / LM passes of the tails add their terms through ordered_sums (producer waves form the terms, one wave adds them in
+    point order, structurally-zero terms are not formed; homography.hip) -- MIS_TAIL_PLAIN=1 sends every sum through the plain loop
+    that forms all 90 products per point instead (the path a chunk with a non-finite record takes).  Six 4K frames: every pair's
+    confidence, inlier count, mask and H bit for bit; the default flow itself is checked against the oracle by the tests above."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for plain in ("0", "1"):
+        path = str(tmp_path / ("plain%s.npz" % plain))
+        env = dict(os.environ, MIS_TAIL_PLAIN=plain)
+        r = subprocess.run([sys.executable, "-c", _CHAINS3_SCRIPT, root, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(path))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 4 * 36
+    ran = 0
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+        ran += k.startswith("n") and int(a[k]) > 200      # (tails with hundreds of inliers: several 256-point chunks per pass)
+    assert ran >= 5
+
+
 def test_enqueue_hook_runs_once_inside_the_next_call(ctx, oracle_mod):
     """mis_match_on_enqueued: the hook runs on the calling thread of the next matcher call (after its work is enqueued), once;
     a cleared hook does not run; the matches are those of a call without a hook."""

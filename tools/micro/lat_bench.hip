@@ -237,10 +237,66 @@ __global__ void k_rescan2(Stamp* st, double* out, double x, int n) {     // four
     END(acc)
 }
 
-template <typename K> void run(const char* name, K kern, int n, int blocks) {
+// round 4: the accumulating wave of homography.hip's ordered_sums -- one 16-byte slot per point (pitch 45 slots), two dependent adds
+__global__ void k_accum(Stamp* st, double* out, double x, int n) {
+    __shared__ double2 P[16 * 45];
+    for (int i = threadIdx.x; i < 16 * 45; i += blockDim.x) P[i] = make_double2(x * 1e-9 + i * 1e-12, x * 1e-9 - i * 1e-12);
+    __syncthreads();
+    double acc = x;
+    const double2* p = P + (threadIdx.x % 45);
+    BEGIN
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int u0 = 0; u0 < 16; u0 += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p[(u0 + u) * 45];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; }
+        }
+        asm volatile("" ::: "memory");
+    }
+    END(acc)
+}
+__global__ void k_add(Stamp* st, double* out, double x, int n) {
+    double a = x + threadIdx.x;
+    BEGIN
+    for (int i = 0; i < n; i++) { a += 0.5; a += 0.25; a += 0.125; a += 0.0625; }
+    END(a)
+}
+__global__ void k_addf(Stamp* st, double* out, double x, int n) {
+    float a = (float)x + threadIdx.x;
+    BEGIN
+    for (int i = 0; i < n; i++) { a += 0.5f; a += 0.25f; a += 0.125f; a += 0.0625f; }
+    END((double)a)
+}
+
+// throughput of independent f64 operations on one wave: 8 chains
+template <int OP> __global__ void k_tput(Stamp* st, double* out, double x, int n) {
+    double a[8];
+    for (int i = 0; i < 8; i++) a[i] = x + threadIdx.x + i;
+    BEGIN
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (OP == 0) a[j] = a[j] + 0.5;
+            else if (OP == 1) a[j] = a[j] * 0.999;
+            else a[j] = __builtin_fma(a[j], 0.999, 0.5);
+        }
+    }
+    END(a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+}
+__global__ void k_mul_dep(Stamp* st, double* out, double x, int n) {
+    double a = x + threadIdx.x;
+    BEGIN
+    for (int i = 0; i < n; i++) { a *= 0.999; a *= 1.001; a *= 0.999; a *= 1.001; }
+    END(a)
+}
+
+template <typename K> void run(const char* name, K kern, int n, int blocks, int threads = 64) {
     Stamp* st; double* out;
-    hipMalloc(&st, sizeof(Stamp)); hipMalloc(&out, 8 * 64);
-    for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, st, out, 1.5, n); hipDeviceSynchronize(); }
+    hipMalloc(&st, sizeof(Stamp)); hipMalloc(&out, 8 * 1024);
+    for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, st, out, 1.5, n); hipDeviceSynchronize(); }
     Stamp h; hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost);
     const double cyc = double(h.c1 - h.c0), us = double(h.r1 - h.r0) * 0.01;
     printf("%-26s blocks %4d  n %6d: %8.1f cycles / iteration  %8.4f us / iteration  (counter %.0f MHz)\n", name, blocks, n, cyc / n, us / n, cyc / us);
@@ -249,6 +305,17 @@ template <typename K> void run(const char* name, K kern, int n, int blocks) {
 int main() {
     for (int blocks : {1, 120}) {
         run("dependent f64 fma", k_fma, 4000, blocks);
+        run("4 dependent f64 adds", k_add, 4000, blocks);
+        run("4 dependent f32 adds", k_addf, 4000, blocks);
+        run("accumulate 16 slots", k_accum, 1000, blocks);
+        run("4 dependent f64 muls", k_mul_dep, 4000, blocks);
+        run("8 independent f64 adds", k_tput<0>, 4000, blocks);
+        run("8 independent f64 muls", k_tput<1>, 4000, blocks);
+        run("8 independent f64 fmas", k_tput<2>, 4000, blocks);
+        run("... f64 muls, 2 waves / block", k_tput<1>, 4000, blocks, 128);
+        run("... f64 muls, 4 waves / block", k_tput<1>, 4000, blocks, 256);
+        run("... f64 muls, 8 waves / block", k_tput<1>, 4000, blocks, 512);
+        run("... f64 adds, 4 waves / block", k_tput<0>, 4000, blocks, 256);
         run("f64 div (generic) + add", k_div, 1000, blocks);
         run("f64 div (lean) + add", k_divlean, 1000, blocks);
         run("f64 sqrt (generic) + add", k_sqrt, 1000, blocks);

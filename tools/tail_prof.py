@@ -19,7 +19,11 @@ hp = (C.c_ulonglong * 8)()
 dp = (C.c_ulonglong * 12)()
 ctx.lib.mis_debug_hyp_prof(hp, 1)
 ctx.lib.mis_debug_draw_prof(dp, 1)
+tl = (C.c_ulonglong * (6 * 1024))()
+ctx.lib.mis_debug_tail_log(tl, 1024, 1)
 step()
+torch.cuda.synchronize()
+ntl = ctx.lib.mis_debug_tail_log(tl, 1024, 1)
 ctx.lib.mis_debug_draw_prof(dp, 1)
 dd = list(dp)
 if dd[11]:
@@ -47,6 +51,19 @@ j = list(jp)
 rot = max(v[1], 1)
 if j[7]:
     print("normal equations: %d passes over %.0f points on average: %.2f us per pass, %.1f ns per point" % (j[7], j[6] / j[7], v[2] * tick / j[7], 1e3 * v[2] * tick / max(j[6], 1)))
-if j[5]:      # library built with -DMIS_JAC_PROF as well (the fine timers serialise the rotation: totals above are then inflated)
+ps = j[3] and not j[2] == 0 and j[4]
+if ps:      # ordered_sums (round 4): shader cycles of its stages ([4], [5]: time at the stage barrier of the accumulating / a producing wave)
+    print("ordered_sums: %d stages of 16 points: accumulating lane %.0f cycles / stage (+ %.0f at the barrier), a producing lane %.0f (+ %.0f), the whole loop %.0f" % (j[3], j[0] / j[3], j[4] / j[3], j[1] / j[3], j[5] / j[3], j[2] / j[3]))
+if j[5] and not ps:      # library built with -DMIS_JAC_PROF as well (the fine timers serialise the rotation: totals above are then inflated)
     print("jacobi calls %d (%.1f rotations each): set-up %.0f cycles / call, eigenvalue sort %.0f cycles / call" % (j[5], rot / j[5], j[0] / j[5], j[4] / j[5]))
     print("per rotation (shader cycles): loads + arithmetic %.0f  rotation + re-scans %.0f  pivot %.0f  sum %.0f" % (j[1] / rot, j[2] / rot, j[3] / rot, sum(j[1:4]) / rot))
+
+# one line per tail (g_tail_log), grouped by launch kind (part * 10 + want), longest first
+ent = [tuple(tl[6 * i + k] for k in range(6)) for i in range(max(ntl, 0))]
+if ent:
+    t_first = min(e[5] for e in ent)
+    for kind in sorted(set(e[4] for e in ent)):
+        grp = sorted((e for e in ent if e[4] == kind), key=lambda e: -e[3])
+        print("launch kind %d: %d tails, entered %.0f .. %.0f us after the first; longest first (points, LM iterations, rotations, us):" % (kind, len(grp), (min(e[5] for e in grp) - t_first) * tick, (max(e[5] for e in grp) - t_first) * tick))
+        print("   " + "  ".join("(%d, %d, %d, %.0f)" % (e[0], e[1], e[2], e[3] * tick) for e in grp[:12]))
+        print("   ... median %.0f us, shortest %.0f us" % (grp[len(grp) // 2][3] * tick, grp[-1][3] * tick))
