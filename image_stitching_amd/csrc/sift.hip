@@ -188,6 +188,32 @@ __global__ __launch_bounds__(256) void sift_blur_cols_kernel(const float* __rest
 // separate passes (and the CPU path): the results are the same bits.  Vertically a strip costs N - 1 extra input rows per
 // segment; the next chunk's global loads are in flight while the current one is filtered.
 constexpr int FB_TW = 256, FB_CH = 8;
+typedef float fb_v2f __attribute__((ext_vector_type(2)));
+// Eight consecutive outputs of an N-tap filter from the N + 7 inputs in(0) .. in(N + 6): out[j] = sum_k tap[k] in(j + k), every sum
+// `acc = 0; acc += tap[k] * v` over ascending k.  Outputs 2i and 2i + 1 share the inputs 2i + 1 .. 2i + N - 1 with taps one apart:
+// those N - 1 steps are one packed multiply and one packed add for the pair (v_pk_mul_f32 / v_pk_add_f32: the full f32 rate of a
+// SIMD needs packed operations -- as separate v_mul / v_add the passes held the vector unit for half of the kernel's time,
+// tools/pmc_sift.sh); output 2i's first term and output 2i + 1's last one are scalar.  The additions of every output are the same,
+// in the same order.
+template <int N, typename In>
+__device__ __forceinline__ void fb_filter8(const float (&tk)[N], In in, float (&out)[8]) {
+    fb_v2f a2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) a2[i] = fb_v2f{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < N + 7; k++) {
+        const float v = in(k);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int d = k - 2 * i;
+            if (d == 0) a2[i].x += tk[0] * v;
+            else if (d >= 1 && d <= N - 1) a2[i] += fb_v2f{tk[d], tk[d - 1]} * fb_v2f{v, v};
+            else if (d == N) a2[i].y += tk[N - 1] * v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { out[2 * i] = a2[i].x; out[2 * i + 1] = a2[i].y; }
+}
 template <int N>
 __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int w, int h, int seg, Taps t) {
     constexpr int R = N / 2, RB = N + FB_CH - 1, SPAN = FB_TW + N - 1;
@@ -208,25 +234,35 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
     float pa[FB_CH], pb[FB_CH], ctr[FB_CH];      // the next chunk's inputs and the DoG's subtrahends of its outputs, in flight during the passes
     auto load_chunk = [&](int c) {
         const int yb = y0 - R + FB_CH * c;
-        const bool yin = yb >= 0 && yb + FB_CH - 1 < h;
+        if (yb >= 0 && yb + FB_CH - 1 < h) {      // (one uniform branch per chunk: the reflected rows' index arithmetic stays out of the common path)
+            const float* ra = src + (size_t)yb * w;
 #pragma unroll
-        for (int j = 0; j < FB_CH; j++) {
-            const size_t ro = (size_t)(yin ? yb + j : mis_reflect101(yb + j, h)) * w;
-            pa[j] = src[ro + xa];
-            pb[j] = tid < N - 1 ? src[ro + xb] : 0.f;
+            for (int j = 0; j < FB_CH; j++) { pa[j] = ra[(size_t)j * w + xa]; pb[j] = tid < N - 1 ? ra[(size_t)j * w + xb] : 0.f; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FB_CH; j++) {
+                const size_t ro = (size_t)mis_reflect101(yb + j, h) * w;
+                pa[j] = src[ro + xa];
+                pb[j] = tid < N - 1 ? src[ro + xb] : 0.f;
+            }
         }
         if (dog) {
             const int m0 = FB_CH * c + 1 - N;
+            if (m0 >= 0 && m0 + FB_CH - 1 < rows_out) {
+                const float* rc = src + (size_t)(y0 + m0) * w + xc;
 #pragma unroll
-            for (int j = 0; j < FB_CH; j++) { const int m = min(max(m0 + j, 0), rows_out - 1); ctr[j] = src[(size_t)(y0 + m) * w + xc]; }
+                for (int j = 0; j < FB_CH; j++) ctr[j] = rc[(size_t)j * w];
+            } else {
+#pragma unroll
+                for (int j = 0; j < FB_CH; j++) { const int m = min(max(m0 + j, 0), rows_out - 1); ctr[j] = src[(size_t)(y0 + m) * w + xc]; }
+            }
         }
     };
     load_chunk(0);
     const int rj = tid >> 5, rx = tid & 31;       // row pass: row of the chunk, block of 8 columns
     for (int c = 0; c < nchunks; c++) {
         mis_lds_barrier();     // the previous chunk's passes are done with the staged rows and the ring's oldest rows (LDS-only barriers: the
-                               // next chunk's loads and this chunk's stores stay in flight across them -- with __syncthreads() every barrier
-                               // waited for them, and a workgroup had loads in flight for a third of its time: 1.1 - 1.8 TB/s)
+                               // next chunk's loads and this chunk's stores stay in flight across them)
 #pragma unroll
         for (int j = 0; j < FB_CH; j++) {
             stage[j * SPITCH + tid + (tid >> 3)] = pa[j];
@@ -239,16 +275,8 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
         if (c + 1 < nchunks) load_chunk(c + 1);
         {   // row pass: filtered row q = FB_CH * c + rj (relative to y0 - R) into its ring slot
             float acc[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) acc[jj] = 0.f;
             const float* my = stage + rj * SPITCH + 9 * rx;
-#pragma unroll
-            for (int k = 0; k < N + 7; k++) {
-                const float v = my[k + (k >> 3)];
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++)
-                    if (k - jj >= 0 && k - jj < N) acc[jj] += tk[k - jj] * v;
-            }
+            fb_filter8<N>(tk, [&](int k) { return my[k + (k >> 3)]; }, acc);
             float* o = ring + ((FB_CH * c + rj) % RB) * RPITCH + 9 * rx;
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) o[jj] = acc[jj];
@@ -258,18 +286,10 @@ __global__ __launch_bounds__(256) void sift_blur_fused_kernel(const float* __res
         const int m0 = FB_CH * c + 1 - N;       // the newest complete output row is FB_CH * c + FB_CH - N: the eight rows that end there
         if (m0 + 7 >= 0 && m0 < rows_out) {
             float acc[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) acc[jj] = 0.f;
-            int slot = ((m0 % RB) + RB) % RB;
+            const int slot0 = ((m0 % RB) + RB) % RB;
             const int col = tid + (tid >> 3);
-#pragma unroll
-            for (int k = 0; k < N + 7; k++) {
-                const float v = m0 + k >= 0 ? ring[slot * RPITCH + col] : 0.f;      // rows above the segment's first input row only meet outputs that are not emitted
-                slot = slot + 1 == RB ? 0 : slot + 1;
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++)
-                    if (k - jj >= 0 && k - jj < N) acc[jj] += tk[k - jj] * v;
-            }
+            // rows above the segment's first input row only meet outputs that are not emitted
+            fb_filter8<N>(tk, [&](int k) { const int sl = slot0 + k < RB ? slot0 + k : slot0 + k - RB; return m0 + k >= 0 ? ring[sl * RPITCH + col] : 0.f; }, acc);
             if (x < w) {
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
@@ -510,15 +530,21 @@ __global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, co
 }
 
 // calcSIFTDescriptor: one wave per keypoint.  The float sums into the (d+2)(d+2)(n+2) histogram are order
-// dependent, so the CPU's order is kept: samples are evaluated 64 at a time in raster order (one per lane: gradient,
-// exp weight, atan2, trilinear split), compacted in that order, and then lanes 0..7 -- one per trilinear corner --
-// walk the compacted samples sequentially.  The 8 corners of one sample are 8 distinct bins, and a wave's LDS
-// operations execute in program order, so every bin receives its contributions in sample order.
+// dependent, so the CPU's order is kept: the samples of the (2 radius + 1)^2 window are visited 64 at a time in raster order, and
+// the ones that fall into the rotated 4 x 4 grid (about a third) are queued in that order; whenever 64 are queued, one lane each
+// evaluates them (gradient, exp weight, atan2, trilinear split -- the expensive part now runs on full waves; evaluated in place
+// it ran with a third of its lanes, and the window index was a 64-bit division per sample) and then their contributions are added
+// one sample after the other.  The histogram lives in REGISTERS during that walk: lane L < 36 owns the spatial cell (L / 6, L % 6)
+// and its ten orientation slots; a sample touches 2 x 2 cells x 2 neighbouring slots, its first slot o0 is the same for all
+// lanes (a scalar switch picks the two registers), and the lanes of the four cells each read their pair of values.  Every bin
+// still receives its contributions in sample order.  (As read-modify-writes of an LDS histogram -- plain, or ds_add_f32 atomics
+// -- the walk kept the CU's one LDS pipeline busy for 88 % of the kernel: 8 lane-operations per sample at ~8 cycles each.)
 constexpr int HISTLEN = 6 * 6 * 10;
 __global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKeyPoint* __restrict__ kps, const unsigned* __restrict__ nk, float* __restrict__ desc) {
     __shared__ float hist[HISTLEN];
-    __shared__ int s_idx[64];
-    __shared__ float s_val[64 * 8];
+    __shared__ int q_ij[128];          // ring of queued samples: (i << 16) | (j & 0xffff)
+    __shared__ __attribute__((aligned(16))) int s_idx[64];
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 8 + 4];
     const int q = blockIdx.x, lane = threadIdx.x;
     if ((unsigned)q >= *nk) return;    // the grid covers the raw keypoints; duplicates were removed on the device
     const int d = 4, n = 8, nl = P.nl, firstOctave = -1;
@@ -539,83 +565,156 @@ __global__ __launch_bounds__(64) void sift_descriptor_kernel(Pyr P, const MisKey
     const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = SIFT_DESCR_SCL_FCTR * scl;
     int radius = mis_round_f(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
     const int rmax = (int)sqrt((double)w * w + (double)h * h);
-    if (radius > rmax) radius = rmax;
+    if (radius > rmax) radius = rmax;      // (< 2^15 for every image this library accepts: i and j fit 16 bits)
     cos_t /= hist_width; sin_t /= hist_width;
     for (int e = lane; e < HISTLEN; e += 64) hist[e] = 0.f;
     __syncthreads();
     const int side = 2 * radius + 1;
     const long long total = (long long)side * side;
-    // offsets of the 8 trilinear corners from the base bin: (r, c, o) in {0,1}^3, o fastest
-    const int corner_off = ((lane >> 2) & 1) * (d + 2) * (n + 2) + ((lane >> 1) & 1) * (n + 2) + (lane & 1);
-    volatile float* vh = hist;
-    for (long long base = 0; base < total; base += 64) {
-        const long long kk = base + lane;
-        bool valid = false;
-        int idx = 0;
-        float v[8];
-        if (kk < total) {
-            const int i = (int)(kk / side) - radius, j = (int)(kk % side) - radius;
+    // lane L < 36 is cell (L / 6, L % 6) of the (d + 2) x (d + 2) grid (lanes >= 36: none)
+    typedef float desc_v16 __attribute__((ext_vector_type(16)));
+    desc_v16 hv = 0.f;      // its orientation slots (0 .. 8 are used; the tenth stays zero)
+    // the first `take` queued samples (from ring position qh): evaluate, then accumulate in order
+    auto drain = [&](int qh, int take) __attribute__((always_inline)) {
+        if (lane < take) {
+            const int e = q_ij[(qh + lane) & 127];
+            const int i = e >> 16, j = (int)(short)(e & 0xffff);
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
-                valid = true;
-                const float dx = AT(img, r, c + 1) - AT(img, r, c - 1), dy = AT(img, r - 1, c) - AT(img, r + 1, c);
-                const float wgt = mis_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-                float obin = (mis_fast_atan2(dy, dx) - ori) * bins_per_rad;
-                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-                const int r0 = mis_floor_f(rbin), c0 = mis_floor_f(cbin);
-                int o0 = mis_floor_f(obin);
-                rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7]; v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
-                v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3]; v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
-                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            }
+            const float dx = AT(img, r, c + 1) - AT(img, r, c - 1), dy = AT(img, r - 1, c) - AT(img, r + 1, c);
+            const float wgt = mis_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (mis_fast_atan2(dy, dx) - ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const int r0 = mis_floor_f(rbin), c0 = mis_floor_f(cbin);
+            int o0 = mis_floor_f(obin);
+            rbin -= r0; cbin -= c0; obin -= o0;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            float v[8];
+            v[7] = v_rc11 * obin; v[6] = v_rc11 - v[7]; v[5] = v_rc10 * obin; v[4] = v_rc10 - v[5];
+            v[3] = v_rc01 * obin; v[2] = v_rc01 - v[3]; v[1] = v_rc00 * obin; v[0] = v_rc00 - v[1];
+            s_idx[lane] = ((r0 + 1) << 8) | ((c0 + 1) << 4) | o0;      // first cell (row, column) and first orientation slot
+#pragma unroll
+            for (int c8 = 0; c8 < 8; c8++) s_val[lane * 8 + c8] = v[c8];
+        }
+        __syncthreads();
+        // (e is the sample's packed {row, column, slot}: the same in every lane; v: this lane's pair of values, if its cell is one of the
+        // four.  The slots are one vector-typed value indexed by a wave-uniform number: register-relative moves; as a private array, or
+        // as named scalars behind a switch -- which the compiler turns back into an array --, the histogram went to scratch memory)
+        // (the sample's first cell as a lane number, Lb = 6 row + column, is a scalar: the four cells are lanes Lb + {0, 1, 6, 7})
+#define MIS_DESC_LB(e) (((e) >> 8) * (d + 2) + (((e) >> 4) & 15))
+#define MIS_DESC_ADD(e, v)                                                                          \
+        do {                                                                                        \
+            const unsigned dd_ = (unsigned)(lane - MIS_DESC_LB(e));                                 \
+            if (dd_ < 8u && ((0xC3u >> dd_) & 1u)) {                                                \
+                const int o_ = (e) & 15;                                                            \
+                hv[o_] += (v).x;                                                                    \
+                hv[o_ + 1] += (v).y;                                                                \
+            }                                                                                       \
+        } while (0)
+        // this lane's two values of sample sI (corner (dr, dc): values 4 dr + 2 dc, + 1); anything in range for the other lanes
+#define MIS_DESC_PAIR(sI_, e) (*reinterpret_cast<const float2*>(s_val + (sI_) * 8 + 2 * (((lane - MIS_DESC_LB(e)) & 1) | (((lane - MIS_DESC_LB(e)) >> 1) & 2))))
+        int sI = 0;
+#pragma unroll 1
+        for (; sI + 4 <= take; sI += 4) {      // four samples' reads in flight
+            const int4 e4v = *reinterpret_cast<const int4*>(s_idx + sI);
+            int4 e4;      // the same in every lane: scalars
+            e4.x = __builtin_amdgcn_readfirstlane(e4v.x); e4.y = __builtin_amdgcn_readfirstlane(e4v.y);
+            e4.z = __builtin_amdgcn_readfirstlane(e4v.z); e4.w = __builtin_amdgcn_readfirstlane(e4v.w);
+            const float2 v0 = MIS_DESC_PAIR(sI, e4.x), v1 = MIS_DESC_PAIR(sI + 1, e4.y), v2 = MIS_DESC_PAIR(sI + 2, e4.z), v3 = MIS_DESC_PAIR(sI + 3, e4.w);
+            MIS_DESC_ADD(e4.x, v0); MIS_DESC_ADD(e4.y, v1); MIS_DESC_ADD(e4.z, v2); MIS_DESC_ADD(e4.w, v3);
+        }
+        for (; sI < take; sI++) {
+            const int e = __builtin_amdgcn_readfirstlane(s_idx[sI]);
+            const float2 v = MIS_DESC_PAIR(sI, e);
+            MIS_DESC_ADD(e, v);
+        }
+        __syncthreads();
+    };
+    // lane's window position (i, j) = (kk / side - radius, kk % side - radius) of kk = base + lane, advanced by 64 per trip
+    int wi = lane / side, wj = lane % side;
+    const int adv_i = 64 / side, adv_j = 64 % side;
+    int qh = 0, qn = 0;      // ring head, queued samples (wave-uniform)
+    for (long long base = 0; base < total; base += 64) {
+        bool valid = false;
+        const int i = wi - radius, j = wj - radius;
+        if (wi < side) {
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            valid = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
         }
         const unsigned long long bal = __ballot(valid);
-        const int slot = __popcll(bal & ((1ull << lane) - 1ull)), cnt = __popcll(bal);
-        if (valid) {
-            s_idx[slot] = idx;
-#pragma unroll
-            for (int c8 = 0; c8 < 8; c8++) s_val[slot * 8 + c8] = v[c8];
+        if (valid) q_ij[(qh + qn + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = (i << 16) | (j & 0xffff);
+        qn += __popcll(bal);
+        wi += adv_i; wj += adv_j;
+        if (wj >= side) { wj -= side; wi++; }
+        if (qn >= 64) {
+            __syncthreads();
+            drain(qh, 64);
+            qh = (qh + 64) & 127; qn -= 64;
         }
-        __syncthreads();
-        if (lane < 8) {
-            for (int sI = 0; sI < cnt; sI++) {
-                const int b = s_idx[sI] + corner_off;
-                vh[b] = vh[b] + s_val[sI * 8 + lane];
-            }
-        }
-        __syncthreads();
     }
-    if (lane == 0) {
-        float* dst = desc + 128 * (size_t)q;
-        float nrm2 = 0;
-        for (int i = 0; i < d; i++)
-            for (int j = 0; j < d; j++) {
-                const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-                hist[idx] += hist[idx + n];
-                hist[idx + 1] += hist[idx + n + 1];
-                for (int kk = 0; kk < n; kk++) { const float v = hist[idx + kk]; dst[(i * d + j) * n + kk] = v; nrm2 += v * v; }
+    __syncthreads();
+    if (qn > 0) drain(qh, qn);
+    if (lane < (d + 2) * (d + 2)) {
+        float* o = hist + lane * (n + 2);
+#pragma unroll
+        for (int k8 = 0; k8 < n + 1; k8++) o[k8] = hv[k8];
+        o[n + 1] = 0.f;
+    }
+    __syncthreads();
+    // The histogram -> descriptor epilogue.  One lane used to do all of it THROUGH the output row in global memory (written, read back
+    // for the threshold pass, written, read back for the scaling: ~400 dependent global round trips per keypoint -- most of the
+    // kernel's 1.9 ms per 8K frame).  Now: the circular bins folded by 16 lanes, element e = (i d + j) n + k handled by lane e & 63,
+    // and only the two sums of squares -- whose order the result depends on -- are walked by one lane, from LDS.
+    if (lane < d * d) {
+        const int idx = ((lane / d + 1) * (d + 2) + (lane % d + 1)) * (n + 2);
+        hist[idx] += hist[idx + n];
+        hist[idx + 1] += hist[idx + n + 1];
+    }
+    __syncthreads();
+    float val[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = lane + 64 * u;
+        val[u] = hist[((e >> 5) + 1) * (d + 2) * (n + 2) + (((e >> 3) & 3) + 1) * (n + 2) + (e & 7)];
+        s_val[e] = val[u] * val[u];
+    }
+    auto ordered_sum128 = [&]() {      // sum of s_val[0 .. 127] in index order, by lane 0; every lane returns it
+        __syncthreads();
+        if (lane == 0) {
+            float acc = 0;
+#pragma unroll 1
+            for (int e = 0; e < 128; e += 8) {
+                float t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = s_val[e + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += t8[u];
             }
-        const int len = d * d * n;
-        const float thr = sqrtf(nrm2) * SIFT_DESCR_MAG_THR;
-        nrm2 = 0;
-        for (int kk = 0; kk < len; kk++) {
-            const float val = dst[kk] < thr ? dst[kk] : thr;
-            dst[kk] = val;
-            nrm2 += val * val;
+            s_val[128] = acc;
         }
-        const float root = sqrtf(nrm2);
-        nrm2 = SIFT_INT_DESCR_FCTR / (root > FLT_EPSILON ? root : FLT_EPSILON);
-        for (int kk = 0; kk < len; kk++) {
-            const int v = mis_round_f(dst[kk] * nrm2);   // saturate_cast<uchar>
-            dst[kk] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
-        }
+        __syncthreads();
+        return s_val[128];
+    };
+    const float thr = sqrtf(ordered_sum128()) * SIFT_DESCR_MAG_THR;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        val[u] = val[u] < thr ? val[u] : thr;
+        s_val[lane + 64 * u] = val[u] * val[u];
+    }
+    const float root = sqrtf(ordered_sum128());
+    const float fct = SIFT_INT_DESCR_FCTR / (root > FLT_EPSILON ? root : FLT_EPSILON);
+    float* dst = desc + 128 * (size_t)q;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int v = mis_round_f(val[u] * fct);   // saturate_cast<uchar>
+        dst[lane + 64 * u] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
 }
 
@@ -819,8 +918,10 @@ static void blur(MisSift* s, const float* src, float* dst, int w, int h, double 
     // the tap counts of SIFT::create()'s sigmas run fused (one read, two writes per layer); `prev` is always the source there.
     // Segments: long enough that the N - 1 extra input rows stay a small share, short enough that a layer is >= ~1500 workgroups
     const int nsx = (w + FB_TW - 1) / FB_TW;
+    // (small layers are bound by the serial walk of a segment, not by its N - 1 extra rows: short segments there)
+    static const int seg_min = getenv("MIS_SIFT_SEG_MIN") ? atoi(getenv("MIS_SIFT_SEG_MIN")) : 16;
     int seg = (h * nsx + 1499) / 1500;
-    seg = std::min(256, std::max(64, (seg + 7) & ~7));
+    seg = std::min(256, std::max(seg_min, (seg + 7) & ~7));
     const dim3 gfused(nsx, (h + seg - 1) / seg);
     const bool fused_ok = (prev == nullptr || prev == src) && (dog != nullptr) == (prev != nullptr);
 #define MIS_BLUR_CASE(NN)                                                                                                                        \
