@@ -418,7 +418,9 @@ struct SiftConsts {
 };
 
 // adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema: one thread per candidate
-__device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd, MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
+// adjustLocalExtrema of one candidate (a thread): false = rejected; otherwise the keypoint without its orientation, and where it sits
+struct SiftSurv { MisKeyPoint kpt; int octv, layer, r, c; };
+__device__ bool sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd, SiftSurv* out) {
     const int octv = cd.x, nl = P.nl, w = P.w[octv], h = P.h[octv];
     int layer = cd.y, r = cd.z, c = cd.w;
     const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
@@ -442,11 +444,11 @@ __device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd
         solve3(H, dD, X);
         xi = -X[2]; xr = -X[1]; xc = -X[0];
         if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
-        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return false;
         c += mis_round_f(xc); r += mis_round_f(xr); layer += mis_round_f(xi);
-        if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= w - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
+        if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= w - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return false;
     }
-    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    if (i >= SIFT_MAX_INTERP_STEPS) return false;
     {
         const float* img = P.dog[octv * (nl + 2) + layer];
         const float* prev = P.dog[octv * (nl + 2) + layer - 1];
@@ -455,13 +457,13 @@ __device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
         const float t = (dD[0] * xc + dD[1] * xr) + dD[2] * xi;
         contr = AT(img, r, c) * img_scale + t * 0.5f;
-        if (fabsf(contr) * nl < K.contrast_threshold) return;
+        if (fabsf(contr) * nl < K.contrast_threshold) return false;
         const float v2 = AT(img, r, c) * 2.f;
         const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
         const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
         const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
         const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy, et = K.edge_threshold;
-        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) return;
+        if (det <= 0 || tr * tr * et >= (et + 1) * (et + 1) * det) return false;
     }
     MisKeyPoint kpt;
     kpt.x = (c + xc) * (1 << octv);
@@ -470,63 +472,104 @@ __device__ void sift_refine_one(const Pyr& P, const SiftConsts& K, const int4 cd
     kpt.size = K.sigma * mis_expf(((layer + xi) / nl) * 0.69314718055994530942f) * (1 << octv) * 2;
     kpt.response = fabsf(contr);
     kpt.angle = 0;
-    // ---- calcOrientationHist on the Gaussian image of the refined layer ----
-    const float scl_octv = kpt.size * 0.5f / (1 << octv);
-    const int radius = mis_round_f(SIFT_ORI_RADIUS * scl_octv), n = SIFT_ORI_HIST_BINS;
-    const float sigma_o = SIFT_ORI_SIG_FCTR * scl_octv, expf_scale = -1.f / (2.f * sigma_o * sigma_o);
-    const float* gimg = P.gauss[octv * (nl + 3) + layer];
-    float temphist[SIFT_ORI_HIST_BINS + 4];
-    float* th = temphist + 2;
-    for (int j = 0; j < n + 4; j++) temphist[j] = 0.f;
-    for (int di = -radius; di <= radius; di++) {
-        const int y = r + di;
-        if (y <= 0 || y >= h - 1) continue;
-        for (int dj = -radius; dj <= radius; dj++) {
-            const int x = c + dj;
-            if (x <= 0 || x >= w - 1) continue;
-            const float dx = AT(gimg, y, x + 1) - AT(gimg, y, x - 1), dy = AT(gimg, y - 1, x) - AT(gimg, y + 1, x);
-            const float wgt = mis_expf((di * di + dj * dj) * expf_scale);
-            const float ori = mis_fast_atan2(dy, dx), mag = sqrtf(dx * dx + dy * dy);
-            int bin = mis_round_f((n / 360.f) * ori);
-            if (bin >= n) bin -= n;
-            if (bin < 0) bin += n;
-            th[bin] += wgt * mag;
-        }
-    }
-    th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
-    float hist[SIFT_ORI_HIST_BINS];
-    for (int j = 0; j < n; j++) hist[j] = (th[j - 2] + th[j + 2]) * (1.f / 16.f) + (th[j - 1] + th[j + 1]) * (4.f / 16.f) + th[j] * (6.f / 16.f);
-    float omax = hist[0];
-    for (int j = 1; j < n; j++) omax = omax > hist[j] ? omax : hist[j];
-    const float mag_thr = omax * SIFT_ORI_PEAK_RATIO;
-    // the lanes that got this far walk the 36 bins in lockstep: peaks of the same bin index are appended with one
-    // global atomic (the counter is a single address; the list order is arbitrary, the keypoints are sorted later)
+    out->kpt = kpt; out->octv = octv; out->layer = layer; out->r = r; out->c = c;
+    return true;
+}
+
+// Round 4: the refinement used to go on, per THREAD, into calcOrientationHist -- a (2 radius + 1)^2 window of gradient samples added
+// into a 36-bin histogram that lived in scratch memory (a read-modify-write of private memory per sample), run by the few lanes of a
+// wave whose candidates survived the contrast and edge tests: 1.1 ms per 8K frame.  Now the survivors are listed and a WAVE takes
+// one: the samples are evaluated 64 at a time (exp weight, atan2, magnitude), and lane b < 36 keeps bin b in a register, adding
+// the samples of its bin in window order (the sums are order dependent; the order is the CPU loop's).
+__global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, const int4* __restrict__ cand, const unsigned* __restrict__ n_cand, unsigned cand_cap,
+                                                        SiftSurv* __restrict__ surv, unsigned* __restrict__ n_surv, unsigned surv_cap) {
+    const unsigned nc = min(*n_cand, cand_cap);
     const int lane = threadIdx.x & 63;
-    for (int j = 0; j < n; j++) {
-        const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
-        const bool peak = hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr;
-        const unsigned long long m = __ballot(peak);
+    for (unsigned q0 = blockIdx.x * 64; q0 < nc; q0 += gridDim.x * 64) {      // (the wave stays together: the list append is a wave operation)
+        const unsigned q = q0 + threadIdx.x;
+        SiftSurv sv;
+        const bool ok = q < nc && sift_refine_one(P, K, cand[q], &sv);
+        const unsigned long long m = __ballot(ok);
         if (!m) continue;
         const int leader = __ffsll((long long)m) - 1;
         unsigned base = 0;
-        if (lane == leader) base = atomicAdd(n_kps, (unsigned)__popcll(m));
+        if (lane == leader) base = atomicAdd(n_surv, (unsigned)__popcll(m));
         base = __shfl(base, leader);
-        if (peak) {
-            float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
-            bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
-            kpt.angle = 360.f - (float)((360.f / n) * bin);
-            if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
+        if (ok) {
             const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < kp_cap) kps[slot] = kpt;
+            if (slot < surv_cap) surv[slot] = sv;
         }
     }
 }
 
-// grid-stride over the candidate list, whose length only the device knows at launch time
-__global__ __launch_bounds__(64) void sift_refine_kernel(Pyr P, SiftConsts K, const int4* __restrict__ cand, const unsigned* __restrict__ n_cand, unsigned cand_cap,
+// calcOrientationHist + the peaks of the smoothed histogram: one wave per surviving candidate (grid-stride over the list)
+__global__ __launch_bounds__(64) void sift_orient_kernel(Pyr P, const SiftSurv* __restrict__ surv, const unsigned* __restrict__ n_surv, unsigned surv_cap,
                                                         MisKeyPoint* __restrict__ kps, unsigned* __restrict__ n_kps, unsigned kp_cap) {
-    const unsigned nc = min(*n_cand, cand_cap);
-    for (unsigned q = blockIdx.x * 64 + threadIdx.x; q < nc; q += gridDim.x * 64) sift_refine_one(P, K, cand[q], kps, n_kps, kp_cap);
+    const unsigned ns = min(*n_surv, surv_cap);
+    const int lane = threadIdx.x, n = SIFT_ORI_HIST_BINS, nl = P.nl;
+    for (unsigned q = blockIdx.x; q < ns; q += gridDim.x) {
+        const SiftSurv sv = surv[q];
+        MisKeyPoint kpt = sv.kpt;
+        const int octv = sv.octv, r = sv.r, c = sv.c, w = P.w[octv], h = P.h[octv];
+        const float scl_octv = kpt.size * 0.5f / (1 << octv);
+        const int radius = mis_round_f(SIFT_ORI_RADIUS * scl_octv);
+        const float sigma_o = SIFT_ORI_SIG_FCTR * scl_octv, expf_scale = -1.f / (2.f * sigma_o * sigma_o);
+        const float* gimg = P.gauss[octv * (nl + 3) + sv.layer];
+        float th = 0.f;      // bin `lane` of the raw histogram (lanes >= 36: unused)
+        const int side = 2 * radius + 1, total = side * side;
+        int wi = lane / side, wj = lane % side;
+        const int adv_i = 64 / side, adv_j = 64 % side;
+        for (int base = 0; base < total; base += 64) {
+            const int di = wi - radius, dj = wj - radius, y = r + di, x = c + dj;
+            const bool valid = wi < side && y > 0 && y < h - 1 && x > 0 && x < w - 1;
+            float val = 0.f;
+            int bin = 0;
+            if (valid) {
+                const float dx = AT(gimg, y, x + 1) - AT(gimg, y, x - 1), dy = AT(gimg, y - 1, x) - AT(gimg, y + 1, x);
+                const float wgt = mis_expf((di * di + dj * dj) * expf_scale);
+                const float ori = mis_fast_atan2(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                bin = mis_round_f((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                val = wgt * mag;
+            }
+            // the samples of this trip in window order: sample s goes to the lane of its bin
+            unsigned long long m = __ballot(valid);
+            while (m) {
+                const int sl = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int b = __builtin_amdgcn_readlane(bin, sl);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), sl));
+                if (lane == b) th += v;
+            }
+            wi += adv_i; wj += adv_j;
+            if (wj >= side) { wj -= side; wi++; }
+        }
+        // smoothing over the circular histogram, its maximum, the peaks
+        const int jl = lane < n ? lane : 0;
+        const float tm2 = __shfl(th, (jl + n - 2) % n), tm1 = __shfl(th, (jl + n - 1) % n), tp1 = __shfl(th, (jl + 1) % n), tp2 = __shfl(th, (jl + 2) % n);
+        const float hj = (tm2 + tp2) * (1.f / 16.f) + (tm1 + tp1) * (4.f / 16.f) + th * (6.f / 16.f);
+        float omax = lane < n ? hj : -FLT_MAX;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(omax, o); omax = omax > ov ? omax : ov; }
+        const float mag_thr = omax * SIFT_ORI_PEAK_RATIO;
+        const float hl = __shfl(hj, (jl + n - 1) % n), hr = __shfl(hj, (jl + 1) % n);
+        const bool peak = lane < n && hj > hl && hj > hr && hj >= mag_thr;
+        const unsigned long long pm = __ballot(peak);
+        if (!pm) continue;
+        const int leader = __ffsll((long long)pm) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(n_kps, (unsigned)__popcll(pm));
+        base = __shfl(base, leader);
+        if (peak) {
+            float bin = lane + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+            bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
+            kpt.angle = 360.f - (float)((360.f / n) * bin);
+            if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
+            const unsigned slot = base + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
+            if (slot < kp_cap) kps[slot] = kpt;
+        }
+    }
 }
 
 // calcSIFTDescriptor: one wave per keypoint.  The float sums into the (d+2)(d+2)(n+2) histogram are order
@@ -817,7 +860,8 @@ struct MisSift {
     float *tmp = nullptr, *grayf = nullptr;
     int4* cand = nullptr;
     MisKeyPoint* raw = nullptr;
-    unsigned* counters = nullptr;   // [0] candidates, [1] raw keypoints, [2] keypoints after duplicate removal
+    unsigned* counters = nullptr;   // [0] candidates, [1] raw keypoints, [2] keypoints after duplicate removal, [3] candidates that survived the refinement
+    SiftSurv* surv = nullptr;       // ... those candidates (kp_cap entries)
     unsigned* perm = nullptr;       // sorted position -> raw index
     uint8_t* dup = nullptr;         // sorted position -> duplicate of an earlier one
     unsigned* rank = nullptr;       // raw index -> sorted position, and raw index -> duplicate flag (2 x kp_cap, zeroed per frame)
@@ -856,6 +900,7 @@ static int sift_plan(MisSift* s, int w, int h) {
     s->kp_cap = (unsigned)std::max<size_t>(65536, (size_t)bw * bh / 16);
     s->cand = (int4*)carve(sizeof(int4) * s->cand_cap);
     s->raw = (MisKeyPoint*)carve(sizeof(MisKeyPoint) * s->kp_cap);
+    s->surv = (SiftSurv*)carve(sizeof(SiftSurv) * s->kp_cap);
     s->counters = (unsigned*)carve(256);
     s->perm = (unsigned*)carve(sizeof(unsigned) * s->kp_cap);
     s->dup = carve(s->kp_cap);
@@ -992,13 +1037,16 @@ extern "C" int mis_sift_detect(MisSift* s, const MisImage* bgr, MisFeatures* out
             hipLaunchKernelGGL(sift_extrema_generic_kernel, dim3((iw + 255) / 256, ih, nl), dim3(256), 0, st, P, o, threshold, s->cand, s->counters, s->cand_cap);
     }
     const SiftConsts K{(float)s->p.contrast_threshold, (float)s->p.edge_threshold, (float)s->p.sigma};
-    hipLaunchKernelGGL(sift_refine_kernel, dim3(32 * ctx->num_cu), dim3(64), 0, st, P, K, (const int4*)s->cand, (const unsigned*)s->counters, s->cand_cap, s->raw,
+    hipLaunchKernelGGL(sift_refine_kernel, dim3(32 * ctx->num_cu), dim3(64), 0, st, P, K, (const int4*)s->cand, (const unsigned*)s->counters, s->cand_cap, s->surv,
+                       s->counters + 3, s->kp_cap);
+    hipLaunchKernelGGL(sift_orient_kernel, dim3(32 * ctx->num_cu), dim3(64), 0, st, P, (const SiftSurv*)s->surv, (const unsigned*)(s->counters + 3), s->kp_cap, s->raw,
                        s->counters + 1, s->kp_cap);
     // the one mid-frame synchronisation: the raw keypoint count sizes the output block and the grids that follow
-    unsigned counts[3] = {0, 0, 0};
-    MIS_HIP(ctx, hipMemcpyAsync(counts, s->counters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    unsigned counts[4] = {0, 0, 0, 0};
+    MIS_HIP(ctx, hipMemcpyAsync(counts, s->counters, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     MIS_HIP(ctx, hipStreamSynchronize(st));
     MIS_CHECK(ctx, counts[0] <= s->cand_cap, MIS_E_INVALID, "SIFT: %u extrema candidates exceed the capacity %u", counts[0], s->cand_cap);
+    MIS_CHECK(ctx, counts[3] <= s->kp_cap, MIS_E_INVALID, "SIFT: %u refined candidates exceed the capacity %u", counts[3], s->kp_cap);
     MIS_CHECK(ctx, counts[1] <= s->kp_cap, MIS_E_INVALID, "SIFT: %u keypoints exceed the capacity %u", counts[1], s->kp_cap);
     // output block: keypoints + descriptors, sized for the raw count (duplicates only shrink it)
     const int nraw = (int)counts[1];
