@@ -1122,7 +1122,7 @@ template <int ADDS, int W, int A> struct PsEmit {
 };
 template <int ADDS, int W> struct PsEmit<ADDS, W, 45> { static __device__ __forceinline__ void put(const double (&)[10], double*) {} };
 
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
 #define PS_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #define PS_ADD(i, who, a, b) do { if (threadIdx.x == (who)) atomicAdd(&g_jac_prof[i], (b) - (a)); } while (0)
 #else
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void ordered_sums(TailShared& S, int cnt, bool all, i
         else PsEmit<ADDS, 2, 0>::put(r, out);
     };
     PS_T(ps0);
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
     unsigned long long ps_acc = 0, ps_prod = 0, ps_bar = 0;
 #endif
     produce(0);
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void ordered_sums(TailShared& S, int cnt, bool all, i
         PS_T(ps1);
         if (sb + 1 < nsub) produce(sb + 1);
         PS_T(ps2);
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
         ps_prod += ps2 - ps1;
 #endif
         if (accumulate) {
@@ -1203,18 +1203,18 @@ __device__ __forceinline__ void ordered_sums(TailShared& S, int cnt, bool all, i
                 }
             }
         }
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
         asm volatile("" :: "v"(acc));
 #endif
         PS_T(ps3);
         lds_barrier();
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
         ps_acc += ps3 - ps2;
         ps_bar += __builtin_readcyclecounter() - ps3;
 #endif
     }
     PS_T(ps4);
-#if defined(MIS_TAIL_PROF) && !defined(MIS_JAC_PROF)
+#if defined(MIS_TAIL_PROF) && defined(MIS_PS_PROF)
     PS_ADD(0, 44, 0ull, ps_acc);
     PS_ADD(1, 64, 0ull, ps_prod);
     PS_ADD(2, 44, ps0, ps4);

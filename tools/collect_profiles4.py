@@ -9,7 +9,8 @@ src = os.path.join(R, "gpurun_out", "prof4_" + tag)
 dst = os.path.join(R, "profiles")
 cp = [("bench.json", "r04_bench_%s.json"), ("stats/b_kernel_stats.csv", "r04_kernel_stats_%s.csv"), ("roofline/b_kernel_stats.csv", "r04_kernel_stats_%s_roofline_only.csv"),
       ("feed_pmc_summary.txt", "r04_feed_pmc_summary_%s.txt"), ("warp_pmc_summary.txt", "r04_warp_pmc_summary_%s.txt"), ("bench_config5.json", "r04_bench_%s_config5.json"),
-      ("bench_config4_1gpu.json", "r04_bench_%s_config4_1gpu.json"), ("bench_reference.json", "r04_bench_%s_reference.json"), ("bench_plus_seams.json", "r04_bench_%s_hot_path_plus_seams.json")]
+      ("bench_config4_1gpu.json", "r04_bench_%s_config4_1gpu.json"), ("sift_timeline.txt", "r04_sift_timeline_8k_%s.txt"), ("lat_bench.txt", "r04_lat_bench_%s.txt"),
+      ("host_timeline.txt", "r04_chain_stamps_%s.txt"), ("tail_prof.txt", "r04_tail_prof_%s.txt"), ("bench_reference.json", "r04_bench_%s_reference.json"), ("bench_plus_seams.json", "r04_bench_%s_hot_path_plus_seams.json")]
 for a, b in cp:
     for p in (os.path.join(src, a), os.path.join(src, os.path.dirname(a), "*", os.path.basename(a))):
         import glob

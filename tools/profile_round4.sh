@@ -21,5 +21,13 @@ if [ "$2" != "quick" ]; then
   python3 bench.py --pipeline reference --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_reference.json 2> $O/bench_reference.err
   python3 bench.py --pipeline hot_path_plus_seams --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_plus_seams.json 2> $O/bench_plus_seams.err
 fi
+if [ "$2" != "quick" ]; then
+  # SIFT: kernel timeline of one 8K detect; the latency micro-benchmark; the matcher's chain stamps; LAST: the tails' per-section timers (rebuilds the library with -DMIS_TAIL_PROF)
+  bash tools/sift_prof.sh > $O/sift_time.txt 2>&1
+  python3 tools/sift_timeline.py > $O/sift_timeline.txt 2>&1
+  [ -x tools/micro/_bin/lat_bench ] && ./tools/micro/_bin/lat_bench > $O/lat_bench.txt 2>&1
+  MIS_MATCH_TRACE=1 python3 tools/host_timeline.py 10 > $O/host_timeline.txt 2>&1
+  bash tools/run_variant.sh "-DMIS_TAIL_PROF" python3 tools/tail_prof.py > $O/tail_prof.txt 2>&1
+fi
 tail -1 $O/bench.json | cut -c1-300
 for f in bench_config5 bench_config4_1gpu bench_reference bench_plus_seams; do [ -f $O/$f.json ] && tail -1 $O/$f.json | cut -c1-160; done

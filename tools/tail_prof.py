@@ -1,4 +1,5 @@
-"""Section timing of scan_tail_kernel (library built with -DMIS_TAIL_PROF): python tools/tail_prof.py"""
+"""Section timing of scan_tail_kernel (library built with -DMIS_TAIL_PROF; with -DMIS_PS_PROF as well: the stages of ordered_sums, whose
+timers slow the passes down) and one line per tail: python tools/tail_prof.py [full]"""
 import ctypes as C, sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_stitching_amd as isa, synth
