@@ -6,10 +6,12 @@ import torch
 import synth
 import image_stitching_amd as isa
 from image_stitching_amd import distributed as misdist
-cams = synth.workload("config3")
+wl = os.environ.get("MIS_WORKLOAD", "config3")      # MIS_WORKLOAD=config5: 8 x 8K, SIFT
+cams = synth.workload(wl)
 ctx = isa.Context(0)
-cfg = isa.StitchConfig() if os.environ.get("MIS_PIPELINE") in ("reference_default", "hot_path_plus_seams") else isa.StitchConfig.hot_path()
-job = misdist.StitchJob(ctx, (3840, 2160), cams, config=cfg)
+feat = "sift" if wl == "config5" else "orb"
+cfg = isa.StitchConfig(features_type=feat) if os.environ.get("MIS_PIPELINE") in ("reference_default", "hot_path_plus_seams") else isa.StitchConfig.hot_path(features_type=feat)
+job = misdist.StitchJob(ctx, (cams[0]["width"], cams[0]["height"]), cams, config=cfg)
 frames = {i: synth.render_frame_gpu(cams[i]) for i in job.my_frames}
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
