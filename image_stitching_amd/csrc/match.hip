@@ -1026,6 +1026,10 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
         HomoSync sy;
         if (compose_gate == 2 || compose_gate == 3) { sy.rec = ws->ev_draw1; sy.rec_pos = compose_gate - 2; ws->ev_gate = ws->ev_draw1; }
         if (hyp_order) sy.wait_hyp1 = ws->ev_side_hyp0;
+        if (trace_ev && !sy.rec) {      // diagnostics: the end of the main chain's second draw
+            if (!ws->tev[7]) hipEventCreate(&ws->tev[7]);
+            sy.rec = ws->tev[7]; sy.rec_pos = 0;
+        }
         if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 6, st, &sy)) != MIS_OK) return rc;
     }
     if ((rc = homo_batch_run(ctx, &ws->b1, rt, p->max_iters, cf, 12, st)) != MIS_OK) return rc;
@@ -1183,8 +1187,9 @@ int match_impl(MisContext* ctx, const MisFeatures* feats, int n, const MisMatchP
             float e1 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0;
             hipEventElapsedTime(&e1, ws->tev[0], ws->tev[1]); hipEventElapsedTime(&e3, ws->tev[0], ws->tev[3]); hipEventElapsedTime(&e4, ws->tev[0], ws->tev[4]);
             hipEventElapsedTime(&e5, ws->tev[0], ws->tev[5]); hipEventElapsedTime(&e6, ws->tev[0], ws->tev[6]);
-            float e2 = 0;
+            float e2 = 0, e7 = 0;
             if (ws->tev[2]) hipEventElapsedTime(&e2, ws->tev[0], ws->tev[2]);
+            if (ws->tev[7]) { hipEventElapsedTime(&e7, ws->tev[0], ws->tev[7]); fprintf(stderr, "match chains: main chain's second draw done %.2f\n", e7); }
             fprintf(stderr, "match chains, ms after the 2-NN pass was enqueued-behind (device events): first phase done %.2f | tails of its finishers done %.2f | main chain: second RANSAC phase done %.2f, done %.2f | side chain done %.2f | third chain done %.2f\n", e1, e6, e2, e3, e4, e5);
         }
     }

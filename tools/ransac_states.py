@@ -18,3 +18,6 @@ for which in (0, 1):
     print("  mode counts:", np.bincount(st[:, 1], minlength=3).tolist(), " iter>128:", int((st[:, 3] > 128).sum()), " n_sub hist:", np.histogram(st[:, 2], bins=[0, 1, 64, 128, 129, 1000, 2001])[0].tolist())
     small = st[(st[:, 0] > 0) & (st[:, 0] < 12)]
     print("  problems with n < 12:", small.tolist()[:20])
+    if which == 0:      # round 4: who needs the second phase?  (n, iterations run) of every problem, by n
+        order = np.argsort(st[:, 0])
+        print("  first estimation, (n, iter) sorted by n:", [(int(st[i, 0]), int(st[i, 3])) for i in order])
