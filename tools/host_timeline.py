@@ -10,7 +10,9 @@ wl = os.environ.get("MIS_WORKLOAD", "config3")      # MIS_WORKLOAD=config5: 8 x 
 cams = synth.workload(wl)
 ctx = isa.Context(0)
 feat = "sift" if wl == "config5" else "orb"
-cfg = isa.StitchConfig(features_type=feat) if os.environ.get("MIS_PIPELINE") in ("reference_default", "hot_path_plus_seams") else isa.StitchConfig.hot_path(features_type=feat)
+pl = os.environ.get("MIS_PIPELINE", "hot_path")      # hot_path | hot_path_plus_seams | reference (bench.py's --pipeline)
+cfg = {"hot_path": lambda: isa.StitchConfig.hot_path(features_type=feat), "hot_path_plus_seams": lambda: isa.StitchConfig(features_type=feat, compose_megapix=-1),
+       "reference_default": lambda: isa.StitchConfig(features_type=feat, compose_megapix=-1), "reference": lambda: isa.StitchConfig.reference(features_type=feat)}[pl]()
 job = misdist.StitchJob(ctx, (cams[0]["width"], cams[0]["height"]), cams, config=cfg)
 frames = {i: synth.render_frame_gpu(cams[i]) for i in job.my_frames}
 torch.cuda.synchronize()

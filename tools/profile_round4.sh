@@ -7,6 +7,13 @@ tag=${1:-a}
 O=$R/gpurun_out/prof4_$tag
 rm -rf $O && mkdir -p $O
 cd $R && BENCH_TRACE=1 python3 bench.py > $O/bench.json 2> $O/bench.err
+# (the plain bench runs first: after the PMC passes a box keeps the profiling clock state for a while -- config 5 then measured 160 - 260 ms per step instead of 83)
+if [ "$2" != "quick" ]; then
+  BENCH_TRACE=1 python3 bench.py --workload config5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
+  python3 bench.py --workload config4 --steps 3 --warmup 1 --no-cpu-baseline --no-cpp-host > $O/bench_config4_1gpu.json 2> $O/bench_config4_1gpu.err
+  python3 bench.py --pipeline reference --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_reference.json 2> $O/bench_reference.err
+  python3 bench.py --pipeline hot_path_plus_seams --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_plus_seams.json 2> $O/bench_plus_seams.err
+fi
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cpp-host > $O/stats.log 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -o b -- python3 $R/bench.py --roofline-only > $O/roofline.log 2>&1 )
 cd $R
@@ -15,12 +22,6 @@ python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/feed_pm
 python3 tools/pmc_json.py gpurun_out/pmcf_fetch gpurun_out/pmcf_write $O/finalize_pmc.json 2 normalize_kernel collapse2x2_kernel collapse2x2_final_kernel > /dev/null
 bash tools/pmc_warp3.sh full > $O/warp_pmc_summary.txt 2>&1
 python3 tools/pmc_json.py gpurun_out/pmc3_fetch gpurun_out/pmc3_write $O/warp_pmc_raw.json 1 warp_fused_kernel warp_strip_batch_kernel > /dev/null
-if [ "$2" != "quick" ]; then
-  BENCH_TRACE=1 python3 bench.py --workload config5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
-  python3 bench.py --workload config4 --steps 3 --warmup 1 --no-cpu-baseline --no-cpp-host > $O/bench_config4_1gpu.json 2> $O/bench_config4_1gpu.err
-  python3 bench.py --pipeline reference --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_reference.json 2> $O/bench_reference.err
-  python3 bench.py --pipeline hot_path_plus_seams --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_plus_seams.json 2> $O/bench_plus_seams.err
-fi
 if [ "$2" != "quick" ]; then
   # SIFT: kernel timeline of one 8K detect; the latency micro-benchmark; the matcher's chain stamps; LAST: the tails' per-section timers (rebuilds the library with -DMIS_TAIL_PROF)
   bash tools/sift_prof.sh > $O/sift_time.txt 2>&1
