@@ -380,7 +380,8 @@ __device__ __forceinline__ void l2_tile_update(const float16v& acc, const float 
     }
 }
 #ifndef K8_WG_PER_CU
-#define K8_WG_PER_CU 2
+#define K8_WG_PER_CU 1      // round 4: 2 -> 1 (at 24 k x 24 k: 4 train slices / 376 workgroups instead of 8 / 752 -- every slice restarts the search bound, and
+                            // 752 workgroups on 512 slots left a quarter of the second round empty: config 5 81.8 -> 80.6 ms per step)
 #endif
 #ifndef K8_SUB
 #define K8_SUB 1
