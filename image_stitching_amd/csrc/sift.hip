@@ -868,9 +868,10 @@ struct MisSift {
     unsigned cand_cap = 0, kp_cap = 0;
     double sig[MAX_LAYERS + 4];
     // second lane of mis_sift_detect_batch: a finder of its own on its own context / stream, driven by a host thread
-    MisSift* helper = nullptr;
-    MisContext* helper_ctx = nullptr;
-    void* helper_stream = nullptr;
+    static constexpr int MAX_LANES = 4;
+    MisSift* helper[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};          // [k], k >= 1: lane k of mis_sift_detect_batch
+    MisContext* helper_ctx[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    void* helper_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};       // streams this finder created (lanes beyond the context's two auxiliary streams)
 };
 
 static int sift_plan(MisSift* s, int w, int h) {
@@ -945,9 +946,11 @@ extern "C" int mis_sift_create(MisContext* ctx, const MisSiftParams* params, int
 
 extern "C" int mis_sift_destroy(MisSift* s) {
     if (!s) return MIS_OK;
-    if (s->helper) { mis_sift_destroy(s->helper); s->helper = nullptr; }
-    if (s->helper_ctx) { mis_context_destroy(s->helper_ctx); s->helper_ctx = nullptr; }
-    if (s->helper_stream) { mis_stream_destroy(s->helper_stream); s->helper_stream = nullptr; }
+    for (int k = 1; k < MisSift::MAX_LANES; k++) {
+        if (s->helper[k]) { mis_sift_destroy(s->helper[k]); s->helper[k] = nullptr; }
+        if (s->helper_ctx[k]) { mis_context_destroy(s->helper_ctx[k]); s->helper_ctx[k] = nullptr; }
+        if (s->helper_stream[k]) { mis_stream_destroy(s->helper_stream[k]); s->helper_stream[k] = nullptr; }
+    }
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     if (s->mem) hipFree(s->mem);
@@ -1098,37 +1101,46 @@ extern "C" int mis_sift_debug_level(MisSift* s, const MisImage* bgr, int octave,
     return mis_dev_image_release(ctx, &din);
 }
 
-// Several frames: two lanes (this finder and a helper with its own scale space, context and stream), one host thread
-// each, frame i on lane i % 2.  A frame's kernels are partly bandwidth bound (the blurs) and partly latency bound (one
-// thread or wave per keypoint, two host synchronisations), so two frames in flight keep the device busier than one.
+// Several frames: up to four lanes (this finder and helpers with their own scale space, context and stream), one host thread
+// each, frame i on lane i % lanes.  A frame's kernels are partly bandwidth bound (the blurs) and partly latency bound (the fifty
+// small layers of octaves >= 2, one wave per keypoint, two host synchronisations), so several frames in flight keep the device
+// busier than one: config 5's eight 8K frames take 54 ms on two lanes (round 3) and (round 4, MIS_SIFT_LANES, default 3) less on three.
 extern "C" int mis_sift_detect_batch(MisSift* s, const MisImage* imgs, int n, MisFeatures* out) {
     if (!s) return MIS_E_INVALID;
     MisContext* ctx = s->ctx;
     MIS_CHECK(ctx, imgs && out && n >= 1, MIS_E_INVALID, "null argument");
     if (n == 1) return mis_sift_detect(s, imgs, out);
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    if (!s->helper) {
-        hipStream_t aux = nullptr;       // the second lane runs on the context's first auxiliary stream (shared with the matcher, which runs later)
-        int rc = mis_aux_stream(ctx, 0, &aux);
-        if (rc == MIS_OK) rc = mis_context_create(ctx->device, (void*)aux, &s->helper_ctx);
-        if (rc == MIS_OK) rc = mis_sift_create(s->helper_ctx, &s->p, s->max_w, s->max_h, &s->helper);
-        if (rc != MIS_OK) return mis_set_error(ctx, rc, "SIFT batch: cannot create the second lane (%s)", s->helper_ctx ? s->helper_ctx->err.c_str() : "stream / context");
+    static const int want = getenv("MIS_SIFT_LANES") ? atoi(getenv("MIS_SIFT_LANES")) : 3;
+    const int nl = std::max(1, std::min({want, n, MisSift::MAX_LANES}));
+    for (int k = 1; k < nl; k++) {
+        if (s->helper[k]) continue;
+        // lanes 1 and 2 run on the context's auxiliary streams (shared with the matcher, which runs later), lane 3 on a stream of its own
+        hipStream_t st = nullptr;
+        int rc = MIS_OK;
+        if (k <= 2) rc = mis_aux_stream(ctx, k - 1, &st);
+        else { rc = mis_stream_create(ctx->device, 0, &s->helper_stream[k]); st = (hipStream_t)s->helper_stream[k]; }
+        if (rc == MIS_OK) rc = mis_context_create(ctx->device, (void*)st, &s->helper_ctx[k]);
+        if (rc == MIS_OK) rc = mis_sift_create(s->helper_ctx[k], &s->p, s->max_w, s->max_h, &s->helper[k]);
+        if (rc != MIS_OK) return mis_set_error(ctx, rc, "SIFT batch: cannot create lane %d (%s)", k, s->helper_ctx[k] ? s->helper_ctx[k]->err.c_str() : "stream / context");
     }
-    // the frames' producers were enqueued on the context's stream; the helper's stream does not see them otherwise
+    // the frames' producers were enqueued on the context's stream; the helpers' streams do not see them otherwise
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MisSift* lanes[2] = {s, s->helper};
-    int rcs[2] = {MIS_OK, MIS_OK};
+    MisSift* lanes[MisSift::MAX_LANES] = {s, s->helper[1], s->helper[2], s->helper[3]};
+    int rcs[MisSift::MAX_LANES] = {MIS_OK, MIS_OK, MIS_OK, MIS_OK};
     auto work = [&](int lane) {
-        for (int i = lane; i < n; i += 2) {
+        for (int i = lane; i < n; i += nl) {
             const int rc = mis_sift_detect(lanes[lane], &imgs[i], &out[i]);
             if (rc != MIS_OK) { rcs[lane] = rc; return; }
             out[i].img_idx = i;
         }
     };
-    std::thread t1(work, 1);
+    std::vector<std::thread> th;
+    for (int k = 1; k < nl; k++) th.emplace_back(work, k);
     work(0);
-    t1.join();
+    for (auto& t : th) t.join();
     if (rcs[0] != MIS_OK) return rcs[0];
-    if (rcs[1] != MIS_OK) return mis_set_error(ctx, rcs[1], "SIFT batch, second lane: %s", s->helper_ctx->err.c_str());
+    for (int k = 1; k < nl; k++)
+        if (rcs[k] != MIS_OK) return mis_set_error(ctx, rcs[k], "SIFT batch, lane %d: %s", k, s->helper_ctx[k]->err.c_str());
     return MIS_OK;
 }
