@@ -43,6 +43,8 @@ int mis_host_stage(MisContext* ctx, size_t bytes, void** out);   // pinned scrat
 int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got);
 int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out);   // k = 0, 1
 void mis_pool_free(MisContext* ctx, void* p, size_t bytes);
+// a device block for a feature set from ctx's pool of recycled blocks, registered so that mis_features_free recycles it (orb.hip)
+int mis_feat_block_alloc(MisContext* ctx, size_t bytes, void** out);
 
 #define MIS_HIP(ctx, call)                                                                             \
     do {                                                                                               \

@@ -1,5 +1,6 @@
 // context.hip -- MisContext: device + stream + error text, image staging helpers.
 #include "common.h"
+#include <mutex>
 #include <stdarg.h>
 
 int mis_set_error(MisContext* ctx, int code, const char* fmt, ...) {
@@ -12,8 +13,10 @@ int mis_set_error(MisContext* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+static std::mutex g_pool_mutex;      // (the SIFT batch's lanes allocate their output blocks from the caller's context on several host threads)
 int mis_pool_alloc(MisContext* ctx, size_t bytes, void** out, size_t* got) {
     // best fit among the recycled blocks (at most 2x the request), else a fresh allocation
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     int best = -1;
     for (int i = 0; i < (int)ctx->pool.size(); i++)
         if (ctx->pool[i].first >= bytes && ctx->pool[i].first <= 2 * bytes && (best < 0 || ctx->pool[i].first < ctx->pool[best].first)) best = i;
@@ -54,6 +57,7 @@ int mis_aux_stream(MisContext* ctx, int k, hipStream_t* out) {
 
 void mis_pool_free(MisContext* ctx, void* p, size_t bytes) {
     // stream-ordered reuse: every consumer of the block was enqueued on ctx->stream before this call
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     if (p) ctx->pool.emplace_back(bytes, p);
 }
 

@@ -1290,6 +1290,17 @@ int orb_ensure_frames(MisOrb* o, int frames) {
 
 }  // namespace
 
+// (common.h) a device block for a feature set from ctx's pool, registered so that mis_features_free recycles it: the SIFT finders' outputs
+int mis_feat_block_alloc(MisContext* ctx, size_t bytes, void** out) {
+    size_t got = 0;
+    const int rc = mis_pool_alloc(ctx, bytes, out, &got);
+    if (rc != MIS_OK) return rc;
+    std::lock_guard<std::mutex> lock(g_feat_mutex);
+    g_feat_sizes[*out] = got;
+    return MIS_OK;
+}
+
+
 extern "C" void mis_orb_default_params(MisOrbParams* p) {
     if (p) *p = MisOrbParams{4000, 1.2f, 8, 1, 0, 2, 0, 40, 20};
 }

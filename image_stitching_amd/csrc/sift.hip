@@ -868,6 +868,7 @@ struct MisSift {
     unsigned cand_cap = 0, kp_cap = 0;
     double sig[MAX_LAYERS + 4];
     // second lane of mis_sift_detect_batch: a finder of its own on its own context / stream, driven by a host thread
+    MisContext* pool_ctx = nullptr;       // a helper lane's output blocks come from (and go back to) the parent's context
     static constexpr int MAX_LANES = 4;
     MisSift* helper[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};          // [k], k >= 1: lane k of mis_sift_detect_batch
     MisContext* helper_ctx[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -1056,8 +1057,10 @@ extern "C" int mis_sift_detect(MisSift* s, const MisImage* bgr, MisFeatures* out
     memset(out, 0, sizeof(*out));
     out->img_w = bgr->width; out->img_h = bgr->height; out->desc_cols = 128; out->desc_dtype = MIS_F32;
     const size_t kb = mis_align_up(sizeof(MisKeyPoint) * (size_t)std::max(nraw, 1), 256), db = sizeof(float) * 128 * (size_t)std::max(nraw, 1);
+    // (from the pool of recycled feature blocks: a hipMalloc / hipFree pair per frame synchronises the device -- with three frames in
+    // flight every few steps of config 5 took 160 - 360 ms instead of 78)
     uint8_t* blk = nullptr;
-    MIS_HIP(ctx, hipMalloc((void**)&blk, kb + db));
+    if ((rc = mis_feat_block_alloc(s->pool_ctx ? s->pool_ctx : ctx, kb + db, (void**)&blk)) != MIS_OK) return rc;
     out->owner_ = blk; out->keypoints = (MisKeyPoint*)blk; out->descriptors = blk + kb;
     if (nraw) {
         // KeyPointsFilter::removeDuplicatedSorted (a total order, so the atomics' append order never shows) + the
@@ -1122,6 +1125,7 @@ extern "C" int mis_sift_detect_batch(MisSift* s, const MisImage* imgs, int n, Mi
         else { rc = mis_stream_create(ctx->device, 0, &s->helper_stream[k]); st = (hipStream_t)s->helper_stream[k]; }
         if (rc == MIS_OK) rc = mis_context_create(ctx->device, (void*)st, &s->helper_ctx[k]);
         if (rc == MIS_OK) rc = mis_sift_create(s->helper_ctx[k], &s->p, s->max_w, s->max_h, &s->helper[k]);
+        if (rc == MIS_OK) s->helper[k]->pool_ctx = ctx;
         if (rc != MIS_OK) return mis_set_error(ctx, rc, "SIFT batch: cannot create lane %d (%s)", k, s->helper_ctx[k] ? s->helper_ctx[k]->err.c_str() : "stream / context");
     }
     // the frames' producers were enqueued on the context's stream; the helpers' streams do not see them otherwise
