@@ -92,8 +92,8 @@ def test_sift_features_feed_the_l2_matcher(ctx, oracle_mod):
 
 
 def test_batch_of_frames_equals_single_calls(ctx):
-    """mis_sift_detect_batch keeps two frames in flight (second lane: own scale space, stream and host thread);
-    results and their order must be those of one call per frame.  Device and host inputs."""
+    """mis_sift_detect_batch keeps several frames in flight (three lanes by default; every lane: own scale space, stream and host
+    thread, output blocks from the caller's pool); results and their order must be those of one call per frame.  Device and host inputs."""
     import torch
     import image_stitching_amd as isa
     w, h = 480, 270
@@ -108,3 +108,45 @@ def test_batch_of_frames_equals_single_calls(ctx):
             assert len(kb) == len(ks) and len(ks) > 100
             assert kb.tobytes() == ks.tobytes() and np.array_equal(db, ds)
     assert f.detect_batch([]) == []
+
+
+_LANES_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import synth, image_stitching_amd as isa
+ctx = isa.Context(0)
+w, h = 640, 360
+frames = [synth.render_frame_gpu(synth.make_camera(w, h, 60.0, 10.0 * k)) for k in range(7)]
+f = isa.SiftFeatureFinder(ctx, (w, h))
+out = {}
+for rep in range(2):      # the second batch reuses the recycled output blocks of the first
+    batch = f.detect_batch(frames)
+    for i, b in enumerate(batch):
+        k, d = b.download()
+        out["k%d_%d" % (rep, i)] = np.frombuffer(k.tobytes(), np.uint8); out["d%d_%d" % (rep, i)] = d
+    del batch
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_batch_lanes_one_to_four_give_identical_features(tmp_path):
+    """MIS_SIFT_LANES = 1, 3 (the default) and 4: seven frames, two batches each (the second on recycled output blocks): every
+    keypoint and descriptor byte for byte.  The switch is read once per process, hence child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for lanes in ("1", "3", "4"):
+        path = str(tmp_path / ("lanes%s.npz" % lanes))
+        r = subprocess.run([sys.executable, "-c", _LANES_SCRIPT, root, path], env=dict(os.environ, MIS_SIFT_LANES=lanes), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(path))
+    a = outs[0]
+    assert len(a.files) == 28 and all(a["k0_%d" % i].size > 24 * 50 for i in range(7))
+    for b in outs[1:]:
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+    for i in range(7):
+        assert a["k0_%d" % i].tobytes() == a["k1_%d" % i].tobytes() and a["d0_%d" % i].tobytes() == a["d1_%d" % i].tobytes()
