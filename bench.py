@@ -536,13 +536,26 @@ def cpp_host_leg(cams, args, world=1, rehearsal=False):
             cmd = [exe, path, "--steps", str(args.steps), "--warmup", str(args.warmup)]
             if world > 1:
                 cmd += ["--ranks", str(world)] + (["--comm", "host", "--one-gpu"] if rehearsal else ["--comm", "rccl"])
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        except subprocess.TimeoutExpired:
-            return {"error": "host/stitch_bench timed out"}
-    if r.returncode != 0:
-        return {"error": (r.stdout + r.stderr)[-300:]}
+            # a session of its own: on a timeout the whole group goes (the launcher's rank children hold GPUs); the sharded leg has never run
+            # on more than one device, so it gets two minutes, not ten -- the ranks of this script wait at a barrier
+            import signal
+            limit = 600 if world == 1 else 120
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=limit)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
+                return {"error": "host/stitch_bench timed out after %d s" % limit}
+        except OSError as e:
+            return {"error": "host/stitch_bench: %s" % e}
+    if proc.returncode != 0:
+        return {"error": (so + se)[-300:]}
     try:
-        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+        return json.loads([l for l in so.strip().splitlines() if l.startswith("{")][-1])
     except (ValueError, IndexError):
         return {"error": "no result line from host/stitch_bench"}
 
