@@ -223,6 +223,7 @@ struct LevMarq {
     double epsilon, prevErrNorm = DBL_MAX, errNorm = 0;
     std::vector<double> param, prevParam, err, JtErr;
     Mat J, JtJ;
+    std::vector<std::vector<std::pair<int, int>>> col_rows;      // optional: per column of J, the row ranges [first, second) that can be non-zero
     LevMarq(int np, int ne, int maxit, double eps) : nparams(np), nerrs(ne), max_iter(maxit), epsilon(eps), param(np, 0.), prevParam(np, 0.), err(ne, 0.), JtErr(np, 0.), J(ne, np), JtJ(np, np) {}
     void step() {
         const double lambda = std::exp(lambdaLg10 * std::log(10.));
@@ -261,10 +262,32 @@ struct LevMarq {
             return true;
         }
         if (state == CALC_J) {
-            // JtJ = J^T J (upper triangle), JtErr = J^T err: every entry the same sequential sum over the rows of J as before, read from
-            // a transposed copy (J's columns are 8 nparams bytes apart: the 6 000 column pairs of 16 cameras streamed 150 k strided
-            // rows each), one row of JtJ per host thread
-            {
+            // JtJ = J^T J (upper triangle), JtErr = J^T err: every entry the same sequential sum over the rows of J as before, one row of
+            // JtJ per host thread.  col_rows (set by the caller): per column the row ranges outside which the column is exactly zero -- a
+            // camera's parameters only move the errors of the pairs the camera is part of, and a central difference of two identical
+            // evaluations is +0 --; a product with such a zero is +-0 and adding it leaves a sum that is not -0 unchanged, so the sums
+            // walk the intersection of the two columns' ranges only (16 cameras: 60 x fewer terms).  Without col_rows: all rows, read
+            // from a transposed copy (J's columns are 8 nparams bytes apart).
+            if (!col_rows.empty()) {
+                ba_parallel_for(nparams, [&](int i) {
+                    const auto& ri = col_rows[i];
+                    for (int j = i; j < nparams; j++) {
+                        const auto& rj = col_rows[j];
+                        double s = 0;
+                        size_t a = 0, b = 0;
+                        while (a < ri.size() && b < rj.size()) {      // sorted, disjoint ranges: their intersection in row order
+                            const int lo = std::max(ri[a].first, rj[b].first), hi = std::min(ri[a].second, rj[b].second);
+                            for (int k = lo; k < hi; k++) s += J(k, i) * J(k, j);
+                            if (ri[a].second < rj[b].second) a++; else b++;
+                        }
+                        JtJ(i, j) = s;
+                    }
+                    double s = 0;
+                    for (const auto& r : ri)
+                        for (int k = r.first; k < r.second; k++) s += J(k, i) * err[k];
+                    JtErr[i] = s;
+                });
+            } else {
                 const size_t ne = (size_t)nerrs;
                 std::vector<double> Jt((size_t)nparams * ne);
                 ba_parallel_for(nparams, [&](int i) { double* o = Jt.data() + (size_t)i * ne; for (int k = 0; k < nerrs; k++) o[k] = J(k, i); });
@@ -320,11 +343,22 @@ struct Adjuster {
     std::vector<double> cam;              // 7 per camera: focal, ppx, ppy, aspect, rvec
     uint8_t refine[5] = {1, 1, 1, 1, 1};   // focal, skew (unused), ppx, aspect, ppy  -- ba_refine_mask "xxxxx"
 
-    void calc_error(std::vector<double>& err) const { calc_error_at(cam, err); }
-    void calc_error_at(const std::vector<double>& cam, std::vector<double>& err) const {
-        err.assign((size_t)total * 2, 0.);
+    std::vector<int> edge_m;                  // first observation of every edge (set by index_edges)
+    std::vector<std::vector<int>> cam_edges;  // per camera: the edges it is part of, ascending
+    void index_edges() {
+        edge_m.assign(edges.size(), 0);
+        cam_edges.assign(n, {});
         int m = 0;
-        for (size_t e = 0; e < edges.size(); e++) {
+        for (size_t e = 0; e < edges.size(); e++) { edge_m[e] = m; m += (int)obs[e].size(); cam_edges[edges[e].i].push_back((int)e); cam_edges[edges[e].j].push_back((int)e); }
+    }
+    void calc_error(std::vector<double>& err) const { calc_error_at(cam, err, nullptr); }
+    // only: the edges to evaluate (the other rows of err are left as they are); nullptr: all, err is resized and zeroed first
+    void calc_error_at(const std::vector<double>& cam, std::vector<double>& err, const std::vector<int>* only) const {
+        if (!only) err.assign((size_t)total * 2, 0.);
+        const size_t ne = only ? only->size() : edges.size();
+        for (size_t q = 0; q < ne; q++) {
+            const size_t e = only ? (size_t)(*only)[q] : q;
+            int m = edge_m[e];
             const int i = edges[e].i, j = edges[e].j;
             const double f1 = cam[i * 7], f2 = cam[j * 7], ppx1 = cam[i * 7 + 1], ppx2 = cam[j * 7 + 1], ppy1 = cam[i * 7 + 2], ppy2 = cam[j * 7 + 2];
             const double a1 = cam[i * 7 + 3], a2 = cam[j * 7 + 3];
@@ -349,13 +383,17 @@ struct Adjuster {
         // columns: 0 focal, 1 ppx, 2 ppy, 3 aspect, 4..6 rotation; refinement mask positions (0,0) (0,2) (1,2) (1,1).  A column is a pair
         // of error evaluations at its own perturbed copy of the cameras: one column per host thread at a time
         const bool on[7] = {(bool)refine[0], (bool)refine[2], (bool)refine[4], (bool)refine[3], true, true, true};
+        // (only the rows of the pairs the column's camera is part of are evaluated and written: elsewhere the two evaluations are
+        // identical, their difference is +0, and J was zeroed by the solver before this call)
         ba_parallel_for(7 * n, [&](int col) {
             if (!on[col % 7]) return;
-            std::vector<double> c = cam, e1, e2;
+            const std::vector<int>& mine = cam_edges[col / 7];
+            std::vector<double> c = cam, e1((size_t)total * 2), e2((size_t)total * 2);
             const double val = c[col];
-            c[col] = val - step; calc_error_at(c, e1);
-            c[col] = val + step; calc_error_at(c, e2);
-            for (int k = 0; k < J.r; k++) J(k, col) = (e2[k] - e1[k]) / (2 * step);
+            c[col] = val - step; calc_error_at(c, e1, &mine);
+            c[col] = val + step; calc_error_at(c, e2, &mine);
+            for (int e : mine)
+                for (int k = 2 * edge_m[e]; k < 2 * (edge_m[e] + (int)obs[e].size()); k++) J(k, col) = (e2[k] - e1[k]) / (2 * step);
         });
     }
 };
@@ -505,8 +543,24 @@ extern "C" int mis_bundle_adjust_reproj(MisContext* ctx, const MisFeatures* feat
             ad.obs.push_back(std::move(ob));
         }
     MIS_CHECK(ctx, ad.total > 0, MIS_E_INVALID, "bundle adjustment: no image pair above the confidence threshold");
+    ad.index_edges();
     LevMarq solver(n * 7, ad.total * 2, 1000, DBL_EPSILON);   // TermCriteria(EPS + COUNT, 1000, DBL_EPSILON)
     solver.param = ad.cam;
+    {
+        // the rows of an edge (two per observation, in edge order) depend on the parameters of its two cameras only
+        std::vector<std::vector<std::pair<int, int>>> cam_rows(n);
+        int row = 0;
+        for (size_t e = 0; e < ad.edges.size(); e++) {
+            const int r1 = row + 2 * (int)ad.obs[e].size();
+            for (int c : {ad.edges[e].i, ad.edges[e].j}) {
+                auto& v = cam_rows[c];
+                if (!v.empty() && v.back().second == row) v.back().second = r1; else v.emplace_back(row, r1);
+            }
+            row = r1;
+        }
+        solver.col_rows.resize((size_t)n * 7);
+        for (int c = 0; c < n; c++) for (int j = 0; j < 7; j++) solver.col_rows[c * 7 + j] = cam_rows[c];
+    }
     const bool trace = getenv("MIS_BA_TRACE") != nullptr;
     for (;;) {
         bool want_J, want_err;
