@@ -159,13 +159,15 @@ def main():
         roof = measure_roofline(ctx, job, frames, cams, args.roofline_launches)
         print(json.dumps({"roofline": roof}), flush=True)
         return
-    for _ in range(args.warmup):
-        out = step()          # same object lifetimes as the timed loop: the allocators reach their steady state here
     # the interpreter's cyclic garbage collector is paused for the timed region (as timeit does): a full collection
-    # walks every torch / ctypes object and costs ~40 ms, twice the step being measured
+    # walks every torch / ctypes object and costs ~40 ms, eight times the step being measured.  It is run and paused BEFORE the warm-up
+    # steps: behind them it left the device idle for those 40 ms right in front of the timed region, and the first two or three timed
+    # steps then ran 0.3 - 0.6 ms slower (5.5, 5.25, 4.95 ... against 4.8)
     import gc
     gc.collect()
     gc.disable()
+    for _ in range(args.warmup):
+        out = step()          # same object lifetimes as the timed loop: the allocators reach their steady state here
     barrier()
     trace = []
     t0 = time.perf_counter()
