@@ -162,7 +162,7 @@ class HipEngine:
         # latency-bound RANSAC chains of the matcher leave most of the device idle
         # (normal priority: a low-priority stream was measured -- the compose work then finishes after the matcher, 20.1 ms)
         h = C.c_void_p()
-        ctx.check(ctx.lib.mis_stream_create(ctx.device.index, 0, C.byref(h)))
+        ctx.check(ctx.lib.mis_stream_create(ctx.device.index, int(os.environ.get('MIS_COMPOSE_PRIO', '0')), C.byref(h)))      # (MIS_COMPOSE_PRIO > 0: the least urgent priority -- measured in round 4, eight runs of 150 steps: no difference)
         self._compose_stream_handle = h
         self.compose_stream = torch.cuda.ExternalStream(h.value, device=ctx.device)
         self.cctx = st.Context(ctx.device.index, stream=h.value)
